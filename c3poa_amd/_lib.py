@@ -1,0 +1,246 @@
+"""ctypes binding of the HIP backend (c3poa_amd/lib/libc3poa_hip.so, C ABI in include/c3poa.h).
+
+There is NO CPU fallback: importing this module without the built library, or creating a handle
+without an MI355X, raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libc3poa_hip.so")
+MAX_PEAKS = 256
+
+STAGE_CONK, STAGE_PEAKS, STAGE_POA, STAGE_POLISH, STAGES_ALL = 1, 2, 4, 8, 15
+ST_OK, ST_NOT_ASSIGNED, ST_NO_PEAKS, ST_NO_CONSENSUS, ST_TOO_SHORT, ST_LIMIT = range(6)
+
+EXPORTS = ["c3_default_config", "c3_version", "c3_create", "c3_destroy", "c3_last_error", "c3_set_splints",
+           "c3_batch_upload", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_timing",
+           "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
+           "c3_poa_msa", "c3_determine_consensus"]
+
+
+class Config(C.Structure):
+    _fields_ = ([("device", C.c_int), ("conk_match", C.c_int), ("conk_mismatch", C.c_int), ("conk_penalty", C.c_int),
+                 ("sg_iters", C.c_int), ("sg_window", C.c_int), ("sg_order", C.c_int), ("mdistcutoff", C.c_int),
+                 ("poa_match", C.c_int), ("poa_mismatch", C.c_int), ("poa_o1", C.c_int), ("poa_e1", C.c_int),
+                 ("poa_o2", C.c_int), ("poa_e2", C.c_int), ("poa_band_b", C.c_int), ("poa_band_f", C.c_double),
+                 ("pol_match", C.c_int), ("pol_mismatch", C.c_int), ("pol_gap", C.c_int), ("pol_window", C.c_int),
+                 ("pol_q", C.c_int), ("dang_band", C.c_int), ("slots_poa", C.c_int), ("slots_win", C.c_int)])
+
+
+class ReadResult(C.Structure):
+    _fields_ = [("status", C.c_int32), ("n_peaks", C.c_int32), ("n_sub", C.c_int32), ("has_front", C.c_int32),
+                ("has_tail", C.c_int32), ("front_end", C.c_int32), ("tail_beg", C.c_int32), ("cons_len", C.c_int32),
+                ("draft_len", C.c_int32), ("n_win", C.c_int32), ("peaks", C.c_int32 * MAX_PEAKS),
+                ("sub_beg", C.c_int32 * MAX_PEAKS), ("sub_end", C.c_int32 * MAX_PEAKS)]
+
+
+RESULT_DTYPE = np.dtype([("status", "<i4"), ("n_peaks", "<i4"), ("n_sub", "<i4"), ("has_front", "<i4"),
+                         ("has_tail", "<i4"), ("front_end", "<i4"), ("tail_beg", "<i4"), ("cons_len", "<i4"),
+                         ("draft_len", "<i4"), ("n_win", "<i4"), ("peaks", "<i4", (MAX_PEAKS,)),
+                         ("sub_beg", "<i4", (MAX_PEAKS,)), ("sub_end", "<i4", (MAX_PEAKS,))])
+assert RESULT_DTYPE.itemsize == C.sizeof(ReadResult)
+
+
+class Timing(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("ms_pack", "ms_conk", "ms_peaks", "ms_poa", "ms_prep", "ms_window",
+                                         "ms_stitch", "ms_total")] + \
+               [(n, C.c_int64) for n in ("n_reads", "n_bases", "n_windows", "cells_conk", "cells_poa", "cells_polish")]
+
+
+_lib = None
+
+
+def load():
+    """Load the shared library; fails loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("c3poa_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, ip, cp, i64p = C.c_void_p, C.POINTER(C.c_int), C.c_char_p, C.c_void_p
+    lib.c3_default_config.argtypes = [C.POINTER(Config)]
+    lib.c3_version.restype = C.c_char_p
+    lib.c3_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    lib.c3_destroy.argtypes = [vp]
+    lib.c3_destroy.restype = None
+    lib.c3_last_error.argtypes = [vp]
+    lib.c3_last_error.restype = C.c_char_p
+    lib.c3_set_splints.argtypes = [vp, C.c_int, cp, i64p]
+    lib.c3_batch_upload.argtypes = [vp, C.c_int, vp, vp, i64p, vp, vp]
+    lib.c3_batch_run.argtypes = [vp, C.c_int]
+    lib.c3_batch_sync.argtypes = [vp]
+    lib.c3_batch_results.argtypes = [vp, vp, vp, C.c_int64, i64p]
+    lib.c3_batch_timing.argtypes = [vp, C.POINTER(Timing)]
+    lib.c3_fetch_track.argtypes = [vp, C.c_int, vp, C.c_int64]
+    lib.c3_fetch_smoothed.argtypes = [vp, C.c_int, vp, C.c_int64]
+    lib.c3_fetch_raw_peaks.argtypes = [vp, C.c_int, vp, C.c_int]
+    lib.c3_fetch_draft.argtypes = [vp, C.c_int, vp, C.c_int]
+    lib.c3_fetch_msa2.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    lib.c3_poa_msa.argtypes = [vp, C.c_int, C.POINTER(cp), ip, vp, C.c_int, ip, vp, C.c_int64, ip]
+    lib.c3_determine_consensus.argtypes = [vp, C.c_int, C.POINTER(cp), C.POINTER(cp), ip, cp, cp, C.c_int,
+                                           cp, cp, C.c_int, vp, C.c_int, ip, vp, C.c_int, ip]
+    _lib = lib
+    return lib
+
+
+class C3Error(RuntimeError):
+    pass
+
+
+def default_config(**kw):
+    cfg = Config()
+    load().c3_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise AttributeError(k)
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _b(s):
+    return s if isinstance(s, (bytes, bytearray)) else s.encode()
+
+
+class Handle:
+    """One per GPU (c3_create / c3_destroy)."""
+
+    def __init__(self, **cfg):
+        self.lib = load()
+        self.cfg = default_config(**cfg)
+        self.h = C.c_void_p()
+        rc = self.lib.c3_create(C.byref(self.cfg), C.byref(self.h))
+        if rc != 0:
+            raise C3Error("c3_create failed (%d): %s" % (rc, self.lib.c3_last_error(None).decode()))
+        self.n = 0
+        self.lens = None
+
+    def close(self):
+        if self.h:
+            self.lib.c3_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise C3Error("c3 error %d: %s" % (rc, self.lib.c3_last_error(self.h).decode()))
+        return rc
+
+    def set_splints(self, splints):
+        """splints: list of sequences (order defines splint_id)"""
+        bs = [_b(s) for s in splints]
+        off = np.zeros(len(bs) + 1, dtype=np.int64)
+        np.cumsum([len(b) for b in bs], out=off[1:])
+        self._chk(self.lib.c3_set_splints(self.h, len(bs), b"".join(bs), off.ctypes.data))
+
+    def upload(self, seqs, quals, strands, splint_ids=None):
+        """seqs/quals: lists of str/bytes (or pre-joined bytes with `lens`), strands: '+'/'-' per read"""
+        bs = [_b(s) for s in seqs]
+        n = len(bs)
+        lens = np.array([len(b) for b in bs], dtype=np.int64)
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(lens, out=off[1:])
+        self.upload_flat(b"".join(bs), b"".join(_b(q) for q in quals), off,
+                         "".join(strands) if not isinstance(strands, (bytes, bytearray)) else strands, splint_ids)
+
+    def upload_flat(self, seq_cat, qual_cat, off, strands, splint_ids=None):
+        n = len(off) - 1
+        off = np.ascontiguousarray(off, dtype=np.int64)
+        st = _b(strands)
+        assert len(st) == n and len(seq_cat) == off[-1] == len(qual_cat)
+        sid = None
+        if splint_ids is not None:
+            sid = np.ascontiguousarray(splint_ids, dtype=np.int16)
+        sq = np.frombuffer(seq_cat, dtype=np.uint8)
+        qq = np.frombuffer(qual_cat, dtype=np.uint8)
+        self._chk(self.lib.c3_batch_upload(self.h, n, sq.ctypes.data, qq.ctypes.data, off.ctypes.data,
+                                           sid.ctypes.data if sid is not None else None,
+                                           np.frombuffer(st, dtype=np.uint8).ctypes.data))
+        self.n = n
+        self.off = off
+
+    def run(self, stages=STAGES_ALL):
+        self._chk(self.lib.c3_batch_run(self.h, stages))
+
+    def results(self, with_consensus=True):
+        res = np.zeros(self.n, dtype=RESULT_DTYPE)
+        coff = np.zeros(self.n + 1, dtype=np.int64)
+        if not with_consensus:
+            self._chk(self.lib.c3_batch_results(self.h, res.ctypes.data, None, 0, coff.ctypes.data))
+            return res, None
+        cap = int(self.off[-1]) + 16
+        buf = np.zeros(cap, dtype=np.uint8)
+        self._chk(self.lib.c3_batch_results(self.h, res.ctypes.data, buf.ctypes.data, cap, coff.ctypes.data))
+        raw = buf.tobytes()
+        cons = [raw[coff[i]:coff[i + 1]].decode() for i in range(self.n)]
+        return res, cons
+
+    def timing(self):
+        t = Timing()
+        self._chk(self.lib.c3_batch_timing(self.h, C.byref(t)))
+        return {f[0]: getattr(t, f[0]) for f in Timing._fields_}
+
+    # ---- probes
+    def track(self, i):
+        L = int(self.off[i + 1] - self.off[i])
+        out = np.zeros(L, dtype=np.int32)
+        self._chk(self.lib.c3_fetch_track(self.h, i, out.ctypes.data, L))
+        return out
+
+    def smoothed(self, i):
+        L = int(self.off[i + 1] - self.off[i])
+        out = np.zeros(L, dtype=np.float64)
+        self._chk(self.lib.c3_fetch_smoothed(self.h, i, out.ctypes.data, L))
+        return out
+
+    def raw_peaks(self, i):
+        out = np.zeros(MAX_PEAKS, dtype=np.int32)
+        n = self._chk(self.lib.c3_fetch_raw_peaks(self.h, i, out.ctypes.data, MAX_PEAKS))
+        return out[:n].astype(np.int64)
+
+    def draft(self, i):
+        L = int(self.off[i + 1] - self.off[i]) + 8
+        buf = C.create_string_buffer(L)
+        n = self._chk(self.lib.c3_fetch_draft(self.h, i, buf, L))
+        return buf.raw[:n].decode()
+
+    def poa_msa(self, seqs, out_cons=True, out_msa=True):
+        n = len(seqs)
+        if n == 0:
+            return [], []
+        bs = [_b(s) for s in seqs]
+        arr = (C.c_char_p * n)(*bs)
+        lens = (C.c_int * n)(*[len(b) for b in bs])
+        tot = sum(len(b) for b in bs) + 16
+        cons = C.create_string_buffer(tot) if out_cons else None
+        msa = C.create_string_buffer(tot * n) if out_msa else None
+        cl, ml = C.c_int(0), C.c_int(0)
+        self._chk(self.lib.c3_poa_msa(self.h, n, arr, lens, cons, tot, C.byref(cl), msa, tot * n, C.byref(ml)))
+        c = [cons.raw[:cl.value].decode()] if out_cons and cl.value else []
+        m = [msa.raw[i * ml.value:(i + 1) * ml.value].decode() for i in range(n)] if out_msa and ml.value else []
+        return c, m
+
+    def determine_consensus(self, subs, quals, front=None, tail=None, return_draft=False):
+        n = len(subs)
+        bs, bq = [_b(s) for s in subs], [_b(q) for q in quals]
+        arr, qarr = (C.c_char_p * n)(*bs), (C.c_char_p * n)(*bq)
+        lens = (C.c_int * n)(*[len(b) for b in bs])
+        tot = sum(len(b) for b in bs) + (len(front[0]) if front else 0) + (len(tail[0]) if tail else 0) + 64
+        out, draft = C.create_string_buffer(tot), C.create_string_buffer(tot)
+        ol, dl = C.c_int(0), C.c_int(0)
+        f = (_b(front[0]), _b(front[1]), len(front[0])) if front else (None, None, 0)
+        t = (_b(tail[0]), _b(tail[1]), len(tail[0])) if tail else (None, None, 0)
+        self._chk(self.lib.c3_determine_consensus(self.h, n, arr, qarr, lens, f[0], f[1], f[2], t[0], t[1], t[2],
+                                                  out, tot, C.byref(ol), draft, tot, C.byref(dl)))
+        if return_draft:
+            return out.raw[:ol.value].decode(), draft.raw[:dl.value].decode()
+        return out.raw[:ol.value].decode()

@@ -1,0 +1,637 @@
+// c3_api.hip -- C ABI (include/c3poa.h) and host orchestration of the HIP hot path.
+// No CPU fallback exists in this library: without a gfx950 device c3_create fails.
+#include "c3_dev.h"
+#include "c3_args.h"
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ---- kernel launchers (one translation unit per kernel family) --------------------------
+extern "C" void c3k_launch_conk(const ConkArgs*, int, int, hipStream_t);
+extern "C" void c3k_launch_peaks(const PeaksArgs*, int, hipStream_t);
+extern "C" void c3k_launch_poa(const PoaArgs*, int, hipStream_t);
+extern "C" void c3k_launch_prep(const PrepArgs*, int, hipStream_t);
+extern "C" void c3k_launch_window(const WinArgs*, int, hipStream_t);
+extern "C" void c3k_launch_stitch(const StitchArgs*, int, hipStream_t);
+
+// ---- small kernels ----------------------------------------------------------------------
+__global__ void k_pack(const uint8_t* ascii, const int64_t* off, const int64_t* woff, int n, uint32_t* pk) {
+  // one block per read slice: word w of read r packs bases 16w..16w+15
+  for (int r = blockIdx.y; r < n; r += gridDim.y) {
+    const int64_t L = off[r + 1] - off[r];
+    const int64_t nw = woff[r + 1] - woff[r];
+    const uint8_t* s = ascii + off[r];
+    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < nw; w += (int64_t)gridDim.x * blockDim.x) {
+      uint32_t x = 0;
+      for (int k = 0; k < 16; ++k) {
+        int64_t i = w * 16 + k;
+        int c = 0;
+        if (i < L) {
+          switch (s[i]) { case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break;
+                          case 'T': case 't': case 'U': case 'u': c = 3; break; default: c = 0; }
+        }
+        x |= (uint32_t)c << (2 * k);
+      }
+      pk[woff[r] + w] = x;
+    }
+  }
+}
+__global__ void k_init_info(C3Info* info, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { C3Info* p = &info[i]; p->status = C3_ST_OK; p->n_peaks = 0; p->n_sub = 0; p->has_front = p->has_tail = 0;
+               p->front_end = p->tail_beg = 0; p->cons_len = 0; p->draft_len = 0; p->n_win = 0; }
+}
+struct Summary { int status, n_sub, max_sub, sum_sub, max_dang; };
+__global__ void k_summary(const C3Info* info, const int64_t* off, int n, Summary* out) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const C3Info* p = &info[i];
+  Summary s; s.status = p->status; s.n_sub = p->n_sub; s.max_sub = 0; s.sum_sub = 0; s.max_dang = 0;
+  for (int k = 0; k < p->n_sub; ++k) { int l = p->sub_end[k] - p->sub_beg[k]; s.sum_sub += l; if (l > s.max_sub) s.max_sub = l; }
+  int L = (int)(off[i + 1] - off[i]);
+  if (p->has_front) s.max_dang = p->front_end;
+  if (p->has_tail && L - p->tail_beg > s.max_dang) s.max_dang = L - p->tail_beg;
+  out[i] = s;
+}
+
+// ---- handle -----------------------------------------------------------------------------
+struct DBuf {
+  void* p = nullptr; size_t cap = 0;
+  hipError_t ensure(size_t bytes) {
+    if (bytes <= cap) return hipSuccess;
+    if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e == hipSuccess) cap = want;
+    return e;
+  }
+  void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+  template <class T> T* as() const { return (T*)p; }
+};
+
+enum { EV_N = 10 };
+struct c3_handle {
+  c3_config cfg; std::string err; hipStream_t stream = nullptr; int n_cus = 256; size_t mem_total = 0;
+  hipEvent_t ev[EV_N];
+  // splints
+  int n_spl = 0, max_spl = 0; std::vector<int> sp_len; DBuf d_sp_codes, d_sp_len;
+  // batch
+  int n = 0; int64_t total = 0, words = 0, maxL = 0; std::vector<int64_t> off, woff;
+  DBuf d_ascii, d_pk, d_woff, d_qual, d_off, d_strand, d_sid, d_info, d_track, d_draft, d_tpos, d_cons, d_counter;
+  DBuf d_raw, d_nraw, d_sum, d_work, d_bufA, d_bufB, d_cand, d_cst, d_msa, d_msa_off, d_msa_len;
+  DBuf s_poa_i, s_poa_nk, s_poa_cells, s_poa_b, s_poa_sc;      // POA scratch
+  DBuf s_eH, s_eD, s_lw, d_wrec, d_wlay, d_wbase, d_wout;       // prep / windows
+  DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc;  // window scratch
+  std::vector<Summary> sum; std::vector<int> work;
+  int peaks_grid = 0; bool debug_msa = false; bool injected = false;
+  int n_windows = 0;
+  c3_timing tm;
+  int stages_done = 0;
+};
+
+static int c3_hip_fail(c3_handle* h, hipError_t e, const char* what, int line) {
+  char buf[512];
+  snprintf(buf, sizeof buf, "HIP error %d (%s) at c3_api.hip:%d: %s", (int)e, hipGetErrorString(e), line, what);
+  if (h) h->err = buf;
+  return C3_E_HIP;
+}
+static int c3_fail(c3_handle* h, int code, const char* msg) { if (h) h->err = msg; return code; }
+
+extern "C" void c3_default_config(c3_config* c) {
+  memset(c, 0, sizeof(*c));
+  c->device = 0;
+  c->conk_match = 5; c->conk_mismatch = -4; c->conk_penalty = 20;
+  c->sg_iters = 3; c->sg_window = 41; c->sg_order = 2; c->mdistcutoff = 500;
+  c->poa_match = 5; c->poa_mismatch = 4; c->poa_o1 = 4; c->poa_e1 = 2; c->poa_o2 = 24; c->poa_e2 = 1;
+  c->poa_band_b = 10; c->poa_band_f = 0.01;
+  c->pol_match = 3; c->pol_mismatch = -5; c->pol_gap = -4; c->pol_window = 500; c->pol_q = 5; c->dang_band = 128;
+  c->slots_poa = 0; c->slots_win = 0;
+}
+extern "C" const char* c3_version(void) { return "c3poa_amd 0.1 (gfx950)"; }
+
+static thread_local std::string g_create_err;
+extern "C" const char* c3_last_error(const c3_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int c3_create(const c3_config* cfg, c3_handle** out) {
+  if (!cfg || !out) return C3_E_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) { g_create_err = "no HIP device: the c3poa HIP backend has no CPU fallback"; return C3_E_NO_DEVICE; }
+  if (cfg->device < 0 || cfg->device >= ndev) { g_create_err = "bad device ordinal"; return C3_E_ARG; }
+  if (cfg->sg_order != 2 && cfg->sg_order != 3) { g_create_err = "sg_order must be 2 or 3"; return C3_E_ARG; }
+  if (cfg->sg_window < 5 || cfg->sg_window > 127 || !(cfg->sg_window & 1)) { g_create_err = "sg_window must be odd, 5..127"; return C3_E_ARG; }
+  c3_handle* h = new c3_handle();
+  h->cfg = *cfg;
+  if ((e = hipSetDevice(cfg->device)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  hipDeviceProp_t prop;
+  if ((e = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  h->mem_total = prop.totalGlobalMem;
+  if ((e = hipStreamCreate(&h->stream)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  for (int i = 0; i < EV_N; ++i) if ((e = hipEventCreate(&h->ev[i])) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  memset(&h->tm, 0, sizeof(h->tm));
+  *out = h;
+  return C3_E_OK;
+}
+
+extern "C" void c3_destroy(c3_handle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->cfg.device);
+  (void)hipStreamSynchronize(h->stream);
+  DBuf* all[] = {&h->d_sp_codes, &h->d_sp_len, &h->d_ascii, &h->d_pk, &h->d_woff, &h->d_qual, &h->d_off, &h->d_strand, &h->d_sid,
+                 &h->d_info, &h->d_track, &h->d_draft, &h->d_tpos, &h->d_cons, &h->d_counter, &h->d_raw, &h->d_nraw, &h->d_sum,
+                 &h->d_work, &h->d_bufA, &h->d_bufB, &h->d_cand, &h->d_cst, &h->d_msa, &h->d_msa_off, &h->d_msa_len,
+                 &h->s_poa_i, &h->s_poa_nk, &h->s_poa_cells, &h->s_poa_b, &h->s_poa_sc, &h->s_eH, &h->s_eD, &h->s_lw, &h->d_wrec,
+                 &h->d_wlay, &h->d_wbase, &h->d_wout, &h->s_win_i, &h->s_win_nk, &h->s_win_h, &h->s_win_d, &h->s_win_b, &h->s_win_sc};
+  for (DBuf* b : all) b->release();
+  for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(h->ev[i]);
+  (void)hipStreamDestroy(h->stream);
+  delete h;
+}
+
+static inline int code_of(char c) {
+  switch (c) { case 'C': case 'c': return 1; case 'G': case 'g': return 2; case 'T': case 't': case 'U': case 'u': return 3; default: return 0; }
+}
+
+extern "C" int c3_set_splints(c3_handle* h, int n, const char* cat, const int64_t* off) {
+  if (!h || n <= 0 || !cat || !off) return C3_E_ARG;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  std::vector<uint8_t> codes((size_t)n * 2 * C3_SPLINT_MAX, 0);
+  h->sp_len.assign(n, 0); h->max_spl = 0;
+  for (int i = 0; i < n; ++i) {
+    int S = (int)(off[i + 1] - off[i]);
+    if (S <= 0 || S > C3_SPLINT_MAX) return c3_fail(h, C3_E_LIMIT, "splint length must be 1..512");
+    h->sp_len[i] = S; h->max_spl = std::max(h->max_spl, S);
+    for (int k = 0; k < S; ++k) {
+      int c = code_of(cat[off[i] + k]);
+      codes[((size_t)i * 2 + 0) * C3_SPLINT_MAX + k] = (uint8_t)c;
+      codes[((size_t)i * 2 + 1) * C3_SPLINT_MAX + (S - 1 - k)] = (uint8_t)(3 - c);   // reverse complement (C3POa.py:234)
+    }
+  }
+  HIPCHK(h->d_sp_codes.ensure(codes.size()));
+  HIPCHK(h->d_sp_len.ensure(sizeof(int) * n));
+  HIPCHK(hipMemcpyAsync(h->d_sp_codes.p, codes.data(), codes.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_sp_len.p, h->sp_len.data(), sizeof(int) * n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->n_spl = n;
+  return C3_E_OK;
+}
+
+static C3Batch dev_batch(c3_handle* h) {
+  C3Batch b; b.n = h->n; b.pk = h->d_pk.as<uint32_t>(); b.woff = h->d_woff.as<int64_t>(); b.qual = h->d_qual.as<uint8_t>();
+  b.off = h->d_off.as<int64_t>(); b.strand = h->d_strand.as<uint8_t>(); b.splint_id = h->d_sid.as<int16_t>();
+  return b;
+}
+static C3Params dev_params(const c3_config& c) {
+  C3Params p;
+  p.conk_match = c.conk_match; p.conk_mismatch = c.conk_mismatch; p.conk_penalty = c.conk_penalty;
+  p.sg_iters = c.sg_iters; p.sg_window = c.sg_window; p.sg_order = c.sg_order; p.mdist = c.mdistcutoff;
+  p.poa_match = c.poa_match; p.poa_mismatch = c.poa_mismatch; p.o1 = c.poa_o1; p.e1 = c.poa_e1; p.o2 = c.poa_o2; p.e2 = c.poa_e2;
+  p.band_b = c.poa_band_b; p.band_f = c.poa_band_f;
+  p.pol_match = c.pol_match; p.pol_mismatch = c.pol_mismatch; p.pol_gap = c.pol_gap; p.pol_window = c.pol_window; p.pol_q = c.pol_q;
+  p.dang_band = c.dang_band;
+  return p;
+}
+
+extern "C" int c3_batch_upload(c3_handle* h, int n, const char* seqs, const char* quals, const int64_t* off,
+                               const int16_t* splint_id, const char* strand) {
+  if (!h || n <= 0 || !seqs || !quals || !off || !strand) return C3_E_ARG;
+  if (h->n_spl <= 0) return c3_fail(h, C3_E_STATE, "c3_set_splints must be called first");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  h->n = n; h->total = off[n] - off[0]; h->off.assign(off, off + n + 1); h->woff.assign(n + 1, 0); h->maxL = 0;
+  if (off[0] != 0) return c3_fail(h, C3_E_ARG, "off[0] must be 0");
+  std::vector<int16_t> sid(n, 0);
+  for (int i = 0; i < n; ++i) {
+    int64_t L = off[i + 1] - off[i];
+    if (L < 0 || L > (1 << 30)) return c3_fail(h, C3_E_ARG, "bad read length");
+    h->maxL = std::max(h->maxL, L);
+    h->woff[i + 1] = h->woff[i] + (L + 15) / 16 + 2;          // +2 words: aligned-window overread
+    if (splint_id) { if (splint_id[i] < 0 || splint_id[i] >= h->n_spl) return c3_fail(h, C3_E_ARG, "splint_id out of range"); sid[i] = splint_id[i]; }
+  }
+  h->words = h->woff[n];
+  const size_t T = (size_t)h->total;
+  HIPCHK(h->d_ascii.ensure(T + 16)); HIPCHK(h->d_pk.ensure(sizeof(uint32_t) * (size_t)h->words + 64));
+  HIPCHK(h->d_qual.ensure(T + 16)); HIPCHK(h->d_off.ensure(sizeof(int64_t) * (n + 1))); HIPCHK(h->d_woff.ensure(sizeof(int64_t) * (n + 1)));
+  HIPCHK(h->d_strand.ensure(n)); HIPCHK(h->d_sid.ensure(sizeof(int16_t) * n)); HIPCHK(h->d_info.ensure(sizeof(C3Info) * (size_t)n));
+  HIPCHK(h->d_counter.ensure(64));
+  HIPCHK(hipEventRecord(h->ev[0], h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_ascii.p, seqs, T, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_qual.p, quals, T, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_off.p, h->off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_woff.p, h->woff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_strand.p, strand, n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_sid.p, sid.data(), sizeof(int16_t) * n, hipMemcpyHostToDevice, h->stream));
+  dim3 g(64, (unsigned)std::min(n, 1024));
+  hipLaunchKernelGGL(k_pack, g, dim3(256), 0, h->stream, h->d_ascii.as<uint8_t>(), h->d_off.as<int64_t>(), h->d_woff.as<int64_t>(), n, h->d_pk.as<uint32_t>());
+  hipLaunchKernelGGL(k_init_info, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), n);
+  HIPCHK(hipEventRecord(h->ev[1], h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  memset(&h->tm, 0, sizeof(h->tm)); h->tm.ms_pack = ms; h->tm.n_reads = n; h->tm.n_bases = h->total;
+  h->stages_done = 0; h->injected = false; h->n_windows = 0;
+  return C3_E_OK;
+}
+
+static int auto_slots(c3_handle* h, int want, size_t per_slot_bytes, int n_items, int waves_per_cu) {
+  int s = want > 0 ? want : h->n_cus * waves_per_cu;
+  size_t budget = h->mem_total ? h->mem_total / 3 : ((size_t)64 << 30);
+  if (per_slot_bytes > 0) { size_t mx = budget / per_slot_bytes; if ((size_t)s > mx) s = (int)std::max<size_t>(mx, 1); }
+  if (s > n_items) s = std::max(n_items, 1);
+  return s;
+}
+
+static int run_conk(c3_handle* h) {
+  HIPCHK(h->d_track.ensure(sizeof(int32_t) * (size_t)h->total + 64));
+  HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 64, h->stream));
+  ConkArgs a; a.b = dev_batch(h); a.sp_codes = h->d_sp_codes.as<uint8_t>(); a.sp_len = h->d_sp_len.as<int>();
+  a.track = h->d_track.as<int32_t>(); a.info = h->d_info.as<C3Info>(); a.counter = h->d_counter.as<int>();
+  a.match = h->cfg.conk_match; a.mismatch = h->cfg.conk_mismatch; a.penalty = h->cfg.conk_penalty;
+  int waves = std::min(h->n, h->n_cus * 32);
+  c3k_launch_conk(&a, h->max_spl, (waves + 3) / 4, h->stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// closed-form Savitzky-Golay coefficients: the same expression as the oracle, evaluated on the host
+static void savgol_coeffs(int window, double* c) {
+  int m = (window - 1) / 2;
+  double den = (double)(2 * m - 1) * (double)(2 * m + 1) * (double)(2 * m + 3);
+  for (int k = -m; k <= m; ++k) c[k + m] = 3.0 * (double)(3 * m * m + 3 * m - 1 - 5 * k * k) / den;
+}
+
+static int run_peaks(c3_handle* h) {
+  const int grid = std::min(h->n, h->n_cus * 8);
+  h->peaks_grid = grid;
+  const size_t mL = (size_t)h->maxL + 8;
+  HIPCHK(h->d_bufA.ensure(sizeof(double) * mL * grid)); HIPCHK(h->d_bufB.ensure(sizeof(double) * mL * grid));
+  HIPCHK(h->d_cand.ensure(sizeof(int32_t) * (mL / 2 + 2) * grid)); HIPCHK(h->d_cst.ensure((mL / 2 + 2) * grid));
+  HIPCHK(h->d_raw.ensure(sizeof(int32_t) * (size_t)h->n * C3_MAX_PEAKS)); HIPCHK(h->d_nraw.ensure(sizeof(int32_t) * (size_t)h->n));
+  PeaksArgs a; memset(&a, 0, sizeof(a));
+  a.b = dev_batch(h); a.track = h->d_track.as<int32_t>(); a.info = h->d_info.as<C3Info>();
+  a.bufA = h->d_bufA.as<double>(); a.bufB = h->d_bufB.as<double>(); a.cand = h->d_cand.as<int32_t>(); a.cstate = h->d_cst.as<uint8_t>();
+  a.raw_peaks = h->d_raw.as<int32_t>(); a.n_raw = h->d_nraw.as<int32_t>(); a.sp_len = h->d_sp_len.as<int>();
+  savgol_coeffs(h->cfg.sg_window, a.coef);
+  a.maxL = (int64_t)mL; a.window = h->cfg.sg_window; a.iters = h->cfg.sg_iters; a.min_dist = h->cfg.mdistcutoff;
+  c3k_launch_peaks(&a, grid, h->stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// summary of the split -> work list + capacities
+static int fetch_summary(c3_handle* h) {
+  const int n = h->n;
+  HIPCHK(h->d_sum.ensure(sizeof(Summary) * (size_t)n));
+  hipLaunchKernelGGL(k_summary, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), h->d_off.as<int64_t>(), n, h->d_sum.as<Summary>());
+  h->sum.resize(n);
+  HIPCHK(hipMemcpyAsync(h->sum.data(), h->d_sum.p, sizeof(Summary) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->work.clear();
+  for (int i = 0; i < n; ++i) if (h->sum[i].status == C3_ST_OK && h->sum[i].n_sub >= 1) h->work.push_back(i);
+  // longest first: better tail behaviour of the dynamic work queues
+  std::stable_sort(h->work.begin(), h->work.end(), [&](int x, int y) {
+    long cx = (long)h->sum[x].sum_sub * h->sum[x].n_sub, cy = (long)h->sum[y].sum_sub * h->sum[y].n_sub; return cx > cy; });
+  HIPCHK(h->d_work.ensure(sizeof(int) * std::max<size_t>(h->work.size(), 1)));
+  if (!h->work.empty()) HIPCHK(hipMemcpyAsync(h->d_work.p, h->work.data(), sizeof(int) * h->work.size(), hipMemcpyHostToDevice, h->stream));
+  return 0;
+}
+
+static int run_poa(c3_handle* h) {
+  const int nw = (int)h->work.size();
+  HIPCHK(h->d_draft.ensure((size_t)h->total + 64)); HIPCHK(h->d_tpos.ensure(sizeof(int32_t) * (size_t)h->total + 64));
+  HIPCHK(hipMemsetAsync(h->d_tpos.p, 0xff, sizeof(int32_t) * (size_t)h->total, h->stream));
+  if (nw == 0) return 0;
+  int max_sum = 0, max_ns = 0, max_q = 0;
+  for (int i : h->work) { max_sum = std::max(max_sum, h->sum[i].sum_sub); max_ns = std::max(max_ns, h->sum[i].n_sub); max_q = std::max(max_q, h->sum[i].max_sub); }
+  const int Ncap = max_sum + 8, K = max_ns + 1, Pcap = max_sum + 8;
+  const int w = h->cfg.poa_band_b + (int)(h->cfg.poa_band_f * max_q);
+  long long cells = (long long)(2 * max_q + 2) * (2 * w + 1 + max_q / 5);
+  if (max_ns < 2) cells = 64;
+  if (cells > 0x7fffff00LL) cells = 0x7fffff00LL;
+  const size_t N = (size_t)Ncap;
+  const int NI = 26;      // int arrays of N (opn/opq count twice)
+  size_t per_slot = N * (NI * 4 + 8 + 5) + N * K * 12 + (size_t)cells * 16;
+  const int slots = auto_slots(h, h->cfg.slots_poa, per_slot, nw, 16);
+  HIPCHK(h->s_poa_i.ensure(sizeof(int) * N * NI * slots)); HIPCHK(h->s_poa_nk.ensure(sizeof(int) * N * K * 3 * slots));
+  HIPCHK(h->s_poa_cells.ensure((size_t)cells * 16 * slots)); HIPCHK(h->s_poa_b.ensure(N * 5 * slots)); HIPCHK(h->s_poa_sc.ensure(sizeof(long long) * N * slots));
+  PoaArgs a; memset(&a, 0, sizeof(a));
+  a.b = dev_batch(h); a.info = h->d_info.as<C3Info>(); a.p = dev_params(h->cfg);
+  a.counter = h->d_counter.as<int>(); a.work = h->d_work.as<int>(); a.n_work = nw;
+  int* ip = h->s_poa_i.as<int>(); const size_t SN = N * slots;
+  int** fields[] = {&a.n_in, &a.n_out, &a.grp, &a.order, &a.order2, &a.index, &a.gfirst, &a.glast, &a.rem, &a.mpl, &a.mpr,
+                    &a.rbeg, &a.rend, &a.roff, &a.anchor, &a.col, &a.col2t, &a.nxt};
+  for (auto f : fields) { *f = ip; ip += SN; }
+  a.opn = ip; ip += 2 * SN; a.opq = ip; ip += 2 * SN; a.path = ip; ip += (size_t)Pcap * slots;   // Pcap == Ncap
+  int* nk = h->s_poa_nk.as<int>(); a.in_from = nk; a.out_to = nk + SN * K; a.out_w = nk + 2 * SN * K;
+  char* cb = h->s_poa_cells.as<char>(); const size_t CS = (size_t)cells * slots;
+  a.H = (int32_t*)cb; a.E1 = (int32_t*)(cb + CS * 4); a.E2 = (int32_t*)(cb + CS * 8); a.D = (uint32_t*)(cb + CS * 12);
+  a.base = h->s_poa_b.as<uint8_t>(); a.rows2 = a.base + SN; a.score = h->s_poa_sc.as<long long>();
+  a.Ncap = Ncap; a.K = K; a.Pcap = Pcap; a.cells_cap = (int)cells;
+  a.draft = h->d_draft.as<uint8_t>(); a.tpos = h->d_tpos.as<int32_t>();
+  a.msa_dbg = nullptr; a.msa_off = nullptr; a.msa_len = nullptr;
+  if (h->debug_msa) {
+    std::vector<int64_t> mo(h->n + 1, 0);
+    for (int i = 0; i < h->n; ++i) mo[i + 1] = mo[i] + (int64_t)h->sum[i].n_sub * (h->sum[i].sum_sub + 2);
+    HIPCHK(h->d_msa.ensure((size_t)mo[h->n] + 64)); HIPCHK(h->d_msa_off.ensure(sizeof(int64_t) * (h->n + 1))); HIPCHK(h->d_msa_len.ensure(sizeof(int) * h->n));
+    HIPCHK(hipMemcpyAsync(h->d_msa_off.p, mo.data(), sizeof(int64_t) * (h->n + 1), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_msa_len.p, 0, sizeof(int) * h->n, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    a.msa_dbg = h->d_msa.as<uint8_t>(); a.msa_off = h->d_msa_off.as<int64_t>(); a.msa_len = h->d_msa_len.as<int>();
+  }
+  HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 64, h->stream));
+  c3k_launch_poa(&a, slots, h->stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st) {
+  const int nw = (int)h->work.size();
+  HIPCHK(h->d_cons.ensure((size_t)h->total + 64));
+  if (nw == 0) return 0;
+  const int WL = h->cfg.pol_window;
+  int max_ns = 0, max_q = 0, max_dang = 0; long long wcap = 0;
+  for (int i : h->work) {
+    max_ns = std::max(max_ns, h->sum[i].n_sub); max_q = std::max(max_q, h->sum[i].max_sub); max_dang = std::max(max_dang, h->sum[i].max_dang);
+    wcap += (2 * h->sum[i].max_sub + WL - 1) / WL + 1;
+  }
+  const int NLcap = max_ns + 2, NWcap = (2 * max_q + WL - 1) / WL + 1;
+  const int64_t ecap = (int64_t)(max_dang + 2) * (2 * h->cfg.dang_band + 1);
+  const size_t per_slot_prep = (size_t)ecap * 5 + (size_t)NLcap * NWcap * 8;
+  const int slots_p = auto_slots(h, h->cfg.slots_poa, per_slot_prep, nw, 16);
+  HIPCHK(h->s_eH.ensure(sizeof(int32_t) * (size_t)ecap * slots_p)); HIPCHK(h->s_eD.ensure((size_t)ecap * slots_p));
+  HIPCHK(h->s_lw.ensure(sizeof(int) * (size_t)NLcap * NWcap * 2 * slots_p));
+  HIPCHK(h->d_wrec.ensure(sizeof(WinRec) * (size_t)wcap)); HIPCHK(h->d_wlay.ensure(sizeof(WLayer) * (size_t)wcap * NLcap));
+  HIPCHK(h->d_wbase.ensure(sizeof(int) * (size_t)h->n));
+  PrepArgs p; memset(&p, 0, sizeof(p));
+  p.b = dev_batch(h); p.info = h->d_info.as<C3Info>(); p.p = dev_params(h->cfg);
+  p.counter = h->d_counter.as<int>(); p.work = h->d_work.as<int>(); p.n_work = nw;
+  p.draft = h->d_draft.as<uint8_t>(); p.tpos = h->d_tpos.as<int32_t>();
+  p.eH = h->s_eH.as<int32_t>(); p.eD = h->s_eD.as<uint8_t>(); p.ecap = ecap;
+  p.lw_first = h->s_lw.as<int>(); p.lw_last = p.lw_first + (size_t)NLcap * NWcap * slots_p; p.NLcap = NLcap; p.NWcap = NWcap;
+  p.wrec = h->d_wrec.as<WinRec>(); p.wlay = h->d_wlay.as<WLayer>(); p.win_base = h->d_wbase.as<int>();
+  p.n_windows = h->d_counter.as<int>() + 8; p.wcap = (int)std::min<long long>(wcap, 0x7fffffff);
+  HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 64, h->stream));
+  HIPCHK(hipEventRecord(h->ev[5], h->stream));
+  c3k_launch_prep(&p, slots_p, h->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev[6], h->stream));
+  int cnt[16];
+  HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 64, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->tm.cells_polish += *(long long*)(cnt + 2);
+  const int n_win = cnt[8];
+  h->n_windows = n_win;
+  const int wout_cap = 3 * WL + 64;
+  HIPCHK(hipEventRecord(h->ev[7], h->stream));
+  if (n_win > 0) {
+    HIPCHK(h->d_wout.ensure((size_t)n_win * wout_cap));
+    const int Ncap = 4 * WL + 64 * NLcap, K = NLcap + 2;
+    const long long hcap = (long long)(Ncap + 1) * 64 * 12;
+    const size_t N = (size_t)Ncap;
+    const int NI = 21;
+    const size_t per_slot = N * (NI * 4 + 8 + 2) + N * K * 16 + (size_t)hcap * 6;
+    const int slots = auto_slots(h, h->cfg.slots_win, per_slot, n_win, 16);
+    HIPCHK(h->s_win_i.ensure(sizeof(int) * (N + 1) * NI * slots)); HIPCHK(h->s_win_nk.ensure(sizeof(int) * N * K * 4 * slots));
+    HIPCHK(h->s_win_h.ensure(sizeof(int32_t) * (size_t)hcap * slots)); HIPCHK(h->s_win_d.ensure(sizeof(uint16_t) * (size_t)hcap * slots));
+    HIPCHK(h->s_win_b.ensure(N * 2 * slots)); HIPCHK(h->s_win_sc.ensure(sizeof(long long) * N * slots));
+    WinArgs a; memset(&a, 0, sizeof(a));
+    a.b = dev_batch(h); a.p = dev_params(h->cfg); a.counter = h->d_counter.as<int>(); a.n_win = n_win;
+    a.wrec_in = h->d_wrec.as<WinRec>(); a.wrec = h->d_wrec.as<WinRec>(); a.wlay = h->d_wlay.as<WLayer>(); a.NLcap = NLcap;
+    a.draft = h->d_draft.as<uint8_t>();
+    int* ip = h->s_win_i.as<int>(); const size_t SN = N * slots;
+    int** fields[] = {&a.n_in, &a.n_out, &a.grp, &a.order, &a.order2, &a.index, &a.gfirst, &a.glast, &a.ncov, &a.rowof, &a.anchor, &a.pred};
+    for (auto f : fields) { *f = ip; ip += SN; }
+    a.rows = ip; ip += (N + 1) * slots; a.opn = ip; ip += 2 * SN; a.opq = ip; ip += 2 * SN;
+    int* nk = h->s_win_nk.as<int>(); a.in_from = nk; a.in_w = nk + SN * K; a.out_to = nk + 2 * SN * K; a.out_w = nk + 3 * SN * K;
+    a.base = h->s_win_b.as<uint8_t>(); a.mask = a.base + SN; a.score = h->s_win_sc.as<long long>();
+    a.H = h->s_win_h.as<int32_t>(); a.D = h->s_win_d.as<uint16_t>(); a.Ncap = Ncap; a.K = K; a.hcap = hcap;
+    a.wout = h->d_wout.as<uint8_t>(); a.wout_cap = wout_cap;
+    HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 64, h->stream));
+    c3k_launch_window(&a, slots, h->stream);
+    HIPCHK(hipGetLastError());
+  }
+  HIPCHK(hipEventRecord(h->ev[8], h->stream));
+  StitchArgs s; memset(&s, 0, sizeof(s));
+  s.b = dev_batch(h); s.info = h->d_info.as<C3Info>(); s.work = h->d_work.as<int>(); s.n_work = nw;
+  s.wrec = h->d_wrec.as<WinRec>(); s.win_base = h->d_wbase.as<int>(); s.wout = h->d_wout.as<uint8_t>(); s.wout_cap = wout_cap;
+  s.cons = h->d_cons.as<char>();
+  c3k_launch_stitch(&s, std::min(nw, h->n_cus * 16), h->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev[9], h->stream));
+  HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 64, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (n_win > 0) h->tm.cells_polish += *(long long*)(cnt + 2);
+  HIPCHK(hipEventElapsedTime(ms_prep, h->ev[5], h->ev[6]));
+  HIPCHK(hipEventElapsedTime(ms_win, h->ev[7], h->ev[8]));
+  HIPCHK(hipEventElapsedTime(ms_st, h->ev[8], h->ev[9]));
+  h->tm.n_windows = n_win;
+  return 0;
+}
+
+extern "C" int c3_batch_run(c3_handle* h, int stages) {
+  if (!h || h->n <= 0) return C3_E_STATE;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  int rc;
+  float ms;
+  hipEvent_t t0 = h->ev[0], t1 = h->ev[1], t2 = h->ev[2], t3 = h->ev[3], t4 = h->ev[4];
+  HIPCHK(hipEventRecord(t0, h->stream));
+  if (stages & C3_STAGE_CONK) { if ((rc = run_conk(h))) return rc; h->tm.cells_conk = 0; for (int i = 0; i < h->n; ++i) h->tm.cells_conk += (h->off[i + 1] - h->off[i]) * (int64_t)h->max_spl; }
+  HIPCHK(hipEventRecord(t1, h->stream));
+  if (stages & C3_STAGE_PEAKS) { if ((rc = run_peaks(h))) return rc; }
+  HIPCHK(hipEventRecord(t2, h->stream));
+  float ms_prep = 0, ms_win = 0, ms_st = 0;
+  if (stages & (C3_STAGE_POA | C3_STAGE_POLISH)) {
+    if ((rc = fetch_summary(h))) return rc;
+    HIPCHK(hipEventRecord(t3, h->stream));
+    if (stages & C3_STAGE_POA) {
+      if ((rc = run_poa(h))) return rc;
+    }
+    HIPCHK(hipEventRecord(t4, h->stream));
+    if (stages & C3_STAGE_POA) {
+      int cnt[16];
+      HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 64, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      if (!h->work.empty()) h->tm.cells_poa = *(long long*)(cnt + 2);
+      HIPCHK(hipEventElapsedTime(&ms, t3, t4)); h->tm.ms_poa = ms;
+    }
+    if (stages & C3_STAGE_POLISH) { if ((rc = run_polish(h, &ms_prep, &ms_win, &ms_st))) return rc; }
+  }
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
+  if (stages & C3_STAGE_CONK) { HIPCHK(hipEventElapsedTime(&ms, t0, t1)); h->tm.ms_conk = ms; }
+  if (stages & C3_STAGE_PEAKS) { HIPCHK(hipEventElapsedTime(&ms, t1, t2)); h->tm.ms_peaks = ms; }
+  if (stages & C3_STAGE_POLISH) { h->tm.ms_prep = ms_prep; h->tm.ms_window = ms_win; h->tm.ms_stitch = ms_st; }
+  h->tm.ms_total = h->tm.ms_conk + h->tm.ms_peaks + h->tm.ms_poa + h->tm.ms_prep + h->tm.ms_window + h->tm.ms_stitch;
+  h->stages_done |= stages;
+  return C3_E_OK;
+}
+
+extern "C" int c3_batch_sync(c3_handle* h) {
+  if (!h) return C3_E_ARG;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return C3_E_OK;
+}
+
+extern "C" int c3_batch_results(c3_handle* h, c3_read_result* res, char* cons, int64_t cons_cap, int64_t* cons_off) {
+  if (!h || h->n <= 0 || !res) return C3_E_ARG;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipMemcpyAsync(res, h->d_info.p, sizeof(C3Info) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (!cons_off) return C3_E_OK;
+  cons_off[0] = 0;
+  for (int i = 0; i < h->n; ++i) cons_off[i + 1] = cons_off[i] + ((res[i].status == C3_ST_OK) ? res[i].cons_len : 0);
+  if (!cons) return C3_E_OK;
+  if (cons_off[h->n] > cons_cap) return c3_fail(h, C3_E_LIMIT, "consensus buffer too small");
+  if (!(h->stages_done & C3_STAGE_POLISH)) return C3_E_OK;
+  // gather: one device->host copy of the arena, then compaction on the host
+  std::vector<char> arena((size_t)h->total + 1);
+  HIPCHK(hipMemcpyAsync(arena.data(), h->d_cons.p, (size_t)h->total, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < h->n; ++i)
+    if (res[i].status == C3_ST_OK && res[i].cons_len > 0) memcpy(cons + cons_off[i], arena.data() + h->off[i], (size_t)res[i].cons_len);
+  return C3_E_OK;
+}
+
+extern "C" int c3_batch_timing(c3_handle* h, c3_timing* t) { if (!h || !t) return C3_E_ARG; *t = h->tm; return C3_E_OK; }
+
+// ---- probes -----------------------------------------------------------------------------
+extern "C" int c3_fetch_track(c3_handle* h, int read, int32_t* out, int64_t cap) {
+  if (!h || read < 0 || read >= h->n || !out) return C3_E_ARG;
+  if (!(h->stages_done & C3_STAGE_CONK)) return c3_fail(h, C3_E_STATE, "conk stage not run");
+  int64_t L = h->off[read + 1] - h->off[read];
+  if (cap < L) return C3_E_LIMIT;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipMemcpy(out, h->d_track.as<int32_t>() + h->off[read], sizeof(int32_t) * (size_t)L, hipMemcpyDeviceToHost));
+  return (int)L;
+}
+extern "C" int c3_fetch_smoothed(c3_handle* h, int read, double* out, int64_t cap) {
+  if (!h || read < 0 || read >= h->n || !out) return C3_E_ARG;
+  if (!(h->stages_done & C3_STAGE_PEAKS)) return c3_fail(h, C3_E_STATE, "peaks stage not run");
+  if (h->n > h->peaks_grid) return c3_fail(h, C3_E_STATE, "smoothed tracks are only retained when the batch fits the peaks grid");
+  int64_t L = h->off[read + 1] - h->off[read];
+  if (cap < L) return C3_E_LIMIT;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  // result buffer after `iters` ping-pong passes: A if iters is even, B if odd
+  const double* src = ((h->cfg.sg_iters & 1) ? h->d_bufB.as<double>() : h->d_bufA.as<double>()) + (size_t)read * ((size_t)h->maxL + 8);
+  HIPCHK(hipMemcpy(out, src, sizeof(double) * (size_t)L, hipMemcpyDeviceToHost));
+  return (int)L;
+}
+extern "C" int c3_fetch_raw_peaks(c3_handle* h, int read, int32_t* out, int cap) {
+  if (!h || read < 0 || read >= h->n || !out) return C3_E_ARG;
+  if (!(h->stages_done & C3_STAGE_PEAKS)) return c3_fail(h, C3_E_STATE, "peaks stage not run");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  int n = 0;
+  HIPCHK(hipMemcpy(&n, h->d_nraw.as<int32_t>() + read, sizeof(int), hipMemcpyDeviceToHost));
+  if (n > cap) return C3_E_LIMIT;
+  if (n > 0) HIPCHK(hipMemcpy(out, h->d_raw.as<int32_t>() + (size_t)read * C3_MAX_PEAKS, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  return n;
+}
+extern "C" int c3_fetch_draft(c3_handle* h, int read, char* out, int cap) {
+  if (!h || read < 0 || read >= h->n || !out) return C3_E_ARG;
+  if (!(h->stages_done & C3_STAGE_POA)) return c3_fail(h, C3_E_STATE, "POA stage not run");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  C3Info inf;
+  HIPCHK(hipMemcpy(&inf, h->d_info.as<C3Info>() + read, sizeof(C3Info), hipMemcpyDeviceToHost));
+  int C = inf.draft_len;
+  if (C > cap) return C3_E_LIMIT;
+  if (C > 0) {
+    std::vector<uint8_t> tmp(C);
+    HIPCHK(hipMemcpy(tmp.data(), h->d_draft.as<uint8_t>() + h->off[read], C, hipMemcpyDeviceToHost));
+    for (int i = 0; i < C; ++i) out[i] = "ACGT"[tmp[i] & 3];
+  }
+  return C;
+}
+static int fetch_msa_rows(c3_handle* h, int read, int nrows, char* out, int64_t cap, int* msa_len) {
+  if (!h->debug_msa || !h->d_msa.p) return c3_fail(h, C3_E_STATE, "MSA rows are only kept by c3_poa_msa / debug batches");
+  int ml = 0;
+  HIPCHK(hipMemcpy(&ml, h->d_msa_len.as<int>() + read, sizeof(int), hipMemcpyDeviceToHost));
+  *msa_len = ml;
+  if (ml <= 0) return 0;
+  if ((int64_t)ml * nrows > cap) return C3_E_LIMIT;
+  std::vector<int64_t> mo(2);
+  HIPCHK(hipMemcpy(mo.data(), h->d_msa_off.as<int64_t>() + read, sizeof(int64_t), hipMemcpyDeviceToHost));
+  std::vector<uint8_t> tmp((size_t)ml * nrows);
+  HIPCHK(hipMemcpy(tmp.data(), h->d_msa.as<uint8_t>() + mo[0], tmp.size(), hipMemcpyDeviceToHost));
+  for (size_t i = 0; i < tmp.size(); ++i) out[i] = tmp[i] > 3 ? '-' : "ACGT"[tmp[i]];
+  return 0;
+}
+extern "C" int c3_fetch_msa2(c3_handle* h, int read, char* rowA, char* rowB, int cap) {
+  if (!h || read < 0 || read >= h->n || !rowA || !rowB) return C3_E_ARG;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  std::vector<char> tmp((size_t)cap * 2 + 2);
+  int ml = 0;
+  int rc = fetch_msa_rows(h, read, 2, tmp.data(), (int64_t)cap * 2, &ml);
+  if (rc) return rc;
+  memcpy(rowA, tmp.data(), ml); memcpy(rowB, tmp.data() + ml, ml);
+  return ml;
+}
+
+// inject a pre-split "read": [front][sub0]...[subn-1][tail]; skips conk/peaks
+static int inject(c3_handle* h, int n, const char* const* subs, const char* const* quals, const int* lens,
+                  const char* front, const char* front_q, int front_len, const char* tail, const char* tail_q, int tail_len) {
+  if (n < 1 || n > C3_MAX_SUB) return c3_fail(h, C3_E_LIMIT, "1..250 subreads");
+  if (h->n_spl <= 0) { const char sp[] = "ACGT"; int64_t o[2] = {0, 4}; int rc = c3_set_splints(h, 1, sp, o); if (rc) return rc; }
+  std::string seq, ql;
+  c3_read_result r; memset(&r, 0, sizeof(r));
+  if (front && front_len > 0) { seq.append(front, front_len); if (front_q) ql.append(front_q, front_len); else ql.append(front_len, 'I'); r.has_front = 1; r.front_end = front_len; }
+  for (int i = 0; i < n; ++i) {
+    r.sub_beg[i] = (int)seq.size(); seq.append(subs[i], lens[i]);
+    if (quals && quals[i]) ql.append(quals[i], lens[i]); else ql.append(lens[i], 'I');
+    r.sub_end[i] = (int)seq.size();
+  }
+  r.n_sub = n; r.n_peaks = n + 1; r.status = C3_ST_OK;
+  if (tail && tail_len > 0) { r.has_tail = 1; r.tail_beg = (int)seq.size(); seq.append(tail, tail_len); if (tail_q) ql.append(tail_q, tail_len); else ql.append(tail_len, 'I'); }
+  int64_t off[2] = {0, (int64_t)seq.size()};
+  int16_t sid = 0; char st = '+';
+  int rc = c3_batch_upload(h, 1, seq.data(), ql.data(), off, &sid, &st);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(h->d_info.p, &r, sizeof(r), hipMemcpyHostToDevice));
+  h->injected = true;
+  return 0;
+}
+
+extern "C" int c3_poa_msa(c3_handle* h, int n, const char* const* seqs, const int* lens,
+                          char* cons, int cons_cap, int* cons_len, char* msa, int64_t msa_cap, int* msa_len) {
+  if (!h) return C3_E_ARG;
+  if (cons_len) *cons_len = 0;
+  if (msa_len) *msa_len = 0;
+  if (n == 0) return C3_E_OK;                       // msa([]) -> empty result (determine_consensus.py:43-47 with repeats==0)
+  if (!seqs || !lens) return C3_E_ARG;
+  int rc = inject(h, n, seqs, nullptr, lens, nullptr, nullptr, 0, nullptr, nullptr, 0);
+  if (rc) return rc;
+  const bool dbg0 = h->debug_msa; h->debug_msa = (msa != nullptr);
+  rc = c3_batch_run(h, C3_STAGE_POA);
+  if (rc == 0 && cons) {
+    // pyabpoa semantics: the consensus is the heaviest bundle also for n == 2; the batch path gives the
+    // pairwise-merged draft there, so only n != 2 is served from the draft
+    if (n == 2) { h->debug_msa = dbg0; return c3_fail(h, C3_E_ARG, "out_cons with exactly 2 sequences is not a reference call shape"); }
+    int C = c3_fetch_draft(h, 0, cons, cons_cap);
+    if (C < 0) rc = C; else if (cons_len) *cons_len = C;
+  }
+  if (rc == 0 && msa) { int ml = 0; rc = fetch_msa_rows(h, 0, n, msa, msa_cap, &ml); if (rc == 0 && msa_len) *msa_len = ml; }
+  h->debug_msa = dbg0;
+  return rc;
+}
+
+extern "C" int c3_determine_consensus(c3_handle* h, int n, const char* const* subs, const char* const* quals,
+                                      const int* lens, const char* front, const char* front_q, int front_len,
+                                      const char* tail, const char* tail_q, int tail_len,
+                                      char* out, int cap, int* out_len, char* draft, int draft_cap, int* draft_len) {
+  if (!h || !subs || !lens || !out || !out_len) return C3_E_ARG;
+  *out_len = 0; if (draft_len) *draft_len = 0;
+  int rc = inject(h, n, subs, quals, lens, front, front_q, front_len, tail, tail_q, tail_len);
+  if (rc) return rc;
+  rc = c3_batch_run(h, C3_STAGE_POA | C3_STAGE_POLISH);
+  if (rc) return rc;
+  if (draft) { int C = c3_fetch_draft(h, 0, draft, draft_cap); if (C < 0) return C; if (draft_len) *draft_len = C; }
+  std::vector<c3_read_result> res(1);
+  int64_t co[2];
+  rc = c3_batch_results(h, res.data(), out, cap, co);
+  if (rc) return rc;
+  *out_len = (res[0].status == C3_ST_OK) ? res[0].cons_len : 0;
+  return C3_E_OK;
+}

@@ -1,0 +1,36 @@
+// c3_args.h -- kernel argument blocks shared by the launchers (c3_api.hip) and the kernels.
+#pragma once
+#include "c3_dev.h"
+
+struct ConkArgs {
+  C3Batch b; const uint8_t* sp_codes; const int* sp_len; int32_t* track; C3Info* info; int* counter;
+  int match, mismatch, penalty;
+};
+struct PeaksArgs {
+  C3Batch b; const int32_t* track; C3Info* info; double* bufA; double* bufB; int32_t* cand; uint8_t* cstate;
+  int32_t* raw_peaks; int32_t* n_raw; const int* sp_len; double coef[64]; int64_t maxL; int window, iters, min_dist;
+};
+struct PoaArgs {
+  C3Batch b; C3Info* info; C3Params p; int* counter; const int* work; int n_work;
+  uint8_t* base; int *n_in, *n_out, *in_from, *out_to, *out_w, *grp, *order, *order2, *index;
+  int *gfirst, *glast, *rem, *mpl, *mpr, *rbeg, *rend, *roff, *opn, *opq, *anchor, *path, *col, *col2t, *nxt;
+  long long* score; int32_t *H, *E1, *E2; uint32_t* D; uint8_t* rows2; int Ncap, K, Pcap, cells_cap;
+  uint8_t* draft; int32_t* tpos; uint8_t* msa_dbg; const int64_t* msa_off; int* msa_len;
+};
+struct WLayer { int qbeg, len, begin, end; };
+struct WinRec { int rid, w, n_layers, blen, tgs, out_len, polished, pad_; };
+struct PrepArgs {
+  C3Batch b; C3Info* info; C3Params p; int* counter; const int* work; int n_work;
+  const uint8_t* draft; int32_t* tpos; int32_t* eH; uint8_t* eD; int64_t ecap; int* lw_first; int* lw_last; int NLcap, NWcap;
+  WinRec* wrec; WLayer* wlay; int* win_base; int* n_windows; int wcap;
+};
+struct WinArgs {
+  C3Batch b; C3Params p; int* counter; int n_win; const WinRec* wrec_in; WinRec* wrec; const WLayer* wlay; int NLcap;
+  const uint8_t* draft;
+  uint8_t* base; int *n_in, *n_out, *in_from, *in_w, *out_to, *out_w, *grp, *order, *order2, *index;
+  int *gfirst, *glast, *ncov, *rowof, *rows, *anchor, *opn, *opq, *pred; uint8_t* mask; long long* score;
+  int32_t* H; uint16_t* D; int Ncap, K; long long hcap; uint8_t* wout; int wout_cap;
+};
+struct StitchArgs {
+  C3Batch b; C3Info* info; const int* work; int n_work; const WinRec* wrec; const int* win_base; const uint8_t* wout; int wout_cap; char* cons;
+};

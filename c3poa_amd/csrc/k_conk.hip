@@ -1,0 +1,112 @@
+// k_conk.hip -- K1: splint x read local-alignment score track, summed per diagonal.
+//
+// Replaces conk.conk(splint, seq, 20) at /root/reference/C3POa.py:123 (conk is an un-vendored
+// Cython dependency; spec frozen in DESIGN.md 4.1 and restated by oracle/c3o_signal.c:c3o_conk).
+//
+// Mapping (MI355X-first, no LDS, no atomics): ONE WAVE PER READ.  Lane l owns R consecutive
+// splint rows (64*R >= S; padding rows sit on top and can never score), and at step t works on
+// read column j = t - l, so the 64 lanes form a systolic anti-diagonal.  The only cross-lane
+// traffic is two DPP wave_shr:1 moves per step: the bottom-row H of the lane above, and the
+// running diagonal sum.  A diagonal's partial sum rides down the lanes as a token (one hop
+// every R+1 steps) and leaves lane 63 complete, where it is stored exactly once: the track is
+// written with plain stores, never read-modified.  Read bases arrive 2-bit packed, 16 per
+// dword, re-aligned once per 16 steps with v_alignbit.
+#include "c3_dev.h"
+#include "c3_args.h"
+
+
+template <int R, bool CHECK>
+__device__ __forceinline__ void conk_step(int rc, bool kill, int (&hprev)[R], int (&P)[R], int& W,
+                                          int& up_prev, const int (&code)[R],
+                                          int match, int mismatch, int penalty) {
+  int up = wave_shr1(hprev[R - 1], 0);
+  int recv = wave_shr1(W, 0);
+  int u = up, d = up_prev;
+  up_prev = up;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    int s = (code[k] == rc) ? match : mismatch;
+    int m = max(u, hprev[k]) - penalty;
+    int hh = max(max(d + s, m), 0);
+    if (CHECK) hh = kill ? 0 : hh;
+    d = hprev[k];
+    hprev[k] = hh;
+    u = hh;
+  }
+  int wn = P[R - 1];
+#pragma unroll
+  for (int k = R - 1; k >= 1; --k) P[k] = P[k - 1] + hprev[k];
+  P[0] = recv + hprev[0];
+  W = wn;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
+  const int lane = wave_lane();
+  for (;;) {
+    int rid = 0;
+    if (lane == 0) rid = atomicAdd(a.counter, 1);
+    rid = wave_first(rid);
+    if (rid >= a.b.n) break;
+    const int64_t off = a.b.off[rid];
+    const int L = (int)(a.b.off[rid + 1] - off);
+    const int st = a.b.strand[rid];
+    if (st != '+' && st != '-') { if (lane == 0) a.info[rid].status = C3_ST_NOT_ASSIGNED; continue; }
+    const int sid = a.b.splint_id[rid];
+    const int S = a.sp_len[sid];
+    const uint8_t* sp = a.sp_codes + ((size_t)sid * 2 + (st == '-')) * C3_SPLINT_MAX;
+    const uint32_t* pk = a.b.pk + a.b.woff[rid];
+    int32_t* track = a.track + off;
+    const int pad = 64 * R - S;
+    int code[R], hprev[R], P[R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      int i = lane * R + k - pad;
+      code[k] = (i >= 0) ? (int)sp[i] : 5;   // padding rows never match
+      hprev[k] = 0; P[k] = 0;
+    }
+    int W = 0, up_prev = 0;
+    // lane 63 finishes diagonal d = t - c0 at step t
+    const int c0 = 63 * (R + 1) + (R - 1) - pad;
+    const int T_end = L + c0;                 // last useful step is L-1+c0
+    for (int t0 = 0; t0 < T_end; t0 += 16) {
+      const bool fast = (t0 >= 63) && (t0 + 15 < L);
+      if (fast) {
+        const int jb = t0 - lane;
+        const uint32_t w0 = pk[jb >> 4], w1 = pk[(jb >> 4) + 1];
+        const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, (jb & 15) * 2);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          int rc = (x >> (2 * s)) & 3;
+          conk_step<R, false>(rc, false, hprev, P, W, up_prev, code, a.match, a.mismatch, a.penalty);
+          int d = t0 + s - c0;
+          if (lane == 63 && d >= 0 && d < L) track[d] = P[R - 1];
+        }
+      } else {
+        for (int s = 0; s < 16; ++s) {
+          int j = t0 + s - lane;
+          bool oob = (j < 0) || (j >= L);
+          int rc = oob ? 4 : c3_code_at(pk, j);
+          conk_step<R, true>(rc, oob, hprev, P, W, up_prev, code, a.match, a.mismatch, a.penalty);
+          int d = t0 + s - c0;
+          if (lane == 63 && d >= 0 && d < L) track[d] = P[R - 1];
+        }
+      }
+    }
+  }
+}
+
+extern "C" void c3k_launch_conk(const ConkArgs* a, int max_splint, int grid, hipStream_t stream) {
+  int R = (max_splint + 63) / 64;
+  dim3 g(grid), b(256);
+  switch (R) {
+    case 1: hipLaunchKernelGGL(k_conk<1>, g, b, 0, stream, *a); break;
+    case 2: hipLaunchKernelGGL(k_conk<2>, g, b, 0, stream, *a); break;
+    case 3: hipLaunchKernelGGL(k_conk<3>, g, b, 0, stream, *a); break;
+    case 4: hipLaunchKernelGGL(k_conk<4>, g, b, 0, stream, *a); break;
+    case 5: hipLaunchKernelGGL(k_conk<5>, g, b, 0, stream, *a); break;
+    case 6: hipLaunchKernelGGL(k_conk<6>, g, b, 0, stream, *a); break;
+    case 7: hipLaunchKernelGGL(k_conk<7>, g, b, 0, stream, *a); break;
+    default: hipLaunchKernelGGL(k_conk<8>, g, b, 0, stream, *a); break;
+  }
+}

@@ -1,0 +1,249 @@
+// k_peaks.hip -- K2: Savitzky-Golay smoothing x3, median gate, find_peaks, shift/clip, subread split.
+//
+// Replaces, per read (paths relative to /root/reference):
+//   bin/call_peaks.py:8-16      call_peaks(scores, min_dist, 3, 41, 2)
+//   bin/savitzky_golay.py:17-38 (float64 FIR, mirrored-difference padding)
+//   scipy.signal.find_peaks(x, distance=, height=)  (strict local maxima, plateau midpoint,
+//                               inclusive height, highest-first distance suppression)
+//   C3POa.py:106-108,127-155    rounding, peak shift/clip, 0.8-1.2x median subread filter
+// Bit-exact (fp64 included) with oracle/c3o_signal.c: same coefficients (computed on the host
+// with the same expression), same fma order.
+//
+// Mapping: one 256-thread workgroup per read; the track is smoothed through two fp64 scratch
+// rows owned by the workgroup (L2-resident), the median is an 8-pass radix select over
+// order-preserving 64-bit keys with an LDS histogram, peak suppression is an argmax loop.
+#include "c3_dev.h"
+#include "c3_args.h"
+
+#define PK_T 256
+
+
+__device__ __forceinline__ double sg_pad(const double* y, int n, int half, int x) {
+  // bin/savitzky_golay.py:33-35
+  if (x < half) return y[0] - fabs(y[half - x] - y[0]);
+  if (x >= n + half) return y[n - 1] + fabs(y[n - 2 - (x - n - half)] - y[n - 1]);
+  return y[x - half];
+}
+
+__device__ __forceinline__ uint64_t dkey(double v) {
+  uint64_t u = (uint64_t)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double dunkey(uint64_t k) {
+  uint64_t u = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+  return __longlong_as_double((long long)u);
+}
+
+// k-th smallest (0-based) of x[0..n): 8-bit radix select, all threads return the key
+__device__ uint64_t block_select(const double* x, int n, int k, unsigned* hist, int* sh_i) {
+  const int tid = threadIdx.x;
+  uint64_t prefix = 0, mask = 0;
+  for (int pass = 7; pass >= 0; --pass) {
+    const int shift = pass * 8;
+    hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += PK_T) {
+      uint64_t key = dkey(x[i]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      unsigned cum = 0; int digit = 255;
+      for (int bkt = 0; bkt < 256; ++bkt) {
+        unsigned c = hist[bkt];
+        if (cum + c > (unsigned)k) { digit = bkt; break; }
+        cum += c;
+      }
+      sh_i[0] = digit; sh_i[1] = (int)cum;
+    }
+    __syncthreads();
+    prefix |= (uint64_t)sh_i[0] << shift;
+    mask |= (uint64_t)0xff << shift;
+    k -= sh_i[1];
+    __syncthreads();
+  }
+  return prefix;
+}
+
+// C3POa.py:106-108 (Python round = half to even; exact in integers)
+__device__ __forceinline__ int c3_rounding(int x, int base) {
+  int q = x / base, r = x % base;
+  if (2 * r < base) return q * base;
+  if (2 * r > base) return (q + 1) * base;
+  return ((q & 1) ? q + 1 : q) * base;
+}
+
+__global__ __launch_bounds__(PK_T) void k_peaks(PeaksArgs a) {
+  __shared__ unsigned hist[256];
+  __shared__ int sh_i[8];
+  __shared__ double sh_d[PK_T];
+  __shared__ int sh_idx[PK_T];
+  __shared__ int sh_cnt[PK_T + 1];
+  __shared__ int kept[C3_MAX_PEAKS + 1];
+  const int tid = threadIdx.x;
+  double* A = a.bufA + (size_t)blockIdx.x * a.maxL;
+  double* B = a.bufB + (size_t)blockIdx.x * a.maxL;
+  int32_t* cand = a.cand + (size_t)blockIdx.x * (a.maxL / 2 + 2);
+  uint8_t* cst = a.cstate + (size_t)blockIdx.x * (a.maxL / 2 + 2);
+  const int half = (a.window - 1) / 2;
+
+  for (int rid = blockIdx.x; rid < a.b.n; rid += gridDim.x) {
+    C3Info* info = &a.info[rid];
+    __syncthreads();
+    if (info->status == C3_ST_NOT_ASSIGNED) { if (tid == 0) a.n_raw[rid] = 0; continue; }
+    const int64_t off = a.b.off[rid];
+    const int n = (int)(a.b.off[rid + 1] - off);
+    if (n < half + 1 || n < 2) { if (tid == 0) { info->status = C3_ST_TOO_SHORT; a.n_raw[rid] = 0; } continue; }
+    const int32_t* tr = a.track + off;
+    for (int i = tid; i < n; i += PK_T) A[i] = (double)tr[i];
+    __syncthreads();
+    // ---- smoothing passes: A -> B -> A -> ...
+    double* src = A; double* dst = B;
+    for (int it = 0; it < a.iters; ++it) {
+      for (int i = tid; i < n; i += PK_T) {
+        double acc = 0.0;
+        if (i >= half && i + half < n) {
+          const double* y = src + (i - half);
+          for (int k = 0; k < half; ++k) acc = __builtin_fma(a.coef[k], y[k] + y[2 * half - k], acc);
+          acc = __builtin_fma(a.coef[half], y[half], acc);
+        } else {
+          for (int k = 0; k < half; ++k)
+            acc = __builtin_fma(a.coef[k], sg_pad(src, n, half, i + k) + sg_pad(src, n, half, i + 2 * half - k), acc);
+          acc = __builtin_fma(a.coef[half], sg_pad(src, n, half, i + half), acc);
+        }
+        dst[i] = acc;
+      }
+      __syncthreads();
+      double* t = src; src = dst; dst = t;
+    }
+    const double* x = src;    // smoothed track
+    // ---- np.median
+    double med;
+    {
+      uint64_t k1 = block_select(x, n, (n - 1) / 2, hist, sh_i);
+      double v1 = dunkey(k1);
+      if (n & 1) med = v1;
+      else {
+        // next order statistic: v1 again if duplicated, else the smallest value above it
+        int cnt_le = 0; uint64_t mn = ~0ull;
+        for (int i = tid; i < n; i += PK_T) {
+          uint64_t key = dkey(x[i]);
+          if (key <= k1) ++cnt_le; else if (key < mn) mn = key;
+        }
+        sh_cnt[tid] = cnt_le; sh_d[tid] = __longlong_as_double((long long)mn);
+        __syncthreads();
+        for (int s = PK_T / 2; s > 0; s >>= 1) {
+          if (tid < s) {
+            sh_cnt[tid] += sh_cnt[tid + s];
+            uint64_t o = (uint64_t)__double_as_longlong(sh_d[tid + s]), m = (uint64_t)__double_as_longlong(sh_d[tid]);
+            if (o < m) sh_d[tid] = sh_d[tid + s];
+          }
+          __syncthreads();
+        }
+        int tot_le = sh_cnt[0]; uint64_t mnk = (uint64_t)__double_as_longlong(sh_d[0]);
+        __syncthreads();
+        double v2 = (tot_le > n / 2) ? v1 : dunkey(mnk);
+        med = (v1 + v2) / 2.0;
+      }
+    }
+    // ---- max
+    double mx = -1.0e308;
+    for (int i = tid; i < n; i += PK_T) mx = fmax(mx, x[i]);
+    sh_d[tid] = mx;
+    __syncthreads();
+    for (int s = PK_T / 2; s > 0; s >>= 1) { if (tid < s) sh_d[tid] = fmax(sh_d[tid], sh_d[tid + s]); __syncthreads(); }
+    mx = sh_d[0];
+    __syncthreads();
+    int n_kept = 0;
+    if (!(mx < 6 * med)) {
+      const double height = med * 3;
+      // ---- strict local maxima (plateau midpoint) with inclusive height, order preserving
+      const int chunk = (n + PK_T - 1) / PK_T;
+      const int lo = max(1, tid * chunk), hi = min(n - 1, (tid + 1) * chunk);
+      int cnt = 0;
+      for (int pass = 0; pass < 2; ++pass) {
+        int w = (pass == 1) ? sh_cnt[tid] : 0;
+        for (int i = lo; i < hi; ++i) {
+          if (x[i - 1] < x[i]) {
+            int ia = i + 1;
+            while (ia < n - 1 && x[ia] == x[i]) ++ia;
+            if (x[ia] < x[i] && x[i] >= height) {
+              if (pass == 0) ++cnt; else { cand[w] = (i + ia - 1) / 2; cst[w] = 1; ++w; }
+            }
+          }
+        }
+        if (pass == 0) {
+          sh_idx[tid] = cnt;
+          __syncthreads();
+          if (tid == 0) { int c = 0; for (int t = 0; t < PK_T; ++t) { sh_cnt[t] = c; c += sh_idx[t]; } sh_cnt[PK_T] = c; }
+          __syncthreads();
+        }
+      }
+      const int nc = sh_cnt[PK_T];
+      __syncthreads();
+      // ---- _select_by_peak_distance: highest first, equal priority -> later index first
+      const int dist = a.min_dist < 1 ? 1 : a.min_dist;
+      for (;;) {
+        double bv = -1.0e308; int bi = -1;
+        for (int c = tid; c < nc; c += PK_T)
+          if (cst[c] == 1) { double v = x[cand[c]]; if (v > bv || (v == bv && c > bi)) { bv = v; bi = c; } }
+        sh_d[tid] = bv; sh_idx[tid] = bi;
+        __syncthreads();
+        for (int s = PK_T / 2; s > 0; s >>= 1) {
+          if (tid < s) {
+            double ov = sh_d[tid + s]; int oi = sh_idx[tid + s];
+            if (oi >= 0 && (sh_idx[tid] < 0 || ov > sh_d[tid] || (ov == sh_d[tid] && oi > sh_idx[tid]))) { sh_d[tid] = ov; sh_idx[tid] = oi; }
+          }
+          __syncthreads();
+        }
+        const int win = sh_idx[0];
+        __syncthreads();
+        if (win < 0) break;
+        const int wp = cand[win];
+        if (tid == 0) { cst[win] = 2; if (n_kept < C3_MAX_PEAKS) kept[n_kept] = wp; }
+        ++n_kept;
+        for (int c = tid; c < nc; c += PK_T)
+          if (cst[c] == 1) { int dlt = cand[c] - wp; if (dlt < 0) dlt = -dlt; if (dlt < dist) cst[c] = 0; }
+        __syncthreads();
+      }
+    }
+    // ---- thread 0: order the kept peaks, shift, clip, split (C3POa.py:127-155)
+    if (tid == 0) {
+      int status = C3_ST_OK;
+      if (n_kept > C3_MAX_PEAKS - 1) { status = C3_ST_LIMIT; n_kept = 0; }
+      for (int i = 1; i < n_kept; ++i) { int v = kept[i], k = i - 1; while (k >= 0 && kept[k] > v) { kept[k + 1] = kept[k]; --k; } kept[k + 1] = v; }
+      a.n_raw[rid] = n_kept;
+      for (int i = 0; i < n_kept; ++i) a.raw_peaks[(size_t)rid * C3_MAX_PEAKS + i] = kept[i];
+      const int S = a.sp_len[a.b.splint_id[rid]];
+      int np = 0;
+      for (int i = 0; i < n_kept; ++i) { int p = kept[i] + S / 2; if (p < n) info->peaks[np++] = p; }
+      info->n_peaks = np;
+      int ns = 0, hf = 0, ht = 0, fe = 0, tb = 0;
+      if (status == C3_ST_OK && np == 0) status = C3_ST_NO_PEAKS;
+      if (np > 1) {
+        const int nl = np - 1;
+        int* r = sh_idx;                       // reuse LDS: nl <= 255
+        int* srt = sh_cnt;
+        for (int i = 0; i < nl; ++i) srt[i] = r[i] = c3_rounding(info->peaks[i + 1] - info->peaks[i], 50);
+        for (int i = 1; i < nl; ++i) { int v = srt[i], k = i - 1; while (k >= 0 && srt[k] > v) { srt[k + 1] = srt[k]; --k; } srt[k + 1] = v; }
+        const double med2 = (nl & 1) ? (double)srt[nl / 2] : ((double)srt[nl / 2 - 1] + (double)srt[nl / 2]) / 2.0;
+        const double lo8 = med2 * 0.8, hi12 = med2 * 1.2;
+        for (int i = 0; i < nl; ++i)
+          if (lo8 <= (double)r[i] && (double)r[i] <= hi12) { info->sub_beg[ns] = info->peaks[i]; info->sub_end[ns] = info->peaks[i + 1]; ++ns; }
+        if (info->peaks[0] > 100) { hf = 1; fe = info->peaks[0]; }
+        if (n - info->peaks[np - 1] > 100) { ht = 1; tb = info->peaks[np - 1]; }
+      } else if (np == 1) {
+        hf = 1; fe = info->peaks[0]; ht = 1; tb = info->peaks[0];
+      }
+      info->n_sub = ns; info->has_front = hf; info->has_tail = ht; info->front_end = fe; info->tail_beg = tb;
+      if (status == C3_ST_OK && ns == 0) status = C3_ST_NO_CONSENSUS;   // repeats == 0 (zero-repeat rescue: DESIGN.md 6)
+      if (status == C3_ST_OK && ns > C3_MAX_SUB) status = C3_ST_LIMIT;
+      info->status = status;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" void c3k_launch_peaks(const PeaksArgs* a, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL(k_peaks, dim3(grid), dim3(PK_T), 0, stream, *a);
+}

@@ -1,0 +1,148 @@
+/*
+ * c3poa.h -- C ABI of the MI355X-native R2C2 consensus hot path (libc3poa_hip.so).
+ *
+ * The reference (rvolden/C3POa v2.2.3) has no FFI layer of its own: its seams are plain Python
+ * call sites into un-vendored native dependencies.  Every entry point below names the reference
+ * call site(s) it replaces (paths relative to the reference repository root); INTEGRATION.md
+ * shows the ctypes stub a maintainer of the reference would add at each site.
+ *
+ * Conventions
+ *   - plain pointers + sizes, no C++/torch types; all functions return 0 or a negative c3_err
+ *   - one c3_handle per GPU, not thread-safe; create once per worker, never per batch
+ *   - a per-read failure is a status code in c3_read_result, never a batch failure
+ *   - sequences are ASCII; A/C/G/T/U in either case are coded 0..3, every other byte is coded
+ *     as 'A' for alignment purposes (2-bit packing)
+ *   - the library FAILS LOUDLY without a GPU: there is no CPU fallback anywhere in it
+ */
+#ifndef C3POA_H
+#define C3POA_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define C3_MAX_PEAKS 256   /* peaks / kept subreads recorded per read */
+
+typedef enum {
+  C3_E_OK = 0,
+  C3_E_NO_DEVICE = -1,
+  C3_E_HIP = -2,
+  C3_E_ARG = -3,
+  C3_E_NOMEM = -4,
+  C3_E_STATE = -5,
+  C3_E_LIMIT = -6
+} c3_err;
+
+/* per-read status (same numbering as the oracle's) */
+typedef enum {
+  C3_ST_OK = 0,
+  C3_ST_NOT_ASSIGNED = 1,  /* C3POa.py:115 */
+  C3_ST_NO_PEAKS = 2,      /* C3POa.py:125,131 */
+  C3_ST_NO_CONSENSUS = 3,  /* repeats == 0, or polish emitted nothing (determine_consensus.py:44-47,97-99) */
+  C3_ST_TOO_SHORT = 4,     /* shorter than the smoothing half-window */
+  C3_ST_LIMIT = 5          /* capacity limit (subreads > 250, band arena, window graph) */
+} c3_status;
+
+/* algorithm constants of the reference call sites; c3_default_config fills them */
+typedef struct {
+  int device;                                   /* HIP device ordinal */
+  int conk_match, conk_mismatch, conk_penalty;  /* conk.conk(splint, seq, 20): C3POa.py:111,123 */
+  int sg_iters, sg_window, sg_order;            /* call_peaks(scores, d, 3, 41, 2): C3POa.py:111,124 */
+  int mdistcutoff;                              /* -d: C3POa.py:45 */
+  int poa_match, poa_mismatch;                  /* poa.msa_aligner(match=5): determine_consensus.py:30 */
+  int poa_o1, poa_e1, poa_o2, poa_e2;           /* abPOA defaults 4,2,24,1 */
+  int poa_band_b; double poa_band_f;            /* abPOA defaults 10, 0.01 */
+  int pol_match, pol_mismatch, pol_gap;         /* racon 3,-5,-4 */
+  int pol_window, pol_q;                        /* racon window 500; -q 5: determine_consensus.py:92 */
+  int dang_band;                                /* half band of the dangling-piece extension, 128 */
+  int slots_poa, slots_win;                     /* resident wave slots (0 = auto) */
+} c3_config;
+
+typedef struct {
+  int32_t status;
+  int32_t n_peaks;                 /* after shift by len(splint)//2 and clip (C3POa.py:127-132) */
+  int32_t n_sub;                   /* kept subreads = "repeats" (determine_consensus.py:12) */
+  int32_t has_front, has_tail;     /* dangling pieces read[:front_end], read[tail_beg:] (C3POa.py:145-155) */
+  int32_t front_end, tail_beg;
+  int32_t cons_len, draft_len;
+  int32_t n_win;
+  int32_t peaks[C3_MAX_PEAKS];
+  int32_t sub_beg[C3_MAX_PEAKS], sub_end[C3_MAX_PEAKS];   /* pure slices of the read (C3POa.py:141-144) */
+} c3_read_result;
+
+/* kernel time of the last c3_batch_run, measured with hipEvents on the library's own stream */
+typedef struct {
+  float ms_pack, ms_conk, ms_peaks, ms_poa, ms_prep, ms_window, ms_stitch, ms_total;
+  int64_t n_reads, n_bases, n_windows;
+  int64_t cells_conk, cells_poa, cells_polish;
+} c3_timing;
+
+typedef struct c3_handle c3_handle;
+
+void c3_default_config(c3_config* cfg);
+const char* c3_version(void);
+
+/* lifecycle.  Replaces the per-task worker process of C3POa.py:236 (mp.Pool, maxtasksperchild=1). */
+int c3_create(const c3_config* cfg, c3_handle** out);
+void c3_destroy(c3_handle* h);
+const char* c3_last_error(const c3_handle* h);
+
+/* splint table (C3POa.py:231-234: splint_dict[name] = [seq, revcomp(seq)]); the library makes the
+ * reverse complements itself.  cat = concatenated ASCII, off[n+1]. */
+int c3_set_splints(c3_handle* h, int n, const char* cat, const int64_t* off);
+
+/* batch = the `reads` argument of analyze_reads (C3POa.py:110) in SoA form.
+ *   seqs/quals: concatenated ASCII, off[n+1]; splint_id[i] = row of c3_set_splints;
+ *   strand[i] = '+' / '-' (adapter_dict[name][1], C3POa.py:117-122), anything else = not assigned.
+ * Copies to the device and packs to 2 bit; the caller may free its buffers on return. */
+int c3_batch_upload(c3_handle* h, int n, const char* seqs, const char* quals, const int64_t* off,
+                    const int16_t* splint_id, const char* strand);
+
+/* run the resident batch through the hot path (asynchronous on the library's stream).
+ * stages: bit0 conk, bit1 peaks+split, bit2 POA/draft, bit3 polish.  C3_STAGES_ALL = whole path
+ * = one call of analyze_reads (C3POa.py:110-173) minus file I/O. */
+#define C3_STAGE_CONK 1
+#define C3_STAGE_PEAKS 2
+#define C3_STAGE_POA 4
+#define C3_STAGE_POLISH 8
+#define C3_STAGES_ALL 15
+int c3_batch_run(c3_handle* h, int stages);
+int c3_batch_sync(c3_handle* h);
+
+/* results of the resident batch.  cons receives the consensus bytes of read i at cons_off[i]
+ * (cons_off[n+1] is written by the call; capacity cons_cap bytes; returns C3_E_LIMIT and the
+ * needed size in cons_off[n] if too small).  Pass cons=NULL to fetch only the per-read records. */
+int c3_batch_results(c3_handle* h, c3_read_result* res, char* cons, int64_t cons_cap, int64_t* cons_off);
+int c3_batch_timing(c3_handle* h, c3_timing* t);
+
+/* ---- stage probes (tests / per-stage shims), all operate on the resident batch ---- */
+/* conk.conk(splint, seq, penalty) score track of read i (C3POa.py:123): L int32 */
+int c3_fetch_track(c3_handle* h, int read, int32_t* out, int64_t cap);
+/* 3x Savitzky-Golay smoothed track (bin/call_peaks.py:10-11): L doubles.  Only valid for the last
+ * `slots` reads processed, so tests call it with single-read batches. */
+int c3_fetch_smoothed(c3_handle* h, int read, double* out, int64_t cap);
+/* raw call_peaks() indices before the shift (bin/call_peaks.py:15) */
+int c3_fetch_raw_peaks(c3_handle* h, int read, int32_t* out, int cap);
+/* draft consensus before polish (abpoa_cons, determine_consensus.py:32,41,47) */
+int c3_fetch_draft(c3_handle* h, int read, char* out, int cap);
+/* 2-row MSA of a 2-subread read (res.msa_seq, determine_consensus.py:34); returns msa_len */
+int c3_fetch_msa2(c3_handle* h, int read, char* rowA, char* rowB, int cap);
+
+/* stand-alone stage entry points used by the per-stage Python shims.  Each one uploads its
+ * arguments, runs the corresponding kernels and returns the result. */
+/* pyabpoa.msa_aligner(match=5).msa(seqs, out_cons, out_msa) (determine_consensus.py:30,34,43):
+ * msa receives n rows of *msa_len chars (row-major).  quals may be NULL. */
+int c3_poa_msa(c3_handle* h, int n, const char* const* seqs, const int* lens,
+               char* cons, int cons_cap, int* cons_len, char* msa, int64_t msa_cap, int* msa_len);
+/* determine_consensus for repeats >= 1 (determine_consensus.py:29-99): draft + polish.
+ * front/tail may be NULL.  returns consensus length in *out_len (0 = nothing emitted). */
+int c3_determine_consensus(c3_handle* h, int n, const char* const* subs, const char* const* quals,
+                           const int* lens, const char* front, const char* front_q, int front_len,
+                           const char* tail, const char* tail_q, int tail_len,
+                           char* out, int cap, int* out_len, char* draft, int draft_cap, int* draft_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
