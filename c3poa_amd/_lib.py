@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libc3poa_hip.so")
+LIB_PATH = os.environ.get("C3POA_LIB", os.path.join(_HERE, "lib", "libc3poa_hip.so"))
 MAX_PEAKS = 256
 
 STAGE_CONK, STAGE_PEAKS, STAGE_POA, STAGE_POLISH, STAGES_ALL = 1, 2, 4, 8, 15

@@ -83,11 +83,12 @@ struct c3_handle {
   DBuf d_raw, d_nraw, d_sum, d_work, d_bufA, d_bufB, d_cand, d_cst, d_msa, d_msa_off, d_msa_len;
   DBuf s_poa_i, s_poa_nk, s_poa_cells, s_poa_b, s_poa_sc;      // POA scratch
   DBuf s_eH, s_eD, s_lw, d_wrec, d_wlay, d_wbase, d_wout;       // prep / windows
-  DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc;  // window scratch
+  DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc;  // window scratch
   std::vector<Summary> sum; std::vector<int> work;
   int peaks_grid = 0; bool debug_msa = false; bool injected = false;
   int n_windows = 0;
   c3_timing tm;
+  unsigned long long phase_poa[12] = {0}, phase_win[12] = {0};
   int stages_done = 0;
 };
 
@@ -145,7 +146,7 @@ extern "C" void c3_destroy(c3_handle* h) {
                  &h->d_info, &h->d_track, &h->d_draft, &h->d_tpos, &h->d_cons, &h->d_counter, &h->d_raw, &h->d_nraw, &h->d_sum,
                  &h->d_work, &h->d_bufA, &h->d_bufB, &h->d_cand, &h->d_cst, &h->d_msa, &h->d_msa_off, &h->d_msa_len,
                  &h->s_poa_i, &h->s_poa_nk, &h->s_poa_cells, &h->s_poa_b, &h->s_poa_sc, &h->s_eH, &h->s_eD, &h->s_lw, &h->d_wrec,
-                 &h->d_wlay, &h->d_wbase, &h->d_wout, &h->s_win_i, &h->s_win_nk, &h->s_win_h, &h->s_win_d, &h->s_win_b, &h->s_win_sc};
+                 &h->d_wlay, &h->d_wbase, &h->d_wout, &h->s_win_i, &h->s_win_nk, &h->s_win_h, &h->s_win_d, &h->s_win_b, &h->s_win_sc, &h->s_win_desc};
   for (DBuf* b : all) b->release();
   for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(h->ev[i]);
   (void)hipStreamDestroy(h->stream);
@@ -216,7 +217,7 @@ extern "C" int c3_batch_upload(c3_handle* h, int n, const char* seqs, const char
   HIPCHK(h->d_ascii.ensure(T + 16)); HIPCHK(h->d_pk.ensure(sizeof(uint32_t) * (size_t)h->words + 64));
   HIPCHK(h->d_qual.ensure(T + 16)); HIPCHK(h->d_off.ensure(sizeof(int64_t) * (n + 1))); HIPCHK(h->d_woff.ensure(sizeof(int64_t) * (n + 1)));
   HIPCHK(h->d_strand.ensure(n)); HIPCHK(h->d_sid.ensure(sizeof(int16_t) * n)); HIPCHK(h->d_info.ensure(sizeof(C3Info) * (size_t)n));
-  HIPCHK(h->d_counter.ensure(64));
+  HIPCHK(h->d_counter.ensure(256));
   HIPCHK(hipEventRecord(h->ev[0], h->stream));
   HIPCHK(hipMemcpyAsync(h->d_ascii.p, seqs, T, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d_qual.p, quals, T, hipMemcpyHostToDevice, h->stream));
@@ -341,9 +342,11 @@ static int run_poa(c3_handle* h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     a.msa_dbg = h->d_msa.as<uint8_t>(); a.msa_off = h->d_msa_off.as<int64_t>(); a.msa_len = h->d_msa_len.as<int>();
   }
-  HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 64, h->stream));
+  HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 256, h->stream));
+  a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
   c3k_launch_poa(&a, slots, h->stream);
   HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(h->phase_poa, h->d_counter.as<char>() + 64, 96, hipMemcpyDeviceToHost, h->stream));
   return 0;
 }
 
@@ -397,6 +400,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     HIPCHK(h->s_win_i.ensure(sizeof(int) * (N + 1) * NI * slots)); HIPCHK(h->s_win_nk.ensure(sizeof(int) * N * K * 4 * slots));
     HIPCHK(h->s_win_h.ensure(sizeof(int32_t) * (size_t)hcap * slots)); HIPCHK(h->s_win_d.ensure(sizeof(uint16_t) * (size_t)hcap * slots));
     HIPCHK(h->s_win_b.ensure(N * 2 * slots)); HIPCHK(h->s_win_sc.ensure(sizeof(long long) * N * slots));
+    HIPCHK(h->s_win_desc.ensure(sizeof(uint4) * (N + 1) * slots));
     WinArgs a; memset(&a, 0, sizeof(a));
     a.b = dev_batch(h); a.p = dev_params(h->cfg); a.counter = h->d_counter.as<int>(); a.n_win = n_win;
     a.wrec_in = h->d_wrec.as<WinRec>(); a.wrec = h->d_wrec.as<WinRec>(); a.wlay = h->d_wlay.as<WLayer>(); a.NLcap = NLcap;
@@ -407,11 +411,13 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     a.rows = ip; ip += (N + 1) * slots; a.opn = ip; ip += 2 * SN; a.opq = ip; ip += 2 * SN;
     int* nk = h->s_win_nk.as<int>(); a.in_from = nk; a.in_w = nk + SN * K; a.out_to = nk + 2 * SN * K; a.out_w = nk + 3 * SN * K;
     a.base = h->s_win_b.as<uint8_t>(); a.mask = a.base + SN; a.score = h->s_win_sc.as<long long>();
-    a.H = h->s_win_h.as<int32_t>(); a.D = h->s_win_d.as<uint16_t>(); a.Ncap = Ncap; a.K = K; a.hcap = hcap;
+    a.H = h->s_win_h.as<int32_t>(); a.D = h->s_win_d.as<uint16_t>(); a.rdesc = h->s_win_desc.as<uint4>(); a.Ncap = Ncap; a.K = K; a.hcap = hcap;
     a.wout = h->d_wout.as<uint8_t>(); a.wout_cap = wout_cap;
-    HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 64, h->stream));
+    HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 256, h->stream));
+    a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
     c3k_launch_window(&a, slots, h->stream);
     HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h->phase_win, h->d_counter.as<char>() + 64, 96, hipMemcpyDeviceToHost, h->stream));
   }
   HIPCHK(hipEventRecord(h->ev[8], h->stream));
   StitchArgs s; memset(&s, 0, sizeof(s));
@@ -493,6 +499,13 @@ extern "C" int c3_batch_results(c3_handle* h, c3_read_result* res, char* cons, i
   HIPCHK(hipStreamSynchronize(h->stream));
   for (int i = 0; i < h->n; ++i)
     if (res[i].status == C3_ST_OK && res[i].cons_len > 0) memcpy(cons + cons_off[i], arena.data() + h->off[i], (size_t)res[i].cons_len);
+  return C3_E_OK;
+}
+
+// diagnostic builds (-DC3_PHASE_PROF) only: per-phase cycle sums of k_poa (which=0) / k_window (which=1)
+extern "C" int c3_debug_phases(c3_handle* h, int which, unsigned long long* out) {
+  if (!h || !out) return C3_E_ARG;
+  memcpy(out, which ? h->phase_win : h->phase_poa, 96);
   return C3_E_OK;
 }
 

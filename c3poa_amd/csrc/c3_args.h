@@ -16,6 +16,7 @@ struct PoaArgs {
   int *gfirst, *glast, *rem, *mpl, *mpr, *rbeg, *rend, *roff, *opn, *opq, *anchor, *path, *col, *col2t, *nxt;
   long long* score; int32_t *H, *E1, *E2; uint32_t* D; uint8_t* rows2; int Ncap, K, Pcap, cells_cap;
   uint8_t* draft; int32_t* tpos; uint8_t* msa_dbg; const int64_t* msa_off; int* msa_len;
+  unsigned long long* phases;
 };
 struct WLayer { int qbeg, len, begin, end; };
 struct WinRec { int rid, w, n_layers, blen, tgs, out_len, polished, pad_; };
@@ -29,7 +30,8 @@ struct WinArgs {
   const uint8_t* draft;
   uint8_t* base; int *n_in, *n_out, *in_from, *in_w, *out_to, *out_w, *grp, *order, *order2, *index;
   int *gfirst, *glast, *ncov, *rowof, *rows, *anchor, *opn, *opq, *pred; uint8_t* mask; long long* score;
-  int32_t* H; uint16_t* D; int Ncap, K; long long hcap; uint8_t* wout; int wout_cap;
+  int32_t* H; uint16_t* D; uint4* rdesc; int Ncap, K; long long hcap; uint8_t* wout; int wout_cap;
+  unsigned long long* phases;
 };
 struct StitchArgs {
   C3Batch b; C3Info* info; const int* work; int n_work; const WinRec* wrec; const int* win_base; const uint8_t* wout; int wout_cap; char* cons;

@@ -70,4 +70,15 @@ __device__ __forceinline__ int wave_scan_add(int x) {
   return x;
 }
 
+// diagnostic build only (-DC3_PHASE_PROF): per-phase cycle sums, never in the shipped library
+#ifdef C3_PHASE_PROF
+#define PH_DECL unsigned long long ph_t0_ = __builtin_readcyclecounter(), ph_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define PH_MARK(i) { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[i] += t_ - ph_t0_; ph_t0_ = t_; }
+#define PH_FLUSH(p) if (wave_lane() == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd((p) + i_, ph_acc_[i_]); }
+#else
+#define PH_DECL
+#define PH_MARK(i)
+#define PH_FLUSH(p)
+#endif
+
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return c3_hip_fail(h, e_, #x, __LINE__); } while (0)

@@ -70,7 +70,14 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 
 // banded global alignment of subread [qb, qb+Q) against the graph; ops are written BACKWARDS
 // into opn/opq, returns their count (or <0 on failure)
-__device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, long long* cells) {
+#ifdef C3_PHASE_PROF
+#define PHA , unsigned long long& ph_t0_, unsigned long long (&ph_acc_)[12]
+#define PHP , ph_t0_, ph_acc_
+#else
+#define PHA
+#define PHP
+#endif
+__device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, long long* cells PHA) {
   const int K = c.K, n = c.n;
   const int mt = P.poa_match, mm = -P.poa_mismatch;
   const int e1 = P.e1, e2 = P.e2, oe1 = P.o1 + P.e1, oe2 = P.o2 + P.e2;
@@ -87,6 +94,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   }
   for (int v = lane; v < n; v += 64) { c.mpl[v] = INT32_MAX / 2; c.mpr[v] = 0; }
   WSYNC();
+  PH_MARK(0)
   int ncell = 0;
   for (int idx = 0; idx < n; ++idx) {
     const int v = c.order[idx];
@@ -184,6 +192,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     WSYNC();
   }
   *cells += ncell;
+  PH_MARK(1)
   // end cell + traceback (lane 0), ops stored backwards
   int nops = 0;
   if (lane == 0) {
@@ -215,11 +224,12 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   }
   nops = wave_first(nops);
   WSYNC();
+  PH_MARK(2)
   return nops;
 }
 
 // fuse the aligned subread (ops backwards in opn/opq; nops<0 means "first sequence": all inserts)
-__device__ void poa_fuse(Ctx& c, int nops, int qb, int Q, int* path, int lane) {
+__device__ void poa_fuse(Ctx& c, int nops, int qb, int Q, int* path, int lane PHA) {
   const int n_old = c.n;
   if (lane == 0) {
     int n_new = 0, prev = SRC, cur_anchor = 0, nn = c.n;
@@ -251,7 +261,9 @@ __device__ void poa_fuse(Ctx& c, int nops, int qb, int Q, int* path, int lane) {
   WSYNC();
   c.n = c.rem[0];
   WSYNC();
+  PH_MARK(3)
   g_reorder(c, n_old, lane);
+  PH_MARK(4)
 }
 
 // bin/consensus.py:50-74 on code rows (4 = gap); out has msa_len bytes
@@ -281,6 +293,7 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
   c.H = a.H + (size_t)slot * a.cells_cap; c.E1 = a.E1 + (size_t)slot * a.cells_cap; c.E2 = a.E2 + (size_t)slot * a.cells_cap;
   c.D = a.D + (size_t)slot * a.cells_cap; c.rows2 = a.rows2 + slot * 4 * N;
   c.K = a.K; c.Ncap = a.Ncap; c.cells_cap = a.cells_cap;
+  PH_DECL
 
   for (;;) {
     int wi = 0;
@@ -313,10 +326,11 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
       for (int s = 0; s < ns && !fail; ++s) {
         const int qb = info->sub_beg[s], Q = info->sub_end[s] - qb;
         int nops = -1;
-        if (s > 0) { nops = poa_align(c, a.p, qb, Q, lane, &cells); if (nops < 0) { fail = 1; break; } }
-        poa_fuse(c, nops, qb, Q, c.path + poff, lane);
+        if (s > 0) { nops = poa_align(c, a.p, qb, Q, lane, &cells PHP); if (nops < 0) { fail = 1; break; } }
+        poa_fuse(c, nops, qb, Q, c.path + poff, lane PHP);
         poff += Q;
       }
+      PH_MARK(9)
       if (!fail) {
         // ---- MSA columns = aligned blocks in topological order
         if (lane == 0) {
@@ -330,6 +344,7 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
           c.rem[0] = nc;
         }
         WSYNC();
+        PH_MARK(5)
         const int ncol = c.rem[0];
         for (int i = lane; i < ncol; i += 64) c.col2t[i] = -1;
         if (a.msa_dbg) {                       // res.msa_seq rows (codes, 4 = gap), row-major
@@ -403,6 +418,7 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
           WSYNC();
           C = c.rem[0];
         }
+        PH_MARK(6)
         // ---- subread -> draft coordinates
         int poff2 = 0;
         for (int s = 0; s < ns; ++s) {
@@ -413,6 +429,7 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
       }
     }
     WSYNC();
+    PH_MARK(7)
     if (lane == 0) {
       info->draft_len = C;
       if (fail) { info->status = C3_ST_LIMIT; info->draft_len = 0; }
@@ -421,6 +438,7 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
     }
     WSYNC();
   }
+  PH_FLUSH(a.phases)
 }
 
 extern "C" void c3k_launch_poa(const PoaArgs* a, int slots, hipStream_t stream) {

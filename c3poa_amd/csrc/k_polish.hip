@@ -191,22 +191,10 @@ __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
 struct WCtx {
   uint8_t* base; int *n_in, *n_out, *in_from, *in_w, *out_to, *out_w, *grp, *order, *order2, *index;
   int *gfirst, *glast, *ncov, *rowof, *rows, *anchor, *opn, *opq, *pred; uint8_t* mask; long long* score;
-  int32_t* H; uint16_t* D;
+  int32_t* H; uint16_t* D; uint4* rdesc;
   int K, n, Ncap; long long hcap;
 };
 
-__device__ __forceinline__ void w_add_edge(WCtx& c, int u, int v, int w) {
-  const int K = c.K;
-  for (int k = 0; k < c.n_out[u]; ++k)
-    if (c.out_to[u * K + k] == v) {
-      c.out_w[u * K + k] += w;
-      for (int t = 0; t < c.n_in[v]; ++t) if (c.in_from[v * K + t] == u) { c.in_w[v * K + t] += w; break; }
-      return;
-    }
-  int no = c.n_out[u], ni = c.n_in[v];
-  c.out_to[u * K + no] = v; c.out_w[u * K + no] = w; c.n_out[u] = no + 1;
-  c.in_from[v * K + ni] = u; c.in_w[v * K + ni] = w; c.n_in[v] = ni + 1;
-}
 __device__ void w_blocks(WCtx& c, int lane) {
   for (int i = lane; i < c.n; i += 64) { c.gfirst[i] = 1 << 30; c.glast[i] = -1; }
   WSYNC();
@@ -227,47 +215,89 @@ __device__ void w_reorder(WCtx& c, int n_old, int lane) {
   w_blocks(c, lane);
 }
 
-// all DP rows of one layer; lane owns columns lane*CPL .. lane*CPL+CPL-1 (element (lane,c) of a
-// row lives at c*64+lane).  Returns 0, or -1 if the matrix does not fit.
+// Row descriptors of one alignment, built in parallel before the DP so that the row loop has no
+// dependent graph loads: x = base | np<<8 | overflow<<16, y = p0 | p1<<16, z = p2 | p3<<16
+// (p = DP row of a masked predecessor in in-edge order; row 0 = the virtual start row).
+__device__ void win_build_desc(WCtx& c, int R, int lane) {
+  const int K = c.K;
+  for (int r = 1 + lane; r <= R; r += 64) {
+    const int v = c.rows[r];
+    const int nin = c.n_in[v];
+    unsigned p[4] = {0, 0, 0, 0};
+    int np = 0;
+    for (int k = 0; k < nin; ++k) {
+      const int pr = c.rowof[c.in_from[v * K + k]];
+      if (pr < 0) continue;
+      if (np < 4) p[np] = (unsigned)pr;
+      ++np;
+    }
+    unsigned ovf = np > 4;
+    if (np == 0) np = 1;                      // no masked predecessor: virtual row 0
+    uint4 d; d.x = (unsigned)c.base[v] | ((unsigned)min(np, 255) << 8) | (ovf << 16);
+    d.y = p[0] | (p[1] << 16); d.z = p[2] | (p[3] << 16); d.w = 0;
+    c.rdesc[r] = d;
+  }
+  WSYNC();
+}
+
+// All DP rows of one layer.  Lane owns columns lane*CPL .. lane*CPL+CPL-1 (element (lane,cc) of a
+// row lives at cc*64+lane), so every lane only ever re-reads cells it stored itself: no barrier in
+// the row loop.  The row just computed stays in registers and feeds the next row directly (the
+// common predecessor); older predecessor rows are fetched with CPL coalesced loads.
+// D cell = type (0 diag, 1 vertical, 2 horizontal) | (row - predecessor row) << 2.
 template <int CPL>
 __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane) {
   const int RS = 64 * CPL, K = c.K;
   const int mt = P.pol_match, mm = P.pol_mismatch, g = P.pol_gap;
-  if ((long long)(R + 1) * RS > c.hcap) return -1;
-  int qc[CPL];
+  if ((long long)(R + 1) * RS > c.hcap || R >= 16383) return -1;
+  int qc[CPL], hcur[CPL];
 #pragma unroll
   for (int cc = 0; cc < CPL; ++cc) {
     const int j = lane * CPL + cc;
     qc[cc] = (j >= 1 && j <= Q) ? c3_code_at(pk, qbeg + j - 1) : 7;
-    if (j <= Q) { c.H[cc * 64 + lane] = j * g; c.D[cc * 64 + lane] = 2; }   // virtual row 0
+    hcur[cc] = j * g;                                                       // virtual row 0
+    if (j <= Q) { c.H[cc * 64 + lane] = j * g; c.D[cc * 64 + lane] = 2; }
   }
-  WSYNC();
+  uint4 dn = c.rdesc[1 <= R ? 1 : 0];
   for (int r = 1; r <= R; ++r) {
-    const int v = c.rows[r];
-    const int vb = c.base[v];
-    const int nin = c.n_in[v];
+    const uint4 de = dn;
+    if (r < R) dn = c.rdesc[r + 1];                                         // prefetch the next descriptor
+    const int vb = de.x & 0xff, np = (de.x >> 8) & 0xff;
+    const bool ovf = (de.x >> 16) & 1;
     int bd[CPL], dd[CPL], bv[CPL], dv[CPL];
 #pragma unroll
     for (int cc = 0; cc < CPL; ++cc) { bd[cc] = INT32_MIN; bv[cc] = INT32_MIN; dd[cc] = 0; dv[cc] = 0; }
-    int np = 0;
-    for (int k = 0; k <= nin; ++k) {
-      int prow, kk;
-      if (k < nin) { prow = c.rowof[c.in_from[v * K + k]]; kk = k; if (prow < 0) continue; ++np; }
-      else { if (np > 0) break; prow = 0; kk = 0x3fff; }          // no masked predecessor: virtual row
-      const int32_t* hp_ = c.H + (size_t)prow * RS;
+    int seen = 0, kedge = 0;
+    for (int t = 0; t < np; ++t) {
+      int prow;
+      if (!ovf) prow = (t == 0) ? (de.y & 0xffff) : (t == 1) ? (de.y >> 16) : (t == 2) ? (de.z & 0xffff) : (de.z >> 16);
+      else {                                                                 // >4 predecessors: walk the in-edges
+        const int v = c.rows[r];
+        prow = -1;
+        while (kedge < c.n_in[v]) { int pr = c.rowof[c.in_from[v * K + kedge]]; ++kedge; if (pr >= 0) { prow = pr; break; } }
+        if (prow < 0) break;
+      }
+      ++seen;
+      const int dl = (r - prow) << 2;
       int hp[CPL];
+      if (prow == r - 1) {
 #pragma unroll
-      for (int cc = 0; cc < CPL; ++cc) hp[cc] = hp_[cc * 64 + lane];
-      const int hleft = wave_shr1(hp[CPL - 1], INT32_MIN);       // column lane*CPL-1 of the predecessor
+        for (int cc = 0; cc < CPL; ++cc) hp[cc] = hcur[cc];
+      } else {
+        const int32_t* hp_ = c.H + (size_t)prow * RS;
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) hp[cc] = hp_[cc * 64 + lane];
+      }
+      const int hleft = wave_shr1(hp[CPL - 1], INT32_MIN);                   // column lane*CPL-1 of the predecessor
 #pragma unroll
       for (int cc = 0; cc < CPL; ++cc) {
         const int hd = cc == 0 ? hleft : hp[cc - 1];
-        if (hd != INT32_MIN) { int cnd = hd + ((vb == qc[cc]) ? mt : mm); if (cnd > bd[cc]) { bd[cc] = cnd; dd[cc] = 0 | (kk << 2); } }
+        if (hd != INT32_MIN) { int cnd = hd + ((vb == qc[cc]) ? mt : mm); if (cnd > bd[cc]) { bd[cc] = cnd; dd[cc] = 0 | dl; } }
         int cv = hp[cc] + g;
-        if (cv > bv[cc]) { bv[cc] = cv; dv[cc] = 1 | (kk << 2); }
+        if (cv > bv[cc]) { bv[cc] = cv; dv[cc] = 1 | dl; }
       }
     }
-    // vertical beats diagonal only when strictly greater (in place: bd/dd become hv/dir)
+    // vertical beats diagonal only when strictly greater (in place: bd/dd become the pre-gap H / dir)
     int run = C3_NEG2;
 #pragma unroll
     for (int cc = 0; cc < CPL; ++cc) {
@@ -278,7 +308,7 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
     }
     // horizontal gap: in-lane prefix + one cross-lane max-scan
     const int s = wave_scan_max(run);
-    int ex = wave_shr1(s, C3_NEG2);                               // max over all previous lanes
+    int ex = wave_shr1(s, C3_NEG2);                                          // max over all previous lanes
     int32_t* hrow = c.H + (size_t)r * RS; uint16_t* drow = c.D + (size_t)r * RS;
 #pragma unroll
     for (int cc = 0; cc < CPL; ++cc) {
@@ -288,10 +318,11 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
       const int lf = ex + g * j;
       if (j > 0 && lf > hh) { hh = lf; d = 2; }
       ex = max(ex, y);
+      hcur[cc] = hh;
       if (j <= Q) { hrow[cc * 64 + lane] = hh; drow[cc * 64 + lane] = (uint16_t)d; }
     }
-    WSYNC();
   }
+  WSYNC();
   return 0;
 }
 
@@ -299,7 +330,7 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
 __device__ int win_rows_lin(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane) {
   const int RS = ((Q + 1 + 63) / 64) * 64, K = c.K;
   const int mt = P.pol_match, mm = P.pol_mismatch, g = P.pol_gap;
-  if ((long long)(R + 1) * RS > c.hcap) return -1;
+  if ((long long)(R + 1) * RS > c.hcap || R >= 16383) return -1;
   for (int j = lane; j <= Q; j += 64) { c.H[j] = j * g; c.D[j] = 2; }
   WSYNC();
   for (int r = 1; r <= R; ++r) {
@@ -314,14 +345,15 @@ __device__ int win_rows_lin(WCtx& c, const C3Params& P, const uint32_t* pk, int 
       const int qc = (act && j >= 1) ? c3_code_at(pk, qbeg + j - 1) : 7;
       int bd = INT32_MIN, dd = 0, bv = INT32_MIN, dv = 0, np = 0;
       for (int k = 0; k <= nin; ++k) {
-        int prow, kk;
-        if (k < nin) { prow = c.rowof[c.in_from[v * K + k]]; kk = k; if (prow < 0) continue; ++np; }
-        else { if (np > 0) break; prow = 0; kk = 0x3fff; }
+        int prow;
+        if (k < nin) { prow = c.rowof[c.in_from[v * K + k]]; if (prow < 0) continue; ++np; }
+        else { if (np > 0) break; prow = 0; }
+        const int dl = (r - prow) << 2;
         const int32_t* hp_ = c.H + (size_t)prow * RS;
         if (act) {
-          if (j > 0) { int cnd = hp_[j - 1] + ((vb == qc) ? mt : mm); if (cnd > bd) { bd = cnd; dd = 0 | (kk << 2); } }
+          if (j > 0) { int cnd = hp_[j - 1] + ((vb == qc) ? mt : mm); if (cnd > bd) { bd = cnd; dd = 0 | dl; } }
           int cv = hp_[j] + g;
-          if (cv > bv) { bv = cv; dv = 1 | (kk << 2); }
+          if (cv > bv) { bv = cv; dv = 1 | dl; }
         }
       }
       int hv = bd, dir = dd;
@@ -349,6 +381,7 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
   if (need <= 2) cpl = 2; else if (need <= 4) cpl = 4; else if (need <= 6) cpl = 6; else if (need <= 8) cpl = 8;
   else if (need <= 10) cpl = 10; else cpl = 0;
   *cpl_out = cpl; *rs_out = cpl ? 64 * cpl : need * 64;
+  if (cpl) win_build_desc(c, R, lane);
   switch (cpl) {
     case 2: return win_rows<2>(c, P, pk, qbeg, Q, R, lane);
     case 4: return win_rows<4>(c, P, pk, qbeg, Q, R, lane);
@@ -371,15 +404,17 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
   c.rowof = a.rowof + slot * N; c.rows = a.rows + slot * (N + 1); c.anchor = a.anchor + slot * N;
   c.opn = a.opn + slot * 2 * N; c.opq = a.opq + slot * 2 * N; c.pred = a.pred + slot * N;
   c.mask = a.mask + slot * N; c.score = a.score + slot * N;
-  c.H = a.H + (size_t)slot * a.hcap; c.D = a.D + (size_t)slot * a.hcap;
+  c.H = a.H + (size_t)slot * a.hcap; c.D = a.D + (size_t)slot * a.hcap; c.rdesc = a.rdesc + slot * (N + 1);
   c.K = a.K; c.Ncap = a.Ncap; c.hcap = a.hcap;
   const C3Params& P = a.p;
+  PH_DECL
 
   for (;;) {
     int wi = 0;
     if (lane == 0) wi = atomicAdd(a.counter, 1);
     wi = wave_first(wi);
     if (wi >= a.n_win) break;
+    PH_MARK(9)
     const WinRec rec = a.wrec_in[wi];
     const int rid = rec.rid, blen = rec.blen, nl = rec.n_layers;
     const int64_t off = a.b.off[rid];
@@ -404,6 +439,7 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
       c.n = blen;
       WSYNC();
       w_blocks(c, lane);
+      PH_MARK(0)
       // ---- stable order of the layers by begin position (tiny; every lane computes it)
       const int offset = (int)(0.01 * (double)blen);
       for (int t = 0; t < nl && !fail; ++t) {
@@ -439,6 +475,7 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
           }
           WSYNC();
         }
+        PH_MARK(1)
         int R = 0;
         for (int i0 = 0; i0 < c.n; i0 += 64) {        // order-preserving compaction
           const int i = i0 + lane;
@@ -452,8 +489,10 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
           R += __popcll(bal);
         }
         WSYNC();
+        PH_MARK(2)
         int cpl = 0, RS = 0;
         if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS) < 0) { fail = 1; break; }
+        PH_MARK(3)
         cells += (long long)(R + 1) * (Q + 1);
         // ---- end row: masked nodes without masked successors; first maximum in order
         int bs = INT32_MIN, br = INT32_MAX / 2;
@@ -467,52 +506,80 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
         }
         const int gbs = wave_max(bs);
         const int gbr = wave_min(bs == gbs ? br : INT32_MAX / 2);
-        // ---- traceback + fusion (lane 0)
-        const int n_old = c.n;
+        PH_MARK(4)
+        // ---- traceback (lane 0; one dependent load per step): rq[q] = DP row aligned to query base q, 0 = insertion
+        int* rq = c.opq; int* tq = c.opn;
         if (lane == 0) {
-          int nops = 0;
           int r = (gbs == INT32_MIN) ? 0 : gbr, j = Q;
           while (r > 0 || j > 0) {
-            const int dir = c.D[(size_t)r * RS + win_idx(j, cpl)], ty = dir & 3, k = dir >> 2;
-            if (ty == 2) { c.opn[nops] = -1; c.opq[nops] = j - 1; ++nops; --j; continue; }
-            const int v = c.rows[r];
-            const int nr = (k == 0x3fff) ? 0 : c.rowof[c.in_from[v * c.K + k]];
-            if (ty == 0) { c.opn[nops] = v; c.opq[nops] = j - 1; --j; } else { c.opn[nops] = v; c.opq[nops] = -1; }
-            ++nops;
-            r = nr;
+            const int d = c.D[(size_t)r * RS + win_idx(j, cpl)], ty = d & 3;
+            if (ty == 2) { rq[j - 1] = 0; --j; continue; }
+            if (ty == 0) { rq[j - 1] = r; --j; }
+            r -= d >> 2;
           }
-          int n_new = 0, prev = -1, prev_w = 0, cur_anchor = -1, nn = c.n;
-          for (int t2 = nops - 1; t2 >= 0; --t2) {
-            const int v = c.opn[t2], qp = c.opq[t2];
-            if (qp < 0) continue;
-            const int cb = c3_code_at(pk, l.qbeg + qp), w = (int)qual[l.qbeg + qp] - 33;
-            int tn;
-            if (v >= 0) {
-              const int rr = c.grp[v];
-              cur_anchor = c.glast[rr];
-              tn = -1;
-              if (c.base[v] == cb) tn = v;
-              else for (int i = c.gfirst[rr]; i <= c.glast[rr]; ++i) { int x = c.order[i]; if (c.base[x] == cb) { tn = x; break; } }
-              if (tn < 0) {
-                if (nn >= c.Ncap) { nn = -1; break; }
-                tn = nn++; c.base[tn] = (uint8_t)cb; c.n_in[tn] = 0; c.n_out[tn] = 0; c.grp[tn] = rr; c.ncov[tn] = 0; c.anchor[n_new++] = cur_anchor;
-              }
-            } else {
-              if (nn >= c.Ncap) { nn = -1; break; }
-              tn = nn++; c.base[tn] = (uint8_t)cb; c.n_in[tn] = 0; c.n_out[tn] = 0; c.grp[tn] = tn; c.ncov[tn] = 0; c.anchor[n_new++] = cur_anchor;
-            }
-            if (prev >= 0) w_add_edge(c, prev, tn, prev_w + w);
-            c.ncov[tn]++;
-            prev = tn; prev_w = w;
-          }
-          c.pred[0] = nn;
         }
         WSYNC();
-        const int nn = c.pred[0];
+        PH_MARK(5)
+        // ---- fusion, parallel over the query bases (every graph node is touched by at most one base)
+        const int n_old = c.n;
+        int carry_anchor = -1, carry_new = 0;
+        for (int q0 = 0; q0 < Q; q0 += 64) {
+          const int q = q0 + lane;
+          const bool act = q < Q;
+          const int r = act ? rq[q] : 0;
+          const int v = r > 0 ? c.rows[r] : -1;
+          const int cb = act ? c3_code_at(pk, l.qbeg + q) : 0;
+          int tgt = -1, gnew = -1, anc = -1;
+          if (v >= 0) {
+            const int rr = c.grp[v];
+            anc = c.glast[rr];
+            if (c.base[v] == cb) tgt = v;
+            else for (int i = c.gfirst[rr]; i <= anc; ++i) { int x = c.order[i]; if (c.base[x] == cb) { tgt = x; break; } }
+            if (tgt < 0) gnew = rr;
+          }
+          const int isnew = act && tgt < 0;
+          const int as = max(wave_scan_max(anc), carry_anchor);       // anchors are non-decreasing along the path
+          carry_anchor = wave_bcast(as, 63);
+          const int ps = wave_scan_add(isnew);
+          const int k = carry_new + ps - isnew;
+          carry_new += wave_bcast(ps, 63);
+          if (isnew) {
+            const int id = n_old + k;
+            if (id < c.Ncap) {
+              c.base[id] = (uint8_t)cb; c.n_in[id] = 0; c.n_out[id] = 0; c.grp[id] = gnew >= 0 ? gnew : id; c.ncov[id] = 0;
+              c.anchor[k] = as;
+            }
+            tgt = id;
+          }
+          if (act) tq[q] = tgt;
+        }
+        const int nn = n_old + carry_new;
+        if (nn > c.Ncap) { fail = 1; break; }
         WSYNC();
-        if (nn < 0) { fail = 1; break; }
+        const int K = c.K;
+        for (int q = lane; q < Q; q += 64) {
+          const int v = tq[q];
+          c.ncov[v] += 1;
+          if (q == 0) continue;
+          const int u = tq[q - 1];
+          const int w = ((int)qual[l.qbeg + q - 1] - 33) + ((int)qual[l.qbeg + q] - 33);
+          const int no = c.n_out[u];
+          int hit = -1;
+          for (int k = 0; k < no; ++k) if (c.out_to[u * K + k] == v) { hit = k; break; }
+          if (hit >= 0) {
+            c.out_w[u * K + hit] += w;
+            for (int t2 = 0; t2 < c.n_in[v]; ++t2) if (c.in_from[v * K + t2] == u) { c.in_w[v * K + t2] += w; break; }
+          } else {
+            const int ni = c.n_in[v];
+            c.out_to[u * K + no] = v; c.out_w[u * K + no] = w; c.n_out[u] = no + 1;
+            c.in_from[v * K + ni] = u; c.in_w[v * K + ni] = w; c.n_in[v] = ni + 1;
+          }
+        }
+        WSYNC();
         c.n = nn;
+        PH_MARK(6)
         w_reorder(c, n_old, lane);
+        PH_MARK(7)
       }
       if (!fail) {
         // ---- spoa heaviest bundle + branch completion (lane 0), coverage trim
@@ -568,6 +635,7 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
         WSYNC();
         olen = c.pred[0];
         WSYNC();
+        PH_MARK(8)
         if (olen < 0) { fail = 1; olen = 0; } else polished = 1;
       }
     }
@@ -578,6 +646,7 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
     }
     WSYNC();
   }
+  PH_FLUSH(a.phases)
 }
 
 // ------------------------------------------------------------------------------------------

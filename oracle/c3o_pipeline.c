@@ -8,6 +8,7 @@
 #include "c3o.h"
 #include <stdlib.h>
 #include <string.h>
+#include <malloc.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -52,6 +53,11 @@ int c3o_process_batch(const char* splint_fwd, const char* splint_rc, int S,
                       const char* seqs, const char* quals, const int64_t* off, int n,
                       const char* strand, const c3o_params* P, int threads,
                       c3o_read_result* results, char* cons, const int64_t* cons_off) {
+  /* keep multi-MB DP buffers on the heap: with the default thresholds every malloc/free of them is
+   * an mmap/munmap, which serialises many-core runs on the kernel's address-space lock */
+  mallopt(M_MMAP_THRESHOLD, 1 << 30);
+  mallopt(M_TRIM_THRESHOLD, 1 << 30);
+  mallopt(M_ARENA_MAX, 1024);
 #ifdef _OPENMP
   if (threads > 0) omp_set_num_threads(threads);
 #endif

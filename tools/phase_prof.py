@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Diagnostic: per-phase cycle shares inside k_poa / k_window (needs the -DC3_PHASE_PROF build:
+C3POA_LIB=c3poa_amd/lib/libc3poa_hip_prof.so python tools/phase_prof.py [n_reads] [cfg])."""
+import ctypes as C
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from c3poa_amd import _lib, synth  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+cfg = sys.argv[2] if len(sys.argv) > 2 else "cfg2"
+recs = list(synth.generate(cfg, n_reads=min(n, 2048)))
+recs = (recs * (n // len(recs) + 1))[:n]
+h = _lib.Handle(mdistcutoff=synth.CONFIGS[cfg]["mdist"])
+h.set_splints([synth.SPLINT1])
+h.upload([r[1] for r in recs], [r[2] for r in recs], [r[3] for r in recs])
+h.run(); h.run()
+print({k: round(v, 2) if isinstance(v, float) else v for k, v in h.timing().items()})
+names = [["remain/init", "DP rows", "traceback", "fuse", "reorder", "columns", "consensus/pairwise", "tpos", "-", "between"],
+         ["backbone", "sort+mask", "compaction", "DP rows", "end select", "traceback", "fuse", "reorder", "consensus", "queue/other"]]
+h.lib.c3_debug_phases.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+for which, kn in ((0, "k_poa"), (1, "k_window")):
+    out = (C.c_uint64 * 12)()
+    h.lib.c3_debug_phases(h.h, which, out)
+    tot = float(sum(out)) or 1.0
+    print(kn, " ".join("%s=%.1f%%" % (names[which][i], 100 * out[i] / tot) for i in range(10) if out[i]))
