@@ -394,10 +394,10 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     const int Ncap = 4 * WL + 64 * NLcap, K = NLcap + 2;
     const long long hcap = (long long)(Ncap + 1) * 64 * 12;
     const size_t N = (size_t)Ncap;
-    const int NI = 21;
+    const int NI = 18;
     const size_t per_slot = N * (NI * 4 + 8 + 2) + N * K * 16 + (size_t)hcap * 6;
     const int slots = auto_slots(h, h->cfg.slots_win, per_slot, n_win, 16);
-    HIPCHK(h->s_win_i.ensure(sizeof(int) * (N + 1) * NI * slots)); HIPCHK(h->s_win_nk.ensure(sizeof(int) * N * K * 4 * slots));
+    HIPCHK(h->s_win_i.ensure(sizeof(int) * N * NI * slots + 64)); HIPCHK(h->s_win_nk.ensure(sizeof(int) * N * K * 4 * slots));
     HIPCHK(h->s_win_h.ensure(sizeof(int32_t) * (size_t)hcap * slots)); HIPCHK(h->s_win_d.ensure(sizeof(uint16_t) * (size_t)hcap * slots));
     HIPCHK(h->s_win_b.ensure(N * 2 * slots)); HIPCHK(h->s_win_sc.ensure(sizeof(long long) * N * slots));
     HIPCHK(h->s_win_desc.ensure(sizeof(uint4) * (N + 1) * slots));
@@ -405,12 +405,8 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     a.b = dev_batch(h); a.p = dev_params(h->cfg); a.counter = h->d_counter.as<int>(); a.n_win = n_win;
     a.wrec_in = h->d_wrec.as<WinRec>(); a.wrec = h->d_wrec.as<WinRec>(); a.wlay = h->d_wlay.as<WLayer>(); a.NLcap = NLcap;
     a.draft = h->d_draft.as<uint8_t>();
-    int* ip = h->s_win_i.as<int>(); const size_t SN = N * slots;
-    int** fields[] = {&a.n_in, &a.n_out, &a.grp, &a.order, &a.order2, &a.index, &a.gfirst, &a.glast, &a.ncov, &a.rowof, &a.anchor, &a.pred};
-    for (auto f : fields) { *f = ip; ip += SN; }
-    a.rows = ip; ip += (N + 1) * slots; a.opn = ip; ip += 2 * SN; a.opq = ip; ip += 2 * SN;
-    int* nk = h->s_win_nk.as<int>(); a.in_from = nk; a.in_w = nk + SN * K; a.out_to = nk + 2 * SN * K; a.out_w = nk + 3 * SN * K;
-    a.base = h->s_win_b.as<uint8_t>(); a.mask = a.base + SN; a.score = h->s_win_sc.as<long long>();
+    a.ibase = h->s_win_i.as<int>(); a.ebase = h->s_win_nk.as<int>();
+    a.base = h->s_win_b.as<uint8_t>(); a.score = h->s_win_sc.as<long long>();
     a.H = h->s_win_h.as<int32_t>(); a.D = h->s_win_d.as<uint16_t>(); a.rdesc = h->s_win_desc.as<uint4>(); a.Ncap = Ncap; a.K = K; a.hcap = hcap;
     a.wout = h->d_wout.as<uint8_t>(); a.wout_cap = wout_cap;
     HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 256, h->stream));

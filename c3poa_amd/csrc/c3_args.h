@@ -28,8 +28,7 @@ struct PrepArgs {
 struct WinArgs {
   C3Batch b; C3Params p; int* counter; int n_win; const WinRec* wrec_in; WinRec* wrec; const WLayer* wlay; int NLcap;
   const uint8_t* draft;
-  uint8_t* base; int *n_in, *n_out, *in_from, *in_w, *out_to, *out_w, *grp, *order, *order2, *index;
-  int *gfirst, *glast, *ncov, *rowof, *rows, *anchor, *opn, *opq, *pred; uint8_t* mask; long long* score;
+  uint8_t* base; int* ibase; int* ebase; long long* score;
   int32_t* H; uint16_t* D; uint4* rdesc; int Ncap, K; long long hcap; uint8_t* wout; int wout_cap;
   unsigned long long* phases;
 };

@@ -188,97 +188,164 @@ __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
 
 // ------------------------------------------------------------------------------------------
 
+// Per-slot scratch of k_window.  Only three base pointers are kept live (the array pointers are
+// base + constant multiples of Ncap), which keeps the uniform state in SGPRs instead of VGPRs.
 struct WCtx {
-  uint8_t* base; int *n_in, *n_out, *in_from, *in_w, *out_to, *out_w, *grp, *order, *order2, *index;
-  int *gfirst, *glast, *ncov, *rowof, *rows, *anchor, *opn, *opq, *pred; uint8_t* mask; long long* score;
-  int32_t* H; uint16_t* D; uint4* rdesc;
+  int* I; int* E; uint8_t* B8; long long* score; int32_t* H; uint8_t* D; uint4* rdesc;
   int K, n, Ncap; long long hcap;
+  __device__ __forceinline__ int* n_in() const { return I; }
+  __device__ __forceinline__ int* n_out() const { return I + (size_t)Ncap; }
+  __device__ __forceinline__ int* grp() const { return I + 2 * (size_t)Ncap; }
+  __device__ __forceinline__ int* order() const { return I + 3 * (size_t)Ncap; }
+  __device__ __forceinline__ int* order2() const { return I + 4 * (size_t)Ncap; }
+  __device__ __forceinline__ int* index() const { return I + 5 * (size_t)Ncap; }
+  __device__ __forceinline__ int* gfirst() const { return I + 6 * (size_t)Ncap; }
+  __device__ __forceinline__ int* glast() const { return I + 7 * (size_t)Ncap; }
+  __device__ __forceinline__ int* ncov() const { return I + 8 * (size_t)Ncap; }
+  __device__ __forceinline__ int* rowof() const { return I + 9 * (size_t)Ncap; }
+  __device__ __forceinline__ int* anchor() const { return I + 10 * (size_t)Ncap; }
+  __device__ __forceinline__ int* pred() const { return I + 11 * (size_t)Ncap; }
+  __device__ __forceinline__ int* hend() const { return I + 11 * (size_t)Ncap; }      // shares pred (disjoint lifetimes)
+  __device__ __forceinline__ int* opn() const { return I + 12 * (size_t)Ncap; }       // 2N
+  __device__ __forceinline__ int* opq() const { return I + 14 * (size_t)Ncap; }       // 2N
+  __device__ __forceinline__ int* rows() const { return I + 16 * (size_t)Ncap; }      // N+1
+  __device__ __forceinline__ int* in_from() const { return E; }
+  __device__ __forceinline__ int* in_w() const { return E + (size_t)Ncap * K; }
+  __device__ __forceinline__ int* out_to() const { return E + 2 * (size_t)Ncap * K; }
+  __device__ __forceinline__ int* out_w() const { return E + 3 * (size_t)Ncap * K; }
+  __device__ __forceinline__ uint8_t* base() const { return B8; }
+  __device__ __forceinline__ uint8_t* mask() const { return B8 + (size_t)Ncap; }
 };
+#define W_INTS 18   // ints of Ncap per slot in WCtx::I (17*Ncap + 1 used)
 
 __device__ void w_blocks(WCtx& c, int lane) {
-  for (int i = lane; i < c.n; i += 64) { c.gfirst[i] = 1 << 30; c.glast[i] = -1; }
+  for (int i = lane; i < c.n; i += 64) { c.gfirst()[i] = 1 << 30; c.glast()[i] = -1; }
   WSYNC();
-  for (int i = lane; i < c.n; i += 64) { int r = c.grp[c.order[i]]; atomicMin(&c.gfirst[r], i); atomicMax(&c.glast[r], i); }
+  for (int i = lane; i < c.n; i += 64) { int r = c.grp()[c.order()[i]]; atomicMin(&c.gfirst()[r], i); atomicMax(&c.glast()[r], i); }
   WSYNC();
 }
 __device__ void w_reorder(WCtx& c, int n_old, int lane) {
   const int n_new = c.n - n_old;
   for (int i = lane; i < n_old; i += 64) {
     int lo = 0, hi = n_new;
-    while (lo < hi) { int m = (lo + hi) >> 1; if (c.anchor[m] < i) lo = m + 1; else hi = m; }
-    c.order2[i + lo] = c.order[i];
+    while (lo < hi) { int m = (lo + hi) >> 1; if (c.anchor()[m] < i) lo = m + 1; else hi = m; }
+    c.order2()[i + lo] = c.order()[i];
   }
-  for (int k = lane; k < n_new; k += 64) c.order2[c.anchor[k] + 1 + k] = n_old + k;
+  for (int k = lane; k < n_new; k += 64) c.order2()[c.anchor()[k] + 1 + k] = n_old + k;
   WSYNC();
-  for (int i = lane; i < c.n; i += 64) { int v = c.order2[i]; c.order[i] = v; c.index[v] = i; }
+  for (int i = lane; i < c.n; i += 64) { int v = c.order2()[i]; c.order()[i] = v; c.index()[v] = i; }
   WSYNC();
   w_blocks(c, lane);
 }
 
 // Row descriptors of one alignment, built in parallel before the DP so that the row loop has no
-// dependent graph loads: x = base | np<<8 | overflow<<16, y = p0 | p1<<16, z = p2 | p3<<16
-// (p = DP row of a masked predecessor in in-edge order; row 0 = the virtual start row).
+// dependent graph loads:
+//   x = base | np<<8 | overflow<<16 | needH<<17 | isend<<18,  y = p0 | p1<<16,  z = p2 | p3<<16
+// p = DP row of a masked predecessor in in-edge order (row 0 = the virtual start row);
+// needH: some masked successor is not the next row, so the H row must be kept in memory;
+// isend: no masked successor, the row is a candidate end of the global alignment.
 __device__ void win_build_desc(WCtx& c, int R, int lane) {
   const int K = c.K;
   for (int r = 1 + lane; r <= R; r += 64) {
-    const int v = c.rows[r];
-    const int nin = c.n_in[v];
+    const int v = c.rows()[r];
+    const int nin = c.n_in()[v];
     unsigned p[4] = {0, 0, 0, 0};
     int np = 0;
     for (int k = 0; k < nin; ++k) {
-      const int pr = c.rowof[c.in_from[v * K + k]];
+      const int pr = c.rowof()[c.in_from()[v * K + k]];
       if (pr < 0) continue;
       if (np < 4) p[np] = (unsigned)pr;
       ++np;
     }
+    unsigned needh = 0, has = 0;
+    for (int k = 0; k < c.n_out()[v]; ++k) {
+      const int sr = c.rowof()[c.out_to()[v * K + k]];
+      if (sr >= 0) { has = 1; if (sr != r + 1) needh = 1; }
+    }
     unsigned ovf = np > 4;
     if (np == 0) np = 1;                      // no masked predecessor: virtual row 0
-    uint4 d; d.x = (unsigned)c.base[v] | ((unsigned)min(np, 255) << 8) | (ovf << 16);
+    uint4 d; d.x = (unsigned)c.base()[v] | ((unsigned)min(np, 255) << 8) | (ovf << 16) | (needh << 17) | ((has ^ 1u) << 18);
     d.y = p[0] | (p[1] << 16); d.z = p[2] | (p[3] << 16); d.w = 0;
     c.rdesc[r] = d;
+    c.hend()[r] = INT32_MIN;
   }
   WSYNC();
 }
 
-// All DP rows of one layer.  Lane owns columns lane*CPL .. lane*CPL+CPL-1 (element (lane,cc) of a
-// row lives at cc*64+lane), so every lane only ever re-reads cells it stored itself: no barrier in
+// predecessor row number t of DP row r (descriptor order); rows with more than 4 masked
+// predecessors walk the in-edge list
+__device__ int win_pred_row(const WCtx& c, const uint4& de, int r, int t) {
+  if (!((de.x >> 16) & 1)) return (t == 0) ? (de.y & 0xffff) : (t == 1) ? (de.y >> 16) : (t == 2) ? (de.z & 0xffff) : (de.z >> 16);
+  const int v = c.rows()[r];
+  int seen = 0;
+  for (int k = 0; k < c.n_in()[v]; ++k) { int pr = c.rowof()[c.in_from()[v * c.K + k]]; if (pr >= 0) { if (seen == t) return pr; ++seen; } }
+  return 0;
+}
+
+// All DP rows of one layer.  Lane owns columns lane*CPL .. lane*CPL+CPL-1 (element (lane,cc) of an
+// H row lives at cc*64+lane), so every lane only ever re-reads cells it stored itself: no barrier in
 // the row loop.  The row just computed stays in registers and feeds the next row directly (the
-// common predecessor); older predecessor rows are fetched with CPL coalesced loads.
-// D cell = type (0 diag, 1 vertical, 2 horizontal) | (row - predecessor row) << 2.
+// common predecessor); H rows go to memory only when a non-adjacent successor will need them.
+//
+// Cells are carried as KEY = score*256 + tag with tag = 255 - p, p = 0..63 diagonal from predecessor
+// t, 64..127 vertical from predecessor t-64, 128 horizontal.  One v_max per candidate then
+// implements "highest score, first candidate in (diag preds, vert preds, horizontal) order" exactly.
+// The D byte of a cell is its tag.
+#define W_TAG_H 127           /* 255 - 128 */
+__device__ __forceinline__ int win_d_type(int tag) { return (255 - tag) >> 6; }       // 0 diag 1 vert 2 horiz
+__device__ __forceinline__ int win_d_pred(int tag) { return (255 - tag) & 63; }
+
 template <int CPL>
-__device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane) {
+__device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane, unsigned long long* dbg) {
   const int RS = 64 * CPL, K = c.K;
-  const int mt = P.pol_match, mm = P.pol_mismatch, g = P.pol_gap;
-  if ((long long)(R + 1) * RS > c.hcap || R >= 16383) return -1;
-  int qc[CPL], hcur[CPL];
+  const int mt8 = P.pol_match * 256, mm8 = P.pol_mismatch * 256, g8 = P.pol_gap * 256;
+  constexpr int DS = (CPL + 3) & ~3, RSD = 64 * DS;                        // D row: natural column order, DS bytes per lane
+  if ((long long)(R + 1) * RSD > c.hcap || R >= 65535) return -1;
+  const int NEG8 = -(1 << 30);
+  int qc[CPL], hcur[CPL], gj8[CPL];
 #pragma unroll
   for (int cc = 0; cc < CPL; ++cc) {
     const int j = lane * CPL + cc;
     qc[cc] = (j >= 1 && j <= Q) ? c3_code_at(pk, qbeg + j - 1) : 7;
-    hcur[cc] = j * g;                                                       // virtual row 0
-    if (j <= Q) { c.H[cc * 64 + lane] = j * g; c.D[cc * 64 + lane] = 2; }
+    hcur[cc] = j * g8;                                                      // virtual row 0
+    gj8[cc] = (j <= Q) ? g8 * j : (1 << 28);                                // columns past Q drop out of the scan
+    if (j <= Q) c.H[cc * 64 + lane] = j * g8;
   }
-  uint4 dn = c.rdesc[1 <= R ? 1 : 0];
-  for (int r = 1; r <= R; ++r) {
-    const uint4 de = dn;
-    if (r < R) dn = c.rdesc[r + 1];                                         // prefetch the next descriptor
+  // gfx9 has ONE in-order vmcnt for loads and stores: consuming any load waits for every older
+  // store.  So the row loop carries no vector loads on its common path -- descriptors come 64 rows at
+  // a time (one per lane) and are broadcast with v_readlane; only rows with a non-adjacent
+  // predecessor touch memory.
+  for (int rb = 1; rb <= R; rb += 64) {
+  uint4 dblk = c.rdesc[min(rb + lane, R)];
+  // pin the wait for this load HERE (the asm "uses" the registers), not inside the row loop
+  asm volatile("" : "+v"(dblk.x), "+v"(dblk.y), "+v"(dblk.z));
+  const int cnt = min(64, R - rb + 1);
+  for (int li = 0; li < cnt; ++li) {
+    const int r = rb + li;
+    uint4 de;
+    de.x = __builtin_amdgcn_readlane(dblk.x, li); de.y = __builtin_amdgcn_readlane(dblk.y, li);
+    de.z = __builtin_amdgcn_readlane(dblk.z, li); de.w = 0;
     const int vb = de.x & 0xff, np = (de.x >> 8) & 0xff;
-    const bool ovf = (de.x >> 16) & 1;
-    int bd[CPL], dd[CPL], bv[CPL], dv[CPL];
+    const bool ovf = (de.x >> 16) & 1, needh = (de.x >> 17) & 1, isend = (de.x >> 18) & 1;
+    if (np > 64) return -1;
+    int sel[CPL], key[CPL];
 #pragma unroll
-    for (int cc = 0; cc < CPL; ++cc) { bd[cc] = INT32_MIN; bv[cc] = INT32_MIN; dd[cc] = 0; dv[cc] = 0; }
-    int seen = 0, kedge = 0;
+    for (int cc = 0; cc < CPL; ++cc) { sel[cc] = (vb == qc[cc]) ? mt8 : mm8; key[cc] = INT32_MIN; }
+    int kedge = 0;
     for (int t = 0; t < np; ++t) {
       int prow;
       if (!ovf) prow = (t == 0) ? (de.y & 0xffff) : (t == 1) ? (de.y >> 16) : (t == 2) ? (de.z & 0xffff) : (de.z >> 16);
       else {                                                                 // >4 predecessors: walk the in-edges
-        const int v = c.rows[r];
+        const int v = c.rows()[r];
         prow = -1;
-        while (kedge < c.n_in[v]) { int pr = c.rowof[c.in_from[v * K + kedge]]; ++kedge; if (pr >= 0) { prow = pr; break; } }
+        while (kedge < c.n_in()[v]) { int pr = c.rowof()[c.in_from()[v * K + kedge]]; ++kedge; if (pr >= 0) { prow = pr; break; } }
         if (prow < 0) break;
       }
-      ++seen;
-      const int dl = (r - prow) << 2;
+#ifdef C3_PHASE_PROF
+      if (prow != r - 1) dbg[0]++;
+      if (t == 0) { dbg[1]++; if (needh) dbg[2]++; }
+#endif
+      const int tagd = 255 - t, tagv = 191 - t;
       int hp[CPL];
       if (prow == r - 1) {
 #pragma unroll
@@ -288,39 +355,45 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc) hp[cc] = hp_[cc * 64 + lane];
       }
-      const int hleft = wave_shr1(hp[CPL - 1], INT32_MIN);                   // column lane*CPL-1 of the predecessor
+      const int hleft = wave_shr1(hp[CPL - 1], NEG8);                        // column lane*CPL-1 of the predecessor
 #pragma unroll
       for (int cc = 0; cc < CPL; ++cc) {
         const int hd = cc == 0 ? hleft : hp[cc - 1];
-        if (hd != INT32_MIN) { int cnd = hd + ((vb == qc[cc]) ? mt : mm); if (cnd > bd[cc]) { bd[cc] = cnd; dd[cc] = 0 | dl; } }
-        int cv = hp[cc] + g;
-        if (cv > bv[cc]) { bv[cc] = cv; dv[cc] = 1 | dl; }
+        key[cc] = max(key[cc], max(hd + sel[cc] + tagd, hp[cc] + g8 + tagv));
       }
     }
-    // vertical beats diagonal only when strictly greater (in place: bd/dd become the pre-gap H / dir)
-    int run = C3_NEG2;
+    // horizontal gap: in-lane prefix + one cross-lane max-scan over y = H - g*j
+    int y[CPL];
+    int run = NEG8;
 #pragma unroll
-    for (int cc = 0; cc < CPL; ++cc) {
-      const int j = lane * CPL + cc;
-      if (bv[cc] > bd[cc]) { bd[cc] = bv[cc]; dd[cc] = dv[cc]; }
-      const int y = (j <= Q) ? bd[cc] - g * j : C3_NEG2;
-      run = max(run, y);
-    }
-    // horizontal gap: in-lane prefix + one cross-lane max-scan
+    for (int cc = 0; cc < CPL; ++cc) { y[cc] = (key[cc] & ~0xff) - gj8[cc]; run = max(run, y[cc]); }
     const int s = wave_scan_max(run);
-    int ex = wave_shr1(s, C3_NEG2);                                          // max over all previous lanes
-    int32_t* hrow = c.H + (size_t)r * RS; uint16_t* drow = c.D + (size_t)r * RS;
+    int ex = wave_shr1(s, NEG8);                                             // max over all previous lanes
+    unsigned dpk[DS / 4];
+#pragma unroll
+    for (int w = 0; w < DS / 4; ++w) dpk[w] = 0;
+    int32_t* hrow = c.H + (size_t)r * RS;
 #pragma unroll
     for (int cc = 0; cc < CPL; ++cc) {
-      const int j = lane * CPL + cc;
-      int hh = bd[cc], d = dd[cc];
-      const int y = (j <= Q) ? hh - g * j : C3_NEG2;
-      const int lf = ex + g * j;
-      if (j > 0 && lf > hh) { hh = lf; d = 2; }
-      ex = max(ex, y);
-      hcur[cc] = hh;
-      if (j <= Q) { hrow[cc * 64 + lane] = hh; drow[cc * 64 + lane] = (uint16_t)d; }
+      const int k2 = max(key[cc], ex + gj8[cc] + W_TAG_H);                   // for j == 0 ex is NEG8: never wins
+      ex = max(ex, y[cc]);
+      hcur[cc] = k2 & ~0xff;
+      dpk[cc / 4] |= (unsigned)(k2 & 0xff) << (8 * (cc & 3));
     }
+    if (needh) {
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) if (lane * CPL + cc <= Q) hrow[cc * 64 + lane] = hcur[cc];
+    }
+    if (isend) {
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) if (lane * CPL + cc == Q) c.hend()[r] = hcur[cc] >> 8;
+    }
+    unsigned* drow = (unsigned*)(c.D + (size_t)r * RSD) + lane * (DS / 4);
+    if (lane * CPL <= Q) {
+#pragma unroll
+      for (int w = 0; w < DS / 4; ++w) drow[w] = dpk[w];
+    }
+  }
   }
   WSYNC();
   return 0;
@@ -330,14 +403,15 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
 __device__ int win_rows_lin(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane) {
   const int RS = ((Q + 1 + 63) / 64) * 64, K = c.K;
   const int mt = P.pol_match, mm = P.pol_mismatch, g = P.pol_gap;
-  if ((long long)(R + 1) * RS > c.hcap || R >= 16383) return -1;
+  if ((long long)(R + 1) * RS > c.hcap || R >= 65535) return -1;
   for (int j = lane; j <= Q; j += 64) { c.H[j] = j * g; c.D[j] = 2; }
   WSYNC();
   for (int r = 1; r <= R; ++r) {
-    const int v = c.rows[r];
-    const int vb = c.base[v];
-    const int nin = c.n_in[v];
-    int32_t* hrow = c.H + (size_t)r * RS; uint16_t* drow = c.D + (size_t)r * RS;
+    const int v = c.rows()[r];
+    const int vb = c.base()[v];
+    const int nin = c.n_in()[v];
+    int32_t* hrow = c.H + (size_t)r * RS; uint8_t* drow = c.D + (size_t)r * RS;
+    const bool isend = (c.rdesc[r].x >> 18) & 1;
     int carry = C3_NEG2;
     for (int c0 = 0; c0 <= Q; c0 += 64) {
       const int j = c0 + lane;
@@ -346,14 +420,14 @@ __device__ int win_rows_lin(WCtx& c, const C3Params& P, const uint32_t* pk, int 
       int bd = INT32_MIN, dd = 0, bv = INT32_MIN, dv = 0, np = 0;
       for (int k = 0; k <= nin; ++k) {
         int prow;
-        if (k < nin) { prow = c.rowof[c.in_from[v * K + k]]; if (prow < 0) continue; ++np; }
+        if (k < nin) { prow = c.rowof()[c.in_from()[v * K + k]]; if (prow < 0) continue; ++np; }
         else { if (np > 0) break; prow = 0; }
-        const int dl = (r - prow) << 2;
+        const int tt = min(np > 0 ? np - 1 : 0, 63);
         const int32_t* hp_ = c.H + (size_t)prow * RS;
         if (act) {
-          if (j > 0) { int cnd = hp_[j - 1] + ((vb == qc) ? mt : mm); if (cnd > bd) { bd = cnd; dd = 0 | dl; } }
+          if (j > 0) { int cnd = hp_[j - 1] + ((vb == qc) ? mt : mm); if (cnd > bd) { bd = cnd; dd = 255 - tt; } }
           int cv = hp_[j] + g;
-          if (cv > bv) { bv = cv; dv = 1 | dl; }
+          if (cv > bv) { bv = cv; dv = 191 - tt; }
         }
       }
       int hv = bd, dir = dd;
@@ -364,30 +438,31 @@ __device__ int win_rows_lin(WCtx& c, const C3Params& P, const uint32_t* pk, int 
       carry = max(carry, wave_bcast(s, 63));
       const int lf = ex + g * j;
       int hh = hv;
-      if (j > 0 && lf > hh) { hh = lf; dir = 2; }
-      if (act) { hrow[j] = hh; drow[j] = (uint16_t)dir; }
+      if (j > 0 && lf > hh) { hh = lf; dir = W_TAG_H; }
+      if (act) { hrow[j] = hh; drow[j] = (uint8_t)dir; }
+      if (isend && j == Q) c.hend()[r] = hh;
     }
     WSYNC();
   }
   return 0;
 }
 
-// element index of column j inside a row for the layout chosen by win_rows_dispatch
-__device__ __forceinline__ int win_idx(int j, int cpl) { return cpl ? (j % cpl) * 64 + j / cpl : j; }
+// byte index of column j inside a D row for the layout chosen by win_rows_dispatch
+__device__ __forceinline__ int win_idx(int j, int cpl) { return cpl ? (j / cpl) * ((cpl + 3) & ~3) + j % cpl : j; }
 
-__device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane, int* cpl_out, int* rs_out) {
+__device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane, int* cpl_out, int* rs_out, unsigned long long* dbg) {
   const int need = (Q + 1 + 63) / 64;
   int cpl;
   if (need <= 2) cpl = 2; else if (need <= 4) cpl = 4; else if (need <= 6) cpl = 6; else if (need <= 8) cpl = 8;
   else if (need <= 10) cpl = 10; else cpl = 0;
-  *cpl_out = cpl; *rs_out = cpl ? 64 * cpl : need * 64;
-  if (cpl) win_build_desc(c, R, lane);
+  *cpl_out = cpl; *rs_out = cpl ? 64 * ((cpl + 3) & ~3) : need * 64;    // D row stride in bytes
+  win_build_desc(c, R, lane);
   switch (cpl) {
-    case 2: return win_rows<2>(c, P, pk, qbeg, Q, R, lane);
-    case 4: return win_rows<4>(c, P, pk, qbeg, Q, R, lane);
-    case 6: return win_rows<6>(c, P, pk, qbeg, Q, R, lane);
-    case 8: return win_rows<8>(c, P, pk, qbeg, Q, R, lane);
-    case 10: return win_rows<10>(c, P, pk, qbeg, Q, R, lane);
+    case 2: return win_rows<2>(c, P, pk, qbeg, Q, R, lane, dbg);
+    case 4: return win_rows<4>(c, P, pk, qbeg, Q, R, lane, dbg);
+    case 6: return win_rows<6>(c, P, pk, qbeg, Q, R, lane, dbg);
+    case 8: return win_rows<8>(c, P, pk, qbeg, Q, R, lane, dbg);
+    case 10: return win_rows<10>(c, P, pk, qbeg, Q, R, lane, dbg);
     default: return win_rows_lin(c, P, pk, qbeg, Q, R, lane);
   }
 }
@@ -396,17 +471,14 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
   const int lane = wave_lane();
   const int slot = blockIdx.x;
   WCtx c;
-  const size_t N = (size_t)a.Ncap, NK = (size_t)a.Ncap * a.K;
-  c.base = a.base + slot * N; c.n_in = a.n_in + slot * N; c.n_out = a.n_out + slot * N;
-  c.in_from = a.in_from + slot * NK; c.in_w = a.in_w + slot * NK; c.out_to = a.out_to + slot * NK; c.out_w = a.out_w + slot * NK;
-  c.grp = a.grp + slot * N; c.order = a.order + slot * N; c.order2 = a.order2 + slot * N; c.index = a.index + slot * N;
-  c.gfirst = a.gfirst + slot * N; c.glast = a.glast + slot * N; c.ncov = a.ncov + slot * N;
-  c.rowof = a.rowof + slot * N; c.rows = a.rows + slot * (N + 1); c.anchor = a.anchor + slot * N;
-  c.opn = a.opn + slot * 2 * N; c.opq = a.opq + slot * 2 * N; c.pred = a.pred + slot * N;
-  c.mask = a.mask + slot * N; c.score = a.score + slot * N;
-  c.H = a.H + (size_t)slot * a.hcap; c.D = a.D + (size_t)slot * a.hcap; c.rdesc = a.rdesc + slot * (N + 1);
+  const size_t N = (size_t)a.Ncap;
+  c.I = a.ibase + (size_t)slot * W_INTS * N; c.E = a.ebase + (size_t)slot * 4 * N * a.K;
+  c.B8 = a.base + (size_t)slot * 2 * N; c.score = a.score + slot * N;
+  c.H = a.H + (size_t)slot * a.hcap; c.D = (uint8_t*)a.D + (size_t)slot * a.hcap; c.rdesc = a.rdesc + slot * (N + 1);
   c.K = a.K; c.Ncap = a.Ncap; c.hcap = a.hcap;
   const C3Params& P = a.p;
+  extern __shared__ int lds_dyn[];                      // [Ncap] scores + [Ncap] u16 predecessors
+  int* s_score = lds_dyn; unsigned short* s_pred = (unsigned short*)(lds_dyn + a.Ncap);
   PH_DECL
 
   for (;;) {
@@ -431,10 +503,10 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
     } else {
       // ---- backbone chain (weight-0 edges, coverage 1)
       for (int i = lane; i < blen; i += 64) {
-        c.base[i] = bb[i]; c.grp[i] = i; c.order[i] = i; c.index[i] = i; c.ncov[i] = 1;
-        c.n_in[i] = i > 0; c.n_out[i] = i + 1 < blen;
-        if (i > 0) { c.in_from[i * c.K] = i - 1; c.in_w[i * c.K] = 0; }
-        if (i + 1 < blen) { c.out_to[i * c.K] = i + 1; c.out_w[i * c.K] = 0; }
+        c.base()[i] = bb[i]; c.grp()[i] = i; c.order()[i] = i; c.index()[i] = i; c.ncov()[i] = 1;
+        c.n_in()[i] = i > 0; c.n_out()[i] = i + 1 < blen;
+        if (i > 0) { c.in_from()[i * c.K] = i - 1; c.in_w()[i * c.K] = 0; }
+        if (i + 1 < blen) { c.out_to()[i * c.K] = i + 1; c.out_w()[i * c.K] = 0; }
       }
       c.n = blen;
       WSYNC();
@@ -455,67 +527,93 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
         const bool full = l.begin < offset && l.end > blen - offset;
         // ---- rows of this alignment (masked sub-graph or everything)
         if (!full) {
-          for (int i = lane; i < c.n; i += 64) c.mask[i] = 0;
+          // spoa Graph::subgraph(begin, end): nodes with id >= begin that reach backbone node `end`
+          // through edges / aligned-block links.  Computed as a shrinking fixpoint over whole aligned
+          // blocks (the block graph is a DAG, so greatest == least fixpoint); a few parallel sweeps.
+          const int K = c.K;
+          const int eidx = c.glast()[c.grp()[l.end]];
+          int* gseed = c.rowof();
+          for (int i = lane; i < c.n; i += 64) { const int v = c.order()[i]; c.mask()[v] = (v >= l.begin && i <= eidx) ? 1 : 0; }
           WSYNC();
-          if (lane == 0) {                  // spoa Graph::subgraph: reverse block sweep
-            const int K = c.K;
-            int i = c.glast[c.grp[l.end]];
-            while (i >= 0) {
-              const int r = c.grp[c.order[i]], f = c.gfirst[r], la = c.glast[r];
-              int seed = 0;
-              for (int t2 = f; t2 <= la && !seed; ++t2) {
-                int x = c.order[t2];
-                if (x < l.begin) continue;
-                if (x == l.end) { seed = 1; break; }
-                for (int k = 0; k < c.n_out[x]; ++k) if (c.mask[c.out_to[x * K + k]]) { seed = 1; break; }
-              }
-              if (seed) for (int t2 = f; t2 <= la; ++t2) { int x = c.order[t2]; if (x >= l.begin) c.mask[x] = 1; }
-              i = f - 1;
+          for (;;) {
+            for (int v = lane; v < c.n; v += 64) if (c.mask()[v]) gseed[c.grp()[v]] = 0;
+            WSYNC();
+            for (int v = lane; v < c.n; v += 64) {
+              if (!c.mask()[v]) continue;
+              int seed = v == l.end;
+              for (int k = 0; k < c.n_out()[v] && !seed; ++k) seed = c.mask()[c.out_to()[v * K + k]];
+              if (seed) gseed[c.grp()[v]] = 1;
             }
+            WSYNC();
+            int changed = 0;
+            for (int v = lane; v < c.n; v += 64) if (c.mask()[v] && !gseed[c.grp()[v]]) { c.mask()[v] = 0; changed = 1; }
+            changed = __ballot(changed) != 0;
+            WSYNC();
+            if (!changed) break;
           }
-          WSYNC();
         }
         PH_MARK(1)
         int R = 0;
         for (int i0 = 0; i0 < c.n; i0 += 64) {        // order-preserving compaction
           const int i = i0 + lane;
-          const int v = i < c.n ? c.order[i] : 0;
-          const bool in = i < c.n && (full || c.mask[v]);
+          const int v = i < c.n ? c.order()[i] : 0;
+          const bool in = i < c.n && (full || c.mask()[v]);
           const unsigned long long bal = __ballot(in);
           if (i < c.n) {
-            if (in) { int r = R + 1 + __popcll(bal & ((1ull << lane) - 1)); c.rows[r] = v; c.rowof[v] = r; }
-            else c.rowof[v] = -1;
+            if (in) { int r = R + 1 + __popcll(bal & ((1ull << lane) - 1)); c.rows()[r] = v; c.rowof()[v] = r; }
+            else c.rowof()[v] = -1;
           }
           R += __popcll(bal);
         }
         WSYNC();
         PH_MARK(2)
         int cpl = 0, RS = 0;
-        if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS) < 0) { fail = 1; break; }
+        unsigned long long dbg_[3] = {0, 0, 0};
+        if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_) < 0) { fail = 1; break; }
+#ifdef C3_PHASE_PROF
+        ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1]; ph_acc_[9] += dbg_[2];
+#endif
         PH_MARK(3)
         cells += (long long)(R + 1) * (Q + 1);
-        // ---- end row: masked nodes without masked successors; first maximum in order
+        // ---- end row: candidate rows (no masked successor) left H[r][Q] in hend; first maximum in order
         int bs = INT32_MIN, br = INT32_MAX / 2;
-        for (int r = 1 + lane; r <= R; r += 64) {
-          const int v = c.rows[r];
-          int has = 0;
-          for (int k = 0; k < c.n_out[v]; ++k) if (c.rowof[c.out_to[v * c.K + k]] >= 0) { has = 1; break; }
-          if (has) continue;
-          const int sc = c.H[(size_t)r * RS + win_idx(Q, cpl)];
-          if (sc > bs) { bs = sc; br = r; }
-        }
+        for (int r = 1 + lane; r <= R; r += 64) { const int sc = c.hend()[r]; if (sc > bs) { bs = sc; br = r; } }
         const int gbs = wave_max(bs);
         const int gbr = wave_min(bs == gbs ? br : INT32_MAX / 2);
         PH_MARK(4)
-        // ---- traceback (lane 0; one dependent load per step): rq[q] = DP row aligned to query base q, 0 = insertion
-        int* rq = c.opq; int* tq = c.opn;
-        if (lane == 0) {
+        // ---- traceback, wave-speculative: lane k fetches the cell k steps down the diagonal; the run of
+        // "diagonal from the previous row" cells is consumed in one go, then the cell that breaks it.
+        // rq[q] = DP row aligned to query base q, 0 = insertion.
+        int* rq = c.opq(); int* tq = c.opn();
+        {
           int r = (gbs == INT32_MIN) ? 0 : gbr, j = Q;
           while (r > 0 || j > 0) {
-            const int d = c.D[(size_t)r * RS + win_idx(j, cpl)], ty = d & 3;
-            if (ty == 2) { rq[j - 1] = 0; --j; continue; }
-            if (ty == 0) { rq[j - 1] = r; --j; }
-            r -= d >> 2;
+            if (r == 0) { for (int q = lane; q < j; q += 64) rq[q] = 0; break; }
+            if (j == 0) break;                                   // only vertical moves remain
+            const int rk = r - lane, jk = j - lane;
+            const bool val = rk >= 1 && jk >= 0;
+            int d = 0, prow = -1;
+            if (val) {
+              d = c.D[(size_t)rk * RS + win_idx(jk, cpl)];
+              if (win_d_type(d) != 2) { const uint4 de = c.rdesc[rk]; prow = ((de.x >> 16) & 1) ? -2 : win_pred_row(c, de, rk, win_d_pred(d)); }
+            }
+            const bool diag1 = val && jk >= 1 && win_d_type(d) == 0 && prow == rk - 1;
+            const unsigned long long bal = __ballot(diag1);
+            const int m = (~bal) ? __builtin_ctzll(~bal) : 64;  // length of the diagonal run
+            if (lane < m) rq[jk - 1] = rk;
+            r -= m; j -= m;
+            if (m < 64 && r > 0 && j >= 0) {
+              // the breaking cell sits in lane m
+              const int db = wave_bcast(d, m);
+              int pb = wave_bcast(prow, m);
+              const int ty = win_d_type(db);
+              if (ty == 2) { if (lane == 0) rq[j - 1] = 0; --j; }
+              else {
+                if (pb == -2) pb = win_pred_row(c, c.rdesc[r], r, win_d_pred(db));   // >4 predecessors (uniform slow path)
+                if (ty == 0) { if (lane == 0) rq[j - 1] = r; --j; }
+                r = pb;
+              }
+            }
           }
         }
         WSYNC();
@@ -527,14 +625,14 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
           const int q = q0 + lane;
           const bool act = q < Q;
           const int r = act ? rq[q] : 0;
-          const int v = r > 0 ? c.rows[r] : -1;
+          const int v = r > 0 ? c.rows()[r] : -1;
           const int cb = act ? c3_code_at(pk, l.qbeg + q) : 0;
           int tgt = -1, gnew = -1, anc = -1;
           if (v >= 0) {
-            const int rr = c.grp[v];
-            anc = c.glast[rr];
-            if (c.base[v] == cb) tgt = v;
-            else for (int i = c.gfirst[rr]; i <= anc; ++i) { int x = c.order[i]; if (c.base[x] == cb) { tgt = x; break; } }
+            const int rr = c.grp()[v];
+            anc = c.glast()[rr];
+            if (c.base()[v] == cb) tgt = v;
+            else for (int i = c.gfirst()[rr]; i <= anc; ++i) { int x = c.order()[i]; if (c.base()[x] == cb) { tgt = x; break; } }
             if (tgt < 0) gnew = rr;
           }
           const int isnew = act && tgt < 0;
@@ -546,8 +644,8 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
           if (isnew) {
             const int id = n_old + k;
             if (id < c.Ncap) {
-              c.base[id] = (uint8_t)cb; c.n_in[id] = 0; c.n_out[id] = 0; c.grp[id] = gnew >= 0 ? gnew : id; c.ncov[id] = 0;
-              c.anchor[k] = as;
+              c.base()[id] = (uint8_t)cb; c.n_in()[id] = 0; c.n_out()[id] = 0; c.grp()[id] = gnew >= 0 ? gnew : id; c.ncov()[id] = 0;
+              c.anchor()[k] = as;
             }
             tgt = id;
           }
@@ -559,20 +657,20 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
         const int K = c.K;
         for (int q = lane; q < Q; q += 64) {
           const int v = tq[q];
-          c.ncov[v] += 1;
+          c.ncov()[v] += 1;
           if (q == 0) continue;
           const int u = tq[q - 1];
           const int w = ((int)qual[l.qbeg + q - 1] - 33) + ((int)qual[l.qbeg + q] - 33);
-          const int no = c.n_out[u];
+          const int no = c.n_out()[u];
           int hit = -1;
-          for (int k = 0; k < no; ++k) if (c.out_to[u * K + k] == v) { hit = k; break; }
+          for (int k = 0; k < no; ++k) if (c.out_to()[u * K + k] == v) { hit = k; break; }
           if (hit >= 0) {
-            c.out_w[u * K + hit] += w;
-            for (int t2 = 0; t2 < c.n_in[v]; ++t2) if (c.in_from[v * K + t2] == u) { c.in_w[v * K + t2] += w; break; }
+            c.out_w()[u * K + hit] += w;
+            for (int t2 = 0; t2 < c.n_in()[v]; ++t2) if (c.in_from()[v * K + t2] == u) { c.in_w()[v * K + t2] += w; break; }
           } else {
-            const int ni = c.n_in[v];
-            c.out_to[u * K + no] = v; c.out_w[u * K + no] = w; c.n_out[u] = no + 1;
-            c.in_from[v * K + ni] = u; c.in_w[v * K + ni] = w; c.n_in[v] = ni + 1;
+            const int ni = c.n_in()[v];
+            c.out_to()[u * K + no] = v; c.out_w()[u * K + no] = w; c.n_out()[u] = no + 1;
+            c.in_from()[v * K + ni] = u; c.in_w()[v * K + ni] = w; c.n_in()[v] = ni + 1;
           }
         }
         WSYNC();
@@ -582,59 +680,87 @@ __global__ __launch_bounds__(64) void k_window(WinArgs a) {
         PH_MARK(7)
       }
       if (!fail) {
-        // ---- spoa heaviest bundle + branch completion (lane 0), coverage trim
-        if (lane == 0) {
+        // ---- spoa heaviest bundle.  Scores / predecessors live in LDS; the forward sweep takes the
+        // nodes 64 at a time: their in-edges are fetched in parallel, then consumed in order with
+        // lane broadcasts (no dependent global loads on the serial path).
+        {
           const int K = c.K, n = c.n;
-          for (int v = 0; v < n; ++v) { c.score[v] = -1; c.pred[v] = -1; }
+          for (int v = lane; v < n; v += 64) { s_score[v] = -1; s_pred[v] = 0xffff; }
+          WSYNC();
           int max_id = 0;
-          for (int i = 0; i < n; ++i) {
-            const int v = c.order[i];
-            for (int k = 0; k < c.n_in[v]; ++k) {
-              const int u = c.in_from[v * K + k]; const long long w = c.in_w[v * K + k];
-              if (c.score[v] < w || (c.score[v] == w && c.score[c.pred[v]] <= c.score[u])) { c.score[v] = w; c.pred[v] = u; }
+          for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
+            int v = 0, nin = 0, u0 = 0, w0 = 0, u1 = 0, w1 = 0;
+            if (i < n) {
+              v = c.order()[i]; nin = c.n_in()[v];
+              if (nin > 0) { u0 = c.in_from()[v * K]; w0 = c.in_w()[v * K]; }
+              if (nin > 1) { u1 = c.in_from()[v * K + 1]; w1 = c.in_w()[v * K + 1]; }
             }
-            if (c.pred[v] != -1) c.score[v] += c.score[c.pred[v]];
-            if (c.score[max_id] < c.score[v]) max_id = v;
-          }
-          while (c.n_out[max_id] > 0) {
-            const int v = max_id;
-            for (int k = 0; k < c.n_out[v]; ++k) {
-              const int t2 = c.out_to[v * K + k];
-              for (int e = 0; e < c.n_in[t2]; ++e) { int u = c.in_from[t2 * K + e]; if (u != v) c.score[u] = -1; }
-            }
-            long long ms = 0; int mid = -1;
-            for (int i = c.index[v] + 1; i < n; ++i) {
-              const int x = c.order[i];
-              c.score[x] = -1; c.pred[x] = -1;
-              for (int k = 0; k < c.n_in[x]; ++k) {
-                const int u = c.in_from[x * K + k]; const long long w = c.in_w[x * K + k];
-                if (c.score[u] == -1) continue;
-                if (c.score[x] < w || (c.score[x] == w && c.score[c.pred[x]] <= c.score[u])) { c.score[x] = w; c.pred[x] = u; }
+            const int cnt = min(64, n - i0);
+            for (int t = 0; t < cnt; ++t) {
+              const int vv = wave_bcast(v, t), nn = wave_bcast(nin, t);
+              int sc = -1, pr = -1;
+              for (int k = 0; k < nn; ++k) {
+                int u, w;
+                if (k == 0) { u = wave_bcast(u0, t); w = wave_bcast(w0, t); }
+                else if (k == 1) { u = wave_bcast(u1, t); w = wave_bcast(w1, t); }
+                else { u = c.in_from()[vv * K + k]; w = c.in_w()[vv * K + k]; }
+                if (sc < w || (sc == w && s_score[pr] <= s_score[u])) { sc = w; pr = u; }
               }
-              if (c.pred[x] != -1) c.score[x] += c.score[c.pred[x]];
-              if (ms < c.score[x]) { ms = c.score[x]; mid = x; }
+              if (pr != -1) sc += s_score[pr];
+              if (lane == 0) { s_score[vv] = sc; s_pred[vv] = (unsigned short)pr; }
+              __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the LDS write has landed
+              if (s_score[max_id] < sc) max_id = vv;
             }
-            if (mid < 0) break;
-            max_id = mid;
           }
-          // consensus path backwards into opn, then trim + emit
+          WSYNC();
+          if (c.n_out()[max_id] > 0) {
+            // branch completion (rare): spill to the global arrays and run spoa's re-scoring there
+            for (int v = lane; v < n; v += 64) { c.score[v] = s_score[v]; c.pred()[v] = s_pred[v] == 0xffff ? -1 : (int)s_pred[v]; }
+            WSYNC();
+            if (lane == 0) {
+              while (c.n_out()[max_id] > 0) {
+                const int v = max_id;
+                for (int k = 0; k < c.n_out()[v]; ++k) {
+                  const int t2 = c.out_to()[v * K + k];
+                  for (int e = 0; e < c.n_in()[t2]; ++e) { int u = c.in_from()[t2 * K + e]; if (u != v) c.score[u] = -1; }
+                }
+                long long ms = 0; int mid = -1;
+                for (int i = c.index()[v] + 1; i < n; ++i) {
+                  const int x = c.order()[i];
+                  c.score[x] = -1; c.pred()[x] = -1;
+                  for (int k = 0; k < c.n_in()[x]; ++k) {
+                    const int u = c.in_from()[x * K + k]; const long long w = c.in_w()[x * K + k];
+                    if (c.score[u] == -1) continue;
+                    if (c.score[x] < w || (c.score[x] == w && c.score[c.pred()[x]] <= c.score[u])) { c.score[x] = w; c.pred()[x] = u; }
+                  }
+                  if (c.pred()[x] != -1) c.score[x] += c.score[c.pred()[x]];
+                  if (ms < c.score[x]) { ms = c.score[x]; mid = x; }
+                }
+                if (mid < 0) break;
+                max_id = mid;
+              }
+              c.anchor()[0] = max_id;
+            }
+            WSYNC();
+            max_id = c.anchor()[0];
+            for (int v = lane; v < n; v += 64) s_pred[v] = c.pred()[v] < 0 ? 0xffff : (unsigned short)c.pred()[v];
+            WSYNC();
+          }
+          // consensus path (LDS pointer chase), coverage trim, emit
           int nc = 0;
-          for (int v = max_id; v != -1; v = c.pred[v]) c.opn[nc++] = v;
+          for (int v = max_id; v != 0xffff; v = s_pred[v]) { if (lane == 0) c.opn()[nc] = v; ++nc; }
+          WSYNC();
           int b = 0, e = nc - 1;      // positions in forward order: forward[i] = opn[nc-1-i]
           if (rec.tgs) {
             const int avg = nl / 2;
-            for (; b < nc; ++b) if (c.ncov[c.opn[nc - 1 - b]] >= avg) break;
-            for (; e >= 0; --e) if (c.ncov[c.opn[nc - 1 - e]] >= avg) break;
+            for (; b < nc; ++b) if (c.ncov()[c.opn()[nc - 1 - b]] >= avg) break;
+            for (; e >= 0; --e) if (c.ncov()[c.opn()[nc - 1 - e]] >= avg) break;
             if (b >= e) { b = 0; e = nc - 1; }
           }
-          int o = 0;
-          if (e - b + 1 > a.wout_cap) o = -1;
-          else for (int i = b; i <= e; ++i) out[o++] = c.base[c.opn[nc - 1 - i]];
-          c.pred[0] = o;
+          if (e - b + 1 > a.wout_cap) olen = -1;
+          else { for (int i = b + lane; i <= e; i += 64) out[i - b] = c.base()[c.opn()[nc - 1 - i]]; olen = e - b + 1; }
         }
-        WSYNC();
-        olen = c.pred[0];
-        WSYNC();
         PH_MARK(8)
         if (olen < 0) { fail = 1; olen = 0; } else polished = 1;
       }
@@ -679,5 +805,8 @@ __global__ __launch_bounds__(64) void k_stitch(StitchArgs a) {
 }
 
 extern "C" void c3k_launch_prep(const PrepArgs* a, int slots, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(slots), dim3(64), 0, s, *a); }
-extern "C" void c3k_launch_window(const WinArgs* a, int slots, hipStream_t s) { hipLaunchKernelGGL(k_window, dim3(slots), dim3(64), 0, s, *a); }
+extern "C" void c3k_launch_window(const WinArgs* a, int slots, hipStream_t s) {
+  const size_t lds = (size_t)a->Ncap * 6 + 16;
+  hipLaunchKernelGGL(k_window, dim3(slots), dim3(64), lds, s, *a);
+}
 extern "C" void c3k_launch_stitch(const StitchArgs* a, int grid, hipStream_t s) { hipLaunchKernelGGL(k_stitch, dim3(grid), dim3(64), 0, s, *a); }
