@@ -23,7 +23,7 @@ struct Ctx {
   uint8_t* base; int *n_in, *n_out, *in_from, *out_to, *out_w, *grp, *order, *order2, *index;
   int *gfirst, *glast, *rem, *mpl, *mpr, *rbeg, *rend, *roff, *opn, *opq, *anchor, *path, *col, *col2t, *nxt;
   long long* score;
-  int32_t *H, *E1, *E2; uint32_t* D; uint8_t* rows2;
+  int32_t *H, *E1, *E2; uint32_t* D; uint8_t* rows2; uint4 *descA, *descB;
   int K, n, Ncap, cells_cap;
   const uint32_t* pk;        // packed read
 };
@@ -68,8 +68,6 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
   return (j < pb || j > pe) ? C3_NEG : a[po + (j - pb)];
 }
 
-// banded global alignment of subread [qb, qb+Q) against the graph; ops are written BACKWARDS
-// into opn/opq, returns their count (or <0 on failure)
 #ifdef C3_PHASE_PROF
 #define PHA , unsigned long long& ph_t0_, unsigned long long (&ph_acc_)[12]
 #define PHP , ph_t0_, ph_acc_
@@ -77,120 +75,193 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 #define PHA
 #define PHP
 #endif
-__device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, long long* cells PHA) {
+// ---- DP of one alignment --------------------------------------------------------------------------
+// LDS ring of the last PR rows (cells and band metadata): reading a predecessor row costs LDS
+// latency only, and -- since gfx9 counts loads and stores in ONE in-order vmcnt -- the row loop
+// carries no vector loads on its common path (descriptors arrive 64 rows at a time and are broadcast
+// with v_readlane).  Rows with a successor more than PR-1 rows ahead, or wider than a ring slot,
+// also go to the global arena; the direction words always do (4 B per cell).
+#define PW 96       // ring slot width (cells)
+#define PR 8        // ring rows
+struct PoaLds { int H[PR][PW], E1[PR][PW], E2[PR][PW]; int beg[PR], end[PR], rl[PR], rr[PR], inl[PR]; };
+
+// scores are carried as score*512 (+ a 9-bit tag while candidates compete): one v_max per candidate
+// implements "highest score, first candidate in order".  Unreachable cells use -(2^20) score units.
+#define S9(x) ((x) * 512)
+#define NEGS (-(1 << 29))
+#define NEG2S (-(1 << 30))
+
+// direction word (device-internal): mp[0..7] | e1code[8..16] | e2code[17..25] | hts[26..27] | hs[28..29]
+// | f1x[30] | f2x[31];  e?code = 2*pred + ext;  hts: 0 M, 1 E1, 2 E2;  hs: 0 Ht, 1 F1, 2 F2
+
+__device__ void poa_build_desc(Ctx& c, int lane) {
   const int K = c.K, n = c.n;
-  const int mt = P.poa_match, mm = -P.poa_mismatch;
-  const int e1 = P.e1, e2 = P.e2, oe1 = P.o1 + P.e1, oe2 = P.o2 + P.e2;
+  for (int idx = lane; idx < n; idx += 64) {
+    const int v = c.order[idx];
+    const int nin = c.n_in[v];
+    unsigned p[4] = {0, 0, 0, 0};
+    for (int k = 0; k < nin && k < 4; ++k) p[k] = (unsigned)c.index[c.in_from[v * K + k]];
+    unsigned far = 0;
+    for (int k = 0; k < c.n_out[v]; ++k) { const int t = c.out_to[v * K + k]; if (t == SNK || c.index[t] - idx > PR - 1) far = 1; }
+    uint4 A; A.x = (unsigned)v; A.y = (unsigned)c.rem[v]; A.z = (unsigned)c.base[v] | ((unsigned)min(nin, 255) << 8) | (far << 16) | ((unsigned)(nin > 4) << 17); A.w = 0;
+    uint4 B; B.x = p[0]; B.y = p[1]; B.z = p[2]; B.w = p[3];
+    c.descA[idx] = A; c.descB[idx] = B;
+  }
+  WSYNC();
+}
+
+// banded global alignment of subread [qb, qb+Q) against the graph; ops are written BACKWARDS
+// into opn/opq, returns their count (or <0 on failure)
+__device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, long long* cells, PoaLds& L PHA) {
+  const int K = c.K, n = c.n;
+  const int mt9 = S9(P.poa_match), mm9 = S9(-P.poa_mismatch);
+  const int e1_9 = S9(P.e1), e2_9 = S9(P.e2), o1_9 = S9(P.o1), o2_9 = S9(P.o2), oe1_9 = S9(P.o1 + P.e1), oe2_9 = S9(P.o2 + P.e2);
   const int w = P.band_b + (int)(P.band_f * (double)Q);
-  // remaining length along the heaviest out-edge (reverse sweep; lane 0)
-  if (lane == 0) {
-    for (int i = n - 1; i >= 0; --i) {
-      int v = c.order[i];
-      if (v == SNK) { c.rem[v] = -1; continue; }
+  // remaining length along the heaviest out-edge (first maximum in out-list order): list ranking by
+  // pointer jumping, log2(n) parallel rounds instead of a serial reverse sweep
+  {
+    int *dA = c.rem, *nA = c.nxt, *dB = c.col, *nB = c.col2t;
+    for (int v = lane; v < n; v += 64) {
       int bw = INT32_MIN, bt = SNK;
       for (int k = 0; k < c.n_out[v]; ++k) { int ww = c.out_w[v * K + k]; if (ww > bw) { bw = ww; bt = c.out_to[v * K + k]; } }
-      c.rem[v] = c.rem[bt] + 1;
+      if (v == SNK) bt = SNK;
+      nA[v] = bt; dA[v] = (v == SNK) ? 0 : 1;
     }
+    WSYNC();
+    for (int span = 1; span < n; span <<= 1) {
+      int pending = 0;
+      for (int v = lane; v < n; v += 64) {
+        const int nx = nA[v];
+        dB[v] = dA[v] + dA[nx]; nB[v] = nA[nx];
+        pending |= nA[nx] != SNK;
+      }
+      WSYNC();
+      int* t = dA; dA = dB; dB = t; t = nA; nA = nB; nB = t;
+      if (!__ballot(pending)) break;
+    }
+    for (int v = lane; v < n; v += 64) dB[v] = dA[v] - 1;
+    WSYNC();
+    if (dB != c.rem) { for (int v = lane; v < n; v += 64) c.rem[v] = dB[v]; WSYNC(); }
   }
-  for (int v = lane; v < n; v += 64) { c.mpl[v] = INT32_MAX / 2; c.mpr[v] = 0; }
-  WSYNC();
+  poa_build_desc(c, lane);
   PH_MARK(0)
   int ncell = 0;
-  for (int idx = 0; idx < n; ++idx) {
-    const int v = c.order[idx];
-    if (v == SNK) { if (lane == 0) { c.rbeg[idx] = 0; c.rend[idx] = -1; c.roff[idx] = ncell; } continue; }
+  for (int ib = 0; ib < n; ib += 64) {
+  uint4 dA = c.descA[min(ib + lane, n - 1)], dB = c.descB[min(ib + lane, n - 1)];
+  asm volatile("" : "+v"(dA.x), "+v"(dA.y), "+v"(dA.z), "+v"(dB.x), "+v"(dB.y), "+v"(dB.z), "+v"(dB.w));   // wait here, not in the row loop
+  const int cnt = min(64, n - ib);
+  for (int li = 0; li < cnt; ++li) {
+    const int idx = ib + li;
+    const int v = __builtin_amdgcn_readlane(dA.x, li);
+    if (v == SNK) continue;
+    const int remv = __builtin_amdgcn_readlane(dA.y, li);
+    const int fl = __builtin_amdgcn_readlane(dA.z, li);
+    const int vb = fl & 0xff, nin = (fl >> 8) & 0xff;
+    const bool far = (fl >> 16) & 1, ovf = (fl >> 17) & 1;
+    int pidx[4];
+    pidx[0] = __builtin_amdgcn_readlane(dB.x, li); pidx[1] = __builtin_amdgcn_readlane(dB.y, li);
+    pidx[2] = __builtin_amdgcn_readlane(dB.z, li); pidx[3] = __builtin_amdgcn_readlane(dB.w, li);
+    // ---- adaptive band: gather the hints of the predecessors (abPOA scatters them to the successors)
     int beg, end;
-    const int qr = Q - c.rem[v];
-    const int nin = c.n_in[v];
+    const int qr = Q - remv;
     if (v == SRC) { beg = 0; end = min(Q, max(qr, 0) + w); }
     else {
-      beg = max(0, min(c.mpl[v], qr) - w);
-      end = min(Q, max(c.mpr[v], qr) + w);
-      int minb = INT32_MAX, maxe = INT32_MIN;
+      int mplv = INT32_MAX / 2, mprv = 0, minb = INT32_MAX, maxe = INT32_MIN;
       for (int k = 0; k < nin; ++k) {
-        int pi = c.index[c.in_from[v * K + k]];
-        minb = min(minb, c.rbeg[pi]); maxe = max(maxe, c.rend[pi] + 1);
+        const int pi = (!ovf || k < 4) ? pidx[k < 4 ? k : 0] : c.index[c.in_from[v * K + k]];
+        int b, e, l, r;
+        if (idx - pi < PR) { const int sl = pi & (PR - 1); b = L.beg[sl]; e = L.end[sl]; l = L.rl[sl]; r = L.rr[sl]; }
+        else { b = c.rbeg[pi]; e = c.rend[pi]; l = c.mpl[pi]; r = c.mpr[pi]; }
+        minb = min(minb, b); maxe = max(maxe, e + 1);
+        if (e >= b) { mplv = min(mplv, l + 1); mprv = max(mprv, r + 1); }
       }
+      beg = max(0, min(mplv, qr) - w);
+      end = min(Q, max(mprv, qr) + w);
       beg = max(beg, minb); end = min(end, maxe);
     }
     if (end < beg) end = beg - 1;
     const int wd = end - beg + 1;
     if (ncell + wd > c.cells_cap) return -4;
-    if (lane == 0) { c.rbeg[idx] = beg; c.rend[idx] = end; c.roff[idx] = ncell; }
+    const int slot = idx & (PR - 1);
+    const bool inl = wd <= PW, toglobal = far || !inl;
     const int ro = ncell;
     ncell += wd;
-    const int vb = c.base[v];
-    int best = INT32_MIN, bl = 0, br = 0;      // per-lane running row maximum
-    int carry1 = C3_NEG2, carry2 = C3_NEG2;     // scan carries: max of ht[k] + e*k over previous chunks
-    int prev_ht = C3_NEG;                        // ht of the column left of the chunk
+    int best = INT32_MIN, bl = 0, br = 0;        // per-lane running row maximum
+    int carry1 = NEG2S, carry2 = NEG2S;          // scan carries over previous chunks
+    int prev_ht = NEGS;
     for (int c0 = 0; c0 < wd; c0 += 64) {
       const int j = beg + c0 + lane;
       const bool act = j <= end;
-      int ht, E1v, E2v; uint32_t d = 0;
-      if (v == SRC) { ht = (j == 0) ? 0 : C3_NEG; E1v = E2v = C3_NEG; }
+      int ht9, E1v, E2v; unsigned d = 0;
+      if (v == SRC) { ht9 = (j == 0) ? 0 : NEGS; E1v = E2v = NEGS; }
       else {
-        int M = INT32_MIN, e1b = INT32_MIN, e2b = INT32_MIN, mp = 0, e1p = 0, e2p = 0, e1x = 0, e2x = 0;
+        int kM = INT32_MIN, kE1 = INT32_MIN, kE2 = INT32_MIN;
         for (int k = 0; k < nin; ++k) {
-          const int pi = c.index[c.in_from[v * K + k]];
-          const int pb = c.rbeg[pi], pe = c.rend[pi], po = c.roff[pi];
-          int hd = (j > 0) ? rdcell(c, c.H, pb, pe, po, j - 1) : C3_NEG;
-          if (hd > M) { M = hd; mp = k; }
-          int hp = rdcell(c, c.H, pb, pe, po, j);
-          int a = hp - oe1, bb = rdcell(c, c.E1, pb, pe, po, j) - e1;
-          int cnd = a >= bb ? a : bb, x = bb > a;
-          if (cnd > e1b) { e1b = cnd; e1p = k; e1x = x; }
-          a = hp - oe2; bb = rdcell(c, c.E2, pb, pe, po, j) - e2;
-          cnd = a >= bb ? a : bb; x = bb > a;
-          if (cnd > e2b) { e2b = cnd; e2p = k; e2x = x; }
+          const int pi = (!ovf || k < 4) ? pidx[k < 4 ? k : 0] : c.index[c.in_from[v * K + k]];
+          int hd = NEGS, hp = NEGS, e1p = NEGS, e2p = NEGS;
+          const int sl = pi & (PR - 1);
+          if (idx - pi < PR && L.inl[sl]) {
+            const int b = L.beg[sl], e = L.end[sl];
+            if (j > 0 && j - 1 >= b && j - 1 <= e) hd = L.H[sl][j - 1 - b];
+            if (j >= b && j <= e) { hp = L.H[sl][j - b]; e1p = L.E1[sl][j - b]; e2p = L.E2[sl][j - b]; }
+          } else {
+            int b, e;
+            if (idx - pi < PR) { b = L.beg[sl]; e = L.end[sl]; } else { b = c.rbeg[pi]; e = c.rend[pi]; }
+            const int po = c.roff[pi];
+            if (j > 0 && j - 1 >= b && j - 1 <= e) hd = c.H[po + (j - 1 - b)];
+            if (j >= b && j <= e) { hp = c.H[po + (j - b)]; e1p = c.E1[po + (j - b)]; e2p = c.E2[po + (j - b)]; }
+          }
+          kM = max(kM, hd + (511 - k));
+          kE1 = max(kE1, max(hp - oe1_9 + (511 - 2 * k), e1p - e1_9 + (510 - 2 * k)));
+          kE2 = max(kE2, max(hp - oe2_9 + (511 - 2 * k), e2p - e2_9 + (510 - 2 * k)));
         }
-        if (j > 0) { int qc = act ? c3_code_at(c.pk, qb + j - 1) : 0; M += (vb == qc) ? mt : mm; } else M = C3_NEG;
-        int hts;
-        if (M >= e1b && M >= e2b) { hts = 0; ht = M; }
-        else if (e1b >= e2b) { hts = 1; ht = e1b; }
-        else { hts = 2; ht = e2b; }
-        E1v = e1b; E2v = e2b;
-        d = (uint32_t)mp | ((uint32_t)e1p << 8) | ((uint32_t)e2p << 16) | ((uint32_t)hts << 24)
-            | ((uint32_t)e1x << 28) | ((uint32_t)e2x << 29);
+        const int qc = (act && j > 0) ? c3_code_at(c.pk, qb + j - 1) : 7;
+        const int M9 = (j > 0) ? (kM & ~511) + ((vb == qc) ? mt9 : mm9) : NEGS;
+        E1v = kE1 & ~511; E2v = kE2 & ~511;
+        const int k2 = max(max(M9 + 2, E1v + 1), E2v);
+        ht9 = k2 & ~511;
+        d = (unsigned)(511 - (kM & 511)) | ((unsigned)(511 - (kE1 & 511)) << 8) | ((unsigned)(511 - (kE2 & 511)) << 17)
+            | ((unsigned)(2 - (k2 & 3)) << 26);
       }
       // horizontal states: F[j] = max_{beg<=k<j} ht[k] - o - e*(j-k)
-      const int htm = act ? ht : C3_NEG2;                    // inactive lanes must not win the scans
-      const int x1 = htm + e1 * j, x2 = htm + e2 * j;
-      const int s1 = wave_scan_max(x1), s2 = wave_scan_max(x2);
-      const int px1 = max(wave_shr1(s1, C3_NEG2), carry1);   // exclusive prefix incl. carry
-      const int px2 = max(wave_shr1(s2, C3_NEG2), carry2);
-      const int htl = wave_shr1(htm, prev_ht);                 // ht[j-1]
-      int f1, f2, f1x = 0, f2x = 0;
-      if (j == beg) { f1 = f2 = C3_NEG2; }
+      const int htm = act ? ht9 : NEG2S;
+      const int s1 = wave_scan_max(htm + e1_9 * j), s2 = wave_scan_max(htm + e2_9 * j);
+      const int px1 = max(wave_shr1(s1, NEG2S), carry1), px2 = max(wave_shr1(s2, NEG2S), carry2);
+      const int htl = wave_shr1(htm, prev_ht);
+      int f1, f2; unsigned f1x = 0, f2x = 0;
+      if (j == beg) { f1 = f2 = NEG2S; }
       else {
-        f1 = px1 - P.o1 - e1 * j; f2 = px2 - P.o2 - e2 * j;
-        f1x = f1 != htl - oe1; f2x = f2 != htl - oe2;
+        f1 = px1 - o1_9 - e1_9 * j; f2 = px2 - o2_9 - e2_9 * j;
+        f1x = f1 != htl - oe1_9; f2x = f2 != htl - oe2_9;
       }
       carry1 = max(carry1, wave_bcast(s1, 63)); carry2 = max(carry2, wave_bcast(s2, 63));
       prev_ht = wave_bcast(htm, 63);
-      int hs, hh;
-      if (ht >= f1 && ht >= f2) { hs = 0; hh = ht; }
-      else if (f1 >= f2) { hs = 1; hh = f1; }
-      else { hs = 2; hh = f2; }
-      d |= ((uint32_t)hs << 26) | ((uint32_t)f1x << 30) | ((uint32_t)f2x << 31);
+      const int k3 = max(max(ht9 + 2, f1 + 1), f2);
+      const int h9 = k3 & ~511;
+      d |= ((unsigned)(2 - (k3 & 3)) << 28) | (f1x << 30) | (f2x << 31);
       if (act) {
-        const int ci = ro + c0 + lane;
-        c.H[ci] = hh; c.E1[ci] = E1v; c.E2[ci] = E2v; c.D[ci] = d;
-        if (hh > best) { best = hh; bl = br = j; } else if (hh == best) br = j;
+        const int ci = c0 + lane;
+        c.D[ro + ci] = d;
+        if (inl) { L.H[slot][ci] = h9; L.E1[slot][ci] = E1v; L.E2[slot][ci] = E2v; }
+        if (toglobal) { c.H[ro + ci] = h9; c.E1[ro + ci] = E1v; c.E2[ro + ci] = E2v; }
+        if (h9 > best) { best = h9; bl = br = j; } else if (h9 == best) br = j;
       }
     }
-    // row maximum: leftmost / rightmost argmax -> adaptive band hints of the successors
-    const int rb = wave_max(best);
-    const int left = wave_min(best == rb ? bl : INT32_MAX / 2);
-    const int right = wave_max(best == rb ? br : -1);
-    if (wd > 0 && lane == 0) {
-      for (int k = 0; k < c.n_out[v]; ++k) {
-        int t = c.out_to[v * K + k];
-        if (right + 1 > c.mpr[t]) c.mpr[t] = right + 1;
-        if (left + 1 < c.mpl[t]) c.mpl[t] = left + 1;
-      }
+    // row maximum: leftmost / rightmost argmax -> band hints read by the successors
+    int left = 0, right = 0;
+    if (wd > 0) {
+      const int rb = wave_max(best);
+      left = wave_min(best == rb ? bl : INT32_MAX / 2);
+      right = wave_max(best == rb ? br : -1);
     }
-    WSYNC();
+    if (lane == 0) {
+      L.beg[slot] = beg; L.end[slot] = end; L.rl[slot] = left; L.rr[slot] = right; L.inl[slot] = inl;
+      c.rbeg[idx] = beg; c.rend[idx] = end; c.roff[idx] = ro;
+      if (far) { c.mpl[idx] = left; c.mpr[idx] = right; }
+    }
   }
+  }
+  WSYNC();
   *cells += ncell;
   PH_MARK(1)
   // end cell + traceback (lane 0), ops stored backwards
@@ -199,24 +270,24 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     int bi = -1, bs = INT32_MIN;
     for (int k = 0; k < c.n_in[SNK]; ++k) {
       int pi = c.index[c.in_from[SNK * K + k]];
-      int hh = rdcell(c, c.H, c.rbeg[pi], c.rend[pi], c.roff[pi], Q);
+      int hh = (Q < c.rbeg[pi] || Q > c.rend[pi]) ? NEGS : c.H[c.roff[pi] + (Q - c.rbeg[pi])];
       if (hh > bs) { bs = hh; bi = pi; }
     }
-    if (bi < 0 || bs <= C3_NEG / 2) nops = -1;
+    if (bi < 0 || bs <= NEGS / 2) nops = -1;
     else {
       int i = bi, j = Q, st = 0;
       while (!(i == 0 && j == 0)) {
         if (j < c.rbeg[i] || j > c.rend[i]) { nops = -2; break; }
         const uint32_t d = c.D[c.roff[i] + (j - c.rbeg[i])];
         const int v = c.order[i];
-        if (st == 0) { int hs = (d >> 26) & 3; st = hs == 0 ? 1 : (hs == 1 ? 4 : 5); }
+        if (st == 0) { int hs = (d >> 28) & 3; st = hs == 0 ? 1 : (hs == 1 ? 4 : 5); }
         else if (st == 1) {
-          int hts = (d >> 24) & 3;
+          int hts = (d >> 26) & 3;
           if (hts == 0) { c.opn[nops] = v; c.opq[nops] = j - 1; ++nops; i = c.index[c.in_from[v * K + (d & 0xff)]]; --j; st = 0; }
           else st = hts == 1 ? 2 : 3;
         }
-        else if (st == 2) { c.opn[nops] = v; c.opq[nops] = -1; ++nops; i = c.index[c.in_from[v * K + ((d >> 8) & 0xff)]]; st = ((d >> 28) & 1) ? 2 : 0; }
-        else if (st == 3) { c.opn[nops] = v; c.opq[nops] = -1; ++nops; i = c.index[c.in_from[v * K + ((d >> 16) & 0xff)]]; st = ((d >> 29) & 1) ? 3 : 0; }
+        else if (st == 2) { const int ec = (d >> 8) & 0x1ff; c.opn[nops] = v; c.opq[nops] = -1; ++nops; i = c.index[c.in_from[v * K + (ec >> 1)]]; st = (ec & 1) ? 2 : 0; }
+        else if (st == 3) { const int ec = (d >> 17) & 0x1ff; c.opn[nops] = v; c.opq[nops] = -1; ++nops; i = c.index[c.in_from[v * K + (ec >> 1)]]; st = (ec & 1) ? 3 : 0; }
         else if (st == 4) { c.opn[nops] = -1; c.opq[nops] = j - 1; ++nops; st = ((d >> 30) & 1) ? 4 : 1; --j; }
         else { c.opn[nops] = -1; c.opq[nops] = j - 1; ++nops; st = ((d >> 31) & 1) ? 5 : 1; --j; }
       }
@@ -228,42 +299,66 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   return nops;
 }
 
-// fuse the aligned subread (ops backwards in opn/opq; nops<0 means "first sequence": all inserts)
-__device__ void poa_fuse(Ctx& c, int nops, int qb, int Q, int* path, int lane PHA) {
-  const int n_old = c.n;
-  if (lane == 0) {
-    int n_new = 0, prev = SRC, cur_anchor = 0, nn = c.n;
-    const int total = nops < 0 ? Q : nops;
-    for (int t = 0; t < total; ++t) {
-      int v, qp;
-      if (nops < 0) { v = -1; qp = t; } else { v = c.opn[nops - 1 - t]; qp = c.opq[nops - 1 - t]; }
-      if (qp < 0) continue;
-      const int cb = c3_code_at(c.pk, qb + qp);
-      int tnode;
-      if (v >= 0) {
-        const int r = c.grp[v];
-        cur_anchor = c.glast[r];
-        tnode = -1;
-        if (c.base[v] == cb) tnode = v;
-        else
-          for (int i = c.gfirst[r]; i <= c.glast[r]; ++i) { int x = c.order[i]; if (c.base[x] == cb) { tnode = x; break; } }
-        if (tnode < 0) { tnode = nn++; c.base[tnode] = (uint8_t)cb; c.n_in[tnode] = 0; c.n_out[tnode] = 0; c.grp[tnode] = r; c.anchor[n_new++] = cur_anchor; }
-      } else {
-        tnode = nn++; c.base[tnode] = (uint8_t)cb; c.n_in[tnode] = 0; c.n_out[tnode] = 0; c.grp[tnode] = tnode; c.anchor[n_new++] = cur_anchor;
-      }
-      g_add_edge(c, prev, tnode, 1);
-      path[qp] = tnode;
-      prev = tnode;
+// fuse the aligned subread into the graph, parallel over its bases: vq[q] = graph row node aligned to
+// base q (-1 = insertion).  Every graph node is touched by at most one base, so targets, new-node
+// ids (prefix sum), anchors (prefix max) and the Q+1 edges are all independent.
+__device__ int poa_fuse(Ctx& c, int nops, int qb, int Q, int* path, int lane PHA) {
+  const int n_old = c.n, K = c.K;
+  int* vq = c.mpl;                                  // scratch (mpl/mpr are re-initialised per alignment)
+  for (int q = lane; q < Q; q += 64) vq[q] = -1;
+  WSYNC();
+  if (nops > 0) {
+    for (int t = lane; t < nops; t += 64) { const int qp = c.opq[t]; if (qp >= 0) vq[qp] = c.opn[t]; }
+    WSYNC();
+  }
+  int carry_anchor = 0 /* order index of SRC */, carry_new = 0;
+  for (int q0 = 0; q0 < Q; q0 += 64) {
+    const int q = q0 + lane;
+    const bool act = q < Q;
+    const int v = act ? vq[q] : -1;
+    const int cb = act ? c3_code_at(c.pk, qb + q) : 0;
+    int tgt = -1, gnew = -1, anc = -1;
+    if (v >= 0) {
+      const int rr = c.grp[v];
+      anc = c.glast[rr];
+      if (c.base[v] == cb) tgt = v;
+      else for (int i = c.gfirst[rr]; i <= anc; ++i) { int x = c.order[i]; if (c.base[x] == cb) { tgt = x; break; } }
+      if (tgt < 0) gnew = rr;
     }
-    g_add_edge(c, prev, SNK, 1);
-    c.rem[0] = nn;    // hand the new node count to the other lanes through scratch
+    const int isnew = act && tgt < 0;
+    const int as = max(wave_scan_max(anc), carry_anchor);
+    carry_anchor = wave_bcast(as, 63);
+    const int ps = wave_scan_add(isnew);
+    const int k = carry_new + ps - isnew;
+    carry_new += wave_bcast(ps, 63);
+    if (isnew) {
+      const int id = n_old + k;
+      if (id < c.Ncap) { c.base[id] = (uint8_t)cb; c.n_in[id] = 0; c.n_out[id] = 0; c.grp[id] = gnew >= 0 ? gnew : id; c.anchor[k] = as; }
+      tgt = id;
+    }
+    if (act) path[q] = tgt;
+  }
+  const int nn = n_old + carry_new;
+  if (nn > c.Ncap) return -1;
+  WSYNC();
+  for (int q = lane; q <= Q; q += 64) {
+    const int u = q == 0 ? SRC : path[q - 1], v = q == Q ? SNK : path[q];
+    const int no = c.n_out[u];
+    int hit = -1;
+    for (int k = 0; k < no; ++k) if (c.out_to[u * K + k] == v) { hit = k; break; }
+    if (hit >= 0) c.out_w[u * K + hit] += 1;
+    else {
+      const int ni = c.n_in[v];
+      c.out_to[u * K + no] = v; c.out_w[u * K + no] = 1; c.n_out[u] = no + 1;
+      c.in_from[v * K + ni] = u; c.n_in[v] = ni + 1;
+    }
   }
   WSYNC();
-  c.n = c.rem[0];
-  WSYNC();
+  c.n = nn;
   PH_MARK(3)
   g_reorder(c, n_old, lane);
   PH_MARK(4)
+  return 0;
 }
 
 // bin/consensus.py:50-74 on code rows (4 = gap); out has msa_len bytes
@@ -292,6 +387,8 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
   c.score = a.score + slot * N;
   c.H = a.H + (size_t)slot * a.cells_cap; c.E1 = a.E1 + (size_t)slot * a.cells_cap; c.E2 = a.E2 + (size_t)slot * a.cells_cap;
   c.D = a.D + (size_t)slot * a.cells_cap; c.rows2 = a.rows2 + slot * 4 * N;
+  c.descA = a.desc + (size_t)slot * 2 * N; c.descB = c.descA + N;
+  __shared__ PoaLds L;
   c.K = a.K; c.Ncap = a.Ncap; c.cells_cap = a.cells_cap;
   PH_DECL
 
@@ -326,8 +423,8 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
       for (int s = 0; s < ns && !fail; ++s) {
         const int qb = info->sub_beg[s], Q = info->sub_end[s] - qb;
         int nops = -1;
-        if (s > 0) { nops = poa_align(c, a.p, qb, Q, lane, &cells PHP); if (nops < 0) { fail = 1; break; } }
-        poa_fuse(c, nops, qb, Q, c.path + poff, lane PHP);
+        if (s > 0) { nops = poa_align(c, a.p, qb, Q, lane, &cells, L PHP); if (nops < 0) { fail = 1; break; } }
+        if (poa_fuse(c, nops, qb, Q, c.path + poff, lane PHP) < 0) { fail = 1; break; }
         poff += Q;
       }
       PH_MARK(9)
