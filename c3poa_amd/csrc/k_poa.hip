@@ -264,53 +264,73 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   WSYNC();
   *cells += ncell;
   PH_MARK(1)
-  // end cell + traceback (lane 0), ops stored backwards
-  int nops = 0;
-  if (lane == 0) {
-    int bi = -1, bs = INT32_MIN;
-    for (int k = 0; k < c.n_in[SNK]; ++k) {
-      int pi = c.index[c.in_from[SNK * K + k]];
-      int hh = (Q < c.rbeg[pi] || Q > c.rend[pi]) ? NEGS : c.H[c.roff[pi] + (Q - c.rbeg[pi])];
-      if (hh > bs) { bs = hh; bi = pi; }
-    }
-    if (bi < 0 || bs <= NEGS / 2) nops = -1;
-    else {
-      int i = bi, j = Q, st = 0;
-      while (!(i == 0 && j == 0)) {
-        if (j < c.rbeg[i] || j > c.rend[i]) { nops = -2; break; }
-        const uint32_t d = c.D[c.roff[i] + (j - c.rbeg[i])];
-        const int v = c.order[i];
-        if (st == 0) { int hs = (d >> 28) & 3; st = hs == 0 ? 1 : (hs == 1 ? 4 : 5); }
-        else if (st == 1) {
-          int hts = (d >> 26) & 3;
-          if (hts == 0) { c.opn[nops] = v; c.opq[nops] = j - 1; ++nops; i = c.index[c.in_from[v * K + (d & 0xff)]]; --j; st = 0; }
-          else st = hts == 1 ? 2 : 3;
+  // ---- end cell: best predecessor of the sink at column Q (first maximum in in-edge order)
+  int bi = -1, bs = INT32_MIN;
+  for (int k = 0; k < c.n_in[SNK]; ++k) {
+    const int pi = c.index[c.in_from[SNK * K + k]];
+    const int hh = (Q < c.rbeg[pi] || Q > c.rend[pi]) ? NEGS : c.H[c.roff[pi] + (Q - c.rbeg[pi])];
+    if (hh > bs) { bs = hh; bi = pi; }
+  }
+  if (bi < 0 || bs <= NEGS / 2) return -1;
+  // ---- traceback.  vq[q] = graph node aligned to base q (-1 = insertion); deletions leave no trace.
+  // In state H the wave speculates 64 steps down the diagonal at once (lane k fetches the cell k steps
+  // back and checks "match move from the previous row"); the cell that breaks the run is resolved by
+  // the scalar state machine below.
+  int* vq = c.mpl;
+  int rc = 0;
+  {
+    int i = bi, j = Q, st = 0;   // st: 0 H, 1 Ht, 2 E1, 3 E2, 4 F1, 5 F2
+    while (!(i == 0 && j == 0)) {
+      if (st == 0 && i > 0 && j > 0) {
+        const int ik = i - lane, jk = j - lane;
+        bool ok = ik >= 1 && jk >= 1;
+        int node = 0;
+        if (ok) {
+          const int b = c.rbeg[ik], e = c.rend[ik];
+          const uint4 A = c.descA[ik];
+          node = (int)A.x;
+          ok = jk >= b && jk <= e;
+          if (ok) {
+            const unsigned d = c.D[c.roff[ik] + (jk - b)];
+            const int mp = d & 0xff;
+            ok = ((d >> 26) & 15) == 0 && mp < 4 && !((A.z >> 17) & 1);
+            if (ok) { const uint4 B = c.descB[ik]; const int pi = mp == 0 ? B.x : mp == 1 ? B.y : mp == 2 ? B.z : B.w; ok = pi == ik - 1; }
+          }
         }
-        else if (st == 2) { const int ec = (d >> 8) & 0x1ff; c.opn[nops] = v; c.opq[nops] = -1; ++nops; i = c.index[c.in_from[v * K + (ec >> 1)]]; st = (ec & 1) ? 2 : 0; }
-        else if (st == 3) { const int ec = (d >> 17) & 0x1ff; c.opn[nops] = v; c.opq[nops] = -1; ++nops; i = c.index[c.in_from[v * K + (ec >> 1)]]; st = (ec & 1) ? 3 : 0; }
-        else if (st == 4) { c.opn[nops] = -1; c.opq[nops] = j - 1; ++nops; st = ((d >> 30) & 1) ? 4 : 1; --j; }
-        else { c.opn[nops] = -1; c.opq[nops] = j - 1; ++nops; st = ((d >> 31) & 1) ? 5 : 1; --j; }
+        const unsigned long long bal = __ballot(ok);
+        const int m = (~bal) ? __builtin_ctzll(~bal) : 64;
+        if (lane < m) vq[jk - 1] = node;
+        i -= m; j -= m;
+        if (m == 64 || (i == 0 && j == 0)) continue;
       }
+      // scalar step at (i, j)
+      if (j < c.rbeg[i] || j > c.rend[i]) { rc = -2; break; }
+      const uint32_t d = c.D[c.roff[i] + (j - c.rbeg[i])];
+      const int v = c.order[i];
+      if (st == 0) { const int hs = (d >> 28) & 3; st = hs == 0 ? 1 : (hs == 1 ? 4 : 5); }
+      else if (st == 1) {
+        const int hts = (d >> 26) & 3;
+        if (hts == 0) { if (lane == 0) vq[j - 1] = v; i = c.index[c.in_from[v * K + (d & 0xff)]]; --j; st = 0; }
+        else st = hts == 1 ? 2 : 3;
+      }
+      else if (st == 2) { const int ec = (d >> 8) & 0x1ff; i = c.index[c.in_from[v * K + (ec >> 1)]]; st = (ec & 1) ? 2 : 0; }
+      else if (st == 3) { const int ec = (d >> 17) & 0x1ff; i = c.index[c.in_from[v * K + (ec >> 1)]]; st = (ec & 1) ? 3 : 0; }
+      else if (st == 4) { if (lane == 0) vq[j - 1] = -1; st = ((d >> 30) & 1) ? 4 : 1; --j; }
+      else { if (lane == 0) vq[j - 1] = -1; st = ((d >> 31) & 1) ? 5 : 1; --j; }
     }
   }
-  nops = wave_first(nops);
   WSYNC();
   PH_MARK(2)
-  return nops;
+  return rc;
 }
 
 // fuse the aligned subread into the graph, parallel over its bases: vq[q] = graph row node aligned to
 // base q (-1 = insertion).  Every graph node is touched by at most one base, so targets, new-node
 // ids (prefix sum), anchors (prefix max) and the Q+1 edges are all independent.
-__device__ int poa_fuse(Ctx& c, int nops, int qb, int Q, int* path, int lane PHA) {
+__device__ int poa_fuse(Ctx& c, bool first, int qb, int Q, int* path, int lane PHA) {
   const int n_old = c.n, K = c.K;
-  int* vq = c.mpl;                                  // scratch (mpl/mpr are re-initialised per alignment)
-  for (int q = lane; q < Q; q += 64) vq[q] = -1;
-  WSYNC();
-  if (nops > 0) {
-    for (int t = lane; t < nops; t += 64) { const int qp = c.opq[t]; if (qp >= 0) vq[qp] = c.opn[t]; }
-    WSYNC();
-  }
+  int* vq = c.mpl;                                  // filled by poa_align's traceback
+  if (first) { for (int q = lane; q < Q; q += 64) vq[q] = -1; WSYNC(); }
   int carry_anchor = 0 /* order index of SRC */, carry_new = 0;
   for (int q0 = 0; q0 < Q; q0 += 64) {
     const int q = q0 + lane;
@@ -422,9 +442,8 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
       int poff = 0;
       for (int s = 0; s < ns && !fail; ++s) {
         const int qb = info->sub_beg[s], Q = info->sub_end[s] - qb;
-        int nops = -1;
-        if (s > 0) { nops = poa_align(c, a.p, qb, Q, lane, &cells, L PHP); if (nops < 0) { fail = 1; break; } }
-        if (poa_fuse(c, nops, qb, Q, c.path + poff, lane PHP) < 0) { fail = 1; break; }
+        if (s > 0) { if (poa_align(c, a.p, qb, Q, lane, &cells, L PHP) < 0) { fail = 1; break; } }
+        if (poa_fuse(c, s == 0, qb, Q, c.path + poff, lane PHP) < 0) { fail = 1; break; }
         poff += Q;
       }
       PH_MARK(9)
