@@ -68,7 +68,7 @@ def main():
     n_unique = a.unique if a.unique > 0 else a.reads
     n_unique = min(n_unique, a.reads)
     t_gen = time.time()
-    recs = make_reads(a.cfg, n_unique, rank * a.reads, os.cpu_count() // max(world, 1))
+    recs = make_reads(a.cfg, n_unique, rank * a.reads, max(1, effective_cores() // max(world, 1)))
     t_gen = time.time() - t_gen
 
     import torch
@@ -157,11 +157,27 @@ def main():
         print(json.dumps(out))
 
 
+def effective_cores():
+    """usable host cores: min(cpu_count, affinity mask, cgroup CPU quota)"""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(recs, mdist, seconds):
     """the oracle (own CPU restatement) on all host cores, bounded sample of the same workload"""
     from c3poa_amd import synth
     from oracle import oracle_py as O
-    cores = os.cpu_count()
+    cores = effective_cores()
     P = O.default_params(mdistcutoff=mdist)
     probe = recs[:min(len(recs), 4 * cores)]
     t = time.perf_counter()
@@ -174,7 +190,7 @@ def cpu_baseline(recs, mdist, seconds):
     dt = time.perf_counter() - t
     return {"value": round(n / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
             "sample": "first %d reads of the same synthetic batch, oracle/libc3oracle.so (own CPU restatement, "
-                      "-O3, OpenMP %d threads), %.1f s" % (n, cores, dt)}
+                      "-O3, OpenMP %d threads = usable host cores of %d), %.1f s" % (n, cores, os.cpu_count(), dt)}
 
 
 if __name__ == "__main__":
