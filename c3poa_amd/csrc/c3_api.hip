@@ -81,7 +81,7 @@ struct c3_handle {
   int n = 0; int64_t total = 0, words = 0, maxL = 0; std::vector<int64_t> off, woff;
   DBuf d_ascii, d_pk, d_woff, d_qual, d_off, d_strand, d_sid, d_info, d_track, d_draft, d_tpos, d_cons, d_counter;
   DBuf d_raw, d_nraw, d_sum, d_work, d_bufA, d_bufB, d_cand, d_cst, d_msa, d_msa_off, d_msa_len;
-  DBuf s_poa_i, s_poa_nk, s_poa_cells, s_poa_b, s_poa_sc, s_poa_desc;      // POA scratch
+  DBuf s_poa_i, s_poa_nk, s_poa_cells, s_poa_b, s_poa_sc, s_poa_desc, s_poa_jump;      // POA scratch
   DBuf s_eH, s_eD, s_lw, d_wrec, d_wlay, d_wbase, d_wout;       // prep / windows
   DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc;  // window scratch
   std::vector<Summary> sum; std::vector<int> work;
@@ -145,7 +145,7 @@ extern "C" void c3_destroy(c3_handle* h) {
   DBuf* all[] = {&h->d_sp_codes, &h->d_sp_len, &h->d_ascii, &h->d_pk, &h->d_woff, &h->d_qual, &h->d_off, &h->d_strand, &h->d_sid,
                  &h->d_info, &h->d_track, &h->d_draft, &h->d_tpos, &h->d_cons, &h->d_counter, &h->d_raw, &h->d_nraw, &h->d_sum,
                  &h->d_work, &h->d_bufA, &h->d_bufB, &h->d_cand, &h->d_cst, &h->d_msa, &h->d_msa_off, &h->d_msa_len,
-                 &h->s_poa_i, &h->s_poa_nk, &h->s_poa_cells, &h->s_poa_b, &h->s_poa_sc, &h->s_poa_desc, &h->s_eH, &h->s_eD, &h->s_lw, &h->d_wrec,
+                 &h->s_poa_i, &h->s_poa_nk, &h->s_poa_cells, &h->s_poa_b, &h->s_poa_sc, &h->s_poa_desc, &h->s_poa_jump, &h->s_eH, &h->s_eD, &h->s_lw, &h->d_wrec,
                  &h->d_wlay, &h->d_wbase, &h->d_wout, &h->s_win_i, &h->s_win_nk, &h->s_win_h, &h->s_win_d, &h->s_win_b, &h->s_win_sc, &h->s_win_desc};
   for (DBuf* b : all) b->release();
   for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(h->ev[i]);
@@ -314,11 +314,12 @@ static int run_poa(c3_handle* h) {
   if (cells > 0x7fffff00LL) cells = 0x7fffff00LL;
   const size_t N = (size_t)Ncap;
   const int NI = 26;      // int arrays of N (opn/opq count twice)
-  size_t per_slot = N * (NI * 4 + 8 + 5 + 32) + N * K * 12 + (size_t)cells * 16;
+  size_t per_slot = N * (NI * 4 + 8 + 5 + 32 + 4 * C3_JUMP_LEVELS) + N * K * 12 + (size_t)cells * 16;
   const int slots = auto_slots(h, h->cfg.slots_poa, per_slot, nw, 16);
   HIPCHK(h->s_poa_i.ensure(sizeof(int) * N * NI * slots)); HIPCHK(h->s_poa_nk.ensure(sizeof(int) * N * K * 3 * slots));
   HIPCHK(h->s_poa_cells.ensure((size_t)cells * 16 * slots)); HIPCHK(h->s_poa_b.ensure(N * 5 * slots)); HIPCHK(h->s_poa_sc.ensure(sizeof(long long) * N * slots));
   HIPCHK(h->s_poa_desc.ensure(sizeof(uint4) * 2 * N * slots));
+  HIPCHK(h->s_poa_jump.ensure(sizeof(int) * C3_JUMP_LEVELS * N * slots));
   PoaArgs a; memset(&a, 0, sizeof(a));
   a.b = dev_batch(h); a.info = h->d_info.as<C3Info>(); a.p = dev_params(h->cfg);
   a.counter = h->d_counter.as<int>(); a.work = h->d_work.as<int>(); a.n_work = nw;
@@ -331,7 +332,7 @@ static int run_poa(c3_handle* h) {
   char* cb = h->s_poa_cells.as<char>(); const size_t CS = (size_t)cells * slots;
   a.H = (int32_t*)cb; a.E1 = (int32_t*)(cb + CS * 4); a.E2 = (int32_t*)(cb + CS * 8); a.D = (uint32_t*)(cb + CS * 12);
   a.base = h->s_poa_b.as<uint8_t>(); a.rows2 = a.base + SN; a.score = h->s_poa_sc.as<long long>();
-  a.Ncap = Ncap; a.K = K; a.Pcap = Pcap; a.cells_cap = (int)cells; a.desc = h->s_poa_desc.as<uint4>();
+  a.Ncap = Ncap; a.K = K; a.Pcap = Pcap; a.cells_cap = (int)cells; a.desc = h->s_poa_desc.as<uint4>(); a.jump = h->s_poa_jump.as<int>();
   a.draft = h->d_draft.as<uint8_t>(); a.tpos = h->d_tpos.as<int32_t>();
   a.msa_dbg = nullptr; a.msa_off = nullptr; a.msa_len = nullptr;
   if (h->debug_msa) {

@@ -16,7 +16,7 @@ struct PoaArgs {
   int *gfirst, *glast, *rem, *mpl, *mpr, *rbeg, *rend, *roff, *opn, *opq, *anchor, *path, *col, *col2t, *nxt;
   long long* score; int32_t *H, *E1, *E2; uint32_t* D; uint8_t* rows2; int Ncap, K, Pcap, cells_cap;
   uint8_t* draft; int32_t* tpos; uint8_t* msa_dbg; const int64_t* msa_off; int* msa_len;
-  unsigned long long* phases; uint4* desc;
+  unsigned long long* phases; uint4* desc; int* jump;
 };
 struct WLayer { int qbeg, len, begin, end; };
 struct WinRec { int rid, w, n_layers, blen, tgs, out_len, polished, pad_; };

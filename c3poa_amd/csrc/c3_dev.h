@@ -7,7 +7,8 @@
 #define C3_NEG (-(1 << 28))    // out-of-band / unreachable score
 #define C3_NEG2 (-(1 << 30))   // "no left neighbour" of the horizontal-gap state
 #define C3_MAX_SUB 250
-#define C3_SPLINT_MAX 512      // 64 lanes x 8 rows per lane in the conk kernel
+#define C3_SPLINT_MAX 512
+#define C3_JUMP_LEVELS 18   // binary-lifting levels of the consensus path (graphs up to 2^18 nodes)      // 64 lanes x 8 rows per lane in the conk kernel
 
 // device view of the resident batch
 struct C3Batch {

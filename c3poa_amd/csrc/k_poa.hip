@@ -23,7 +23,7 @@ struct Ctx {
   uint8_t* base; int *n_in, *n_out, *in_from, *out_to, *out_w, *grp, *order, *order2, *index;
   int *gfirst, *glast, *rem, *mpl, *mpr, *rbeg, *rend, *roff, *opn, *opq, *anchor, *path, *col, *col2t, *nxt;
   long long* score;
-  int32_t *H, *E1, *E2; uint32_t* D; uint8_t* rows2; uint4 *descA, *descB;
+  int32_t *H, *E1, *E2; uint32_t* D; uint8_t* rows2; uint4 *descA, *descB; int* jump;
   int K, n, Ncap, cells_cap;
   const uint32_t* pk;        // packed read
 };
@@ -83,7 +83,8 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 // also go to the global arena; the direction words always do (4 B per cell).
 #define PW 96       // ring slot width (cells)
 #define PR 8        // ring rows
-struct PoaLds { int H[PR][PW], E1[PR][PW], E2[PR][PW]; int beg[PR], end[PR], rl[PR], rr[PR], inl[PR]; };
+#define PQW 112     // packed query words kept in LDS (1792 bases); longer subreads read the packed read
+struct PoaLds { int H[PR][PW], E1[PR][PW], E2[PR][PW]; int beg[PR], end[PR], rl[PR], rr[PR], inl[PR]; unsigned qpk[PQW]; };
 
 // scores are carried as score*512 (+ a 9-bit tag while candidates compete): one v_max per candidate
 // implements "highest score, first candidate in order".  Unreachable cells use -(2^20) score units.
@@ -144,6 +145,17 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     if (dB != c.rem) { for (int v = lane; v < n; v += 64) c.rem[v] = dB[v]; WSYNC(); }
   }
   poa_build_desc(c, lane);
+  // the subread, 2-bit packed and re-aligned to its first base, goes to LDS: the row loop must not
+  // touch global memory for it (a vector load would wait for every older row store)
+  const bool qlds = Q <= PQW * 16;
+  if (qlds) {
+    for (int i = lane; i * 16 < Q; i += 64) {
+      const long long b0 = (long long)qb + 16 * i;
+      const unsigned w0 = c.pk[b0 >> 4], w1 = c.pk[(b0 >> 4) + 1];
+      L.qpk[i] = __builtin_amdgcn_alignbit(w1, w0, (unsigned)(b0 & 15) * 2);
+    }
+  }
+  WSYNC();
   PH_MARK(0)
   int ncell = 0;
   for (int ib = 0; ib < n; ib += 64) {
@@ -215,7 +227,8 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
           kE1 = max(kE1, max(hp - oe1_9 + (511 - 2 * k), e1p - e1_9 + (510 - 2 * k)));
           kE2 = max(kE2, max(hp - oe2_9 + (511 - 2 * k), e2p - e2_9 + (510 - 2 * k)));
         }
-        const int qc = (act && j > 0) ? c3_code_at(c.pk, qb + j - 1) : 7;
+        int qc = 7;
+        if (act && j > 0) qc = qlds ? (int)((L.qpk[(j - 1) >> 4] >> (((j - 1) & 15) * 2)) & 3) : c3_code_at(c.pk, qb + j - 1);
         const int M9 = (j > 0) ? (kM & ~511) + ((vb == qc) ? mt9 : mm9) : NEGS;
         E1v = kE1 & ~511; E2v = kE2 & ~511;
         const int k2 = max(max(M9 + 2, E1v + 1), E2v);
@@ -407,7 +420,7 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
   c.score = a.score + slot * N;
   c.H = a.H + (size_t)slot * a.cells_cap; c.E1 = a.E1 + (size_t)slot * a.cells_cap; c.E2 = a.E2 + (size_t)slot * a.cells_cap;
   c.D = a.D + (size_t)slot * a.cells_cap; c.rows2 = a.rows2 + slot * 4 * N;
-  c.descA = a.desc + (size_t)slot * 2 * N; c.descB = c.descA + N;
+  c.descA = a.desc + (size_t)slot * 2 * N; c.descB = c.descA + N; c.jump = a.jump + (size_t)slot * C3_JUMP_LEVELS * N;
   __shared__ PoaLds L;
   c.K = a.K; c.Ncap = a.Ncap; c.cells_cap = a.cells_cap;
   PH_DECL
@@ -449,19 +462,21 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
       PH_MARK(9)
       if (!fail) {
         // ---- MSA columns = aligned blocks in topological order
-        if (lane == 0) {
-          int nc = 0, prev_rep = -1;
-          for (int i = 0; i < c.n; ++i) {
-            int v = c.order[i];
-            if (v == SRC || v == SNK) { c.col[v] = -1; continue; }
-            if (c.grp[v] != prev_rep) { ++nc; prev_rep = c.grp[v]; }
-            c.col[v] = nc - 1;
+        int ncol_acc = 0;
+        for (int i0 = 0; i0 < c.n; i0 += 64) {      // column = number of block starts up to here (prefix sum)
+          const int i = i0 + lane;
+          int v = -1, start = 0;
+          if (i < c.n) {
+            v = c.order[i];
+            if (v != SRC && v != SNK) start = (i == 0) || (c.grp[v] != c.grp[c.order[i - 1]]) || c.order[i - 1] == SRC;
           }
-          c.rem[0] = nc;
+          const int ps = wave_scan_add(start);
+          if (i < c.n) c.col[v] = (v == SRC || v == SNK) ? -1 : ncol_acc + ps - 1;
+          ncol_acc += wave_bcast(ps, 63);
         }
         WSYNC();
         PH_MARK(5)
-        const int ncol = c.rem[0];
+        const int ncol = ncol_acc;
         for (int i = lane; i < ncol; i += 64) c.col2t[i] = -1;
         if (a.msa_dbg) {                       // res.msa_seq rows (codes, 4 = gap), row-major
           uint8_t* dbg = a.msa_dbg + a.msa_off[rid];
@@ -513,26 +528,69 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
           WSYNC();
           C = c.rem[0];
         } else {
-          // ---- heaviest bundling (reverse sweep, lane 0)
-          if (lane == 0) {
-            const int K = c.K;
-            for (int i = c.n - 1; i >= 0; --i) {
-              int v = c.order[i];
-              if (v == SNK) { c.score[v] = 0; c.nxt[v] = -1; continue; }
-              int bw = INT32_MIN, bt = -1;
-              for (int k = 0; k < c.n_out[v]; ++k) {
-                int t = c.out_to[v * K + k], ww = c.out_w[v * K + k];
-                if (ww > bw) { bw = ww; bt = t; }
-                else if (ww == bw && c.score[bt] <= c.score[t]) bt = t;
+          // ---- abPOA heaviest bundling.  Reverse sweep, 64 nodes at a time: their out-edges are fetched in
+          // parallel and consumed in order through lane broadcasts; scores of the last 512 nodes sit in
+          // an LDS ring (ties need them), older ones come from memory.  The path itself is then read
+          // off binary-lifting jump tables instead of a 1500-step pointer chase.
+          {
+            const int K = c.K, n = c.n;
+            int* sring = &L.H[0][0];                       // PR*PW >= 512 ints, free after the alignments
+            int* sc32 = c.rem;                             // scores of all nodes (global copy)
+            for (int i1 = n; i1 > 0; i1 -= 64) {
+              const int i = i1 - 1 - lane;                 // lane 0 = last node of the chunk
+              int v = 0, no = 0, t0 = 0, w0 = 0, x0 = 0, t1 = 0, w1 = 0, x1 = 0;
+              if (i >= 0) {
+                v = c.order[i]; no = c.n_out[v];
+                if (no > 0) { t0 = c.out_to[v * K]; w0 = c.out_w[v * K]; x0 = c.index[t0]; }
+                if (no > 1) { t1 = c.out_to[v * K + 1]; w1 = c.out_w[v * K + 1]; x1 = c.index[t1]; }
               }
-              c.nxt[v] = bt; c.score[v] = (long long)bw + c.score[bt];
+              const int cnt = min(64, i1);
+              for (int t = 0; t < cnt; ++t) {
+                const int vv = wave_bcast(v, t), nn = wave_bcast(no, t), ii = i1 - 1 - t;
+                int bw = INT32_MIN, bt = SNK, sbt = 0;
+                if (vv != SNK) {
+                  for (int k = 0; k < nn; ++k) {
+                    int tt, ww, xx;
+                    if (k == 0) { tt = wave_bcast(t0, t); ww = wave_bcast(w0, t); xx = wave_bcast(x0, t); }
+                    else if (k == 1) { tt = wave_bcast(t1, t); ww = wave_bcast(w1, t); xx = wave_bcast(x1, t); }
+                    else { tt = c.out_to[vv * K + k]; ww = c.out_w[vv * K + k]; xx = c.index[tt]; }
+                    const int st = (xx - ii < 512) ? sring[xx & 511] : sc32[tt];
+                    if (ww > bw) { bw = ww; bt = tt; sbt = st; }
+                    else if (ww == bw && sbt <= st) { bt = tt; sbt = st; }
+                  }
+                }
+                const int scv = (vv == SNK) ? 0 : bw + sbt;
+                if (lane == 0) { sring[ii & 511] = scv; sc32[vv] = scv; c.nxt[vv] = bt; }
+              }
             }
-            int o = 0;
-            for (int v = c.nxt[SRC]; v != SNK && v >= 0; v = c.nxt[v]) { draft[o] = c.base[v]; c.col2t[c.col[v]] = o; ++o; }
-            c.rem[0] = o;
+            WSYNC();
+            // jump tables J_r = nxt^(2^r) and hop counts; level r lives in c.jump + r*Ncap (level 0 = nxt)
+            int* d0 = c.mpl; int* d1 = c.mpr;
+            for (int v = lane; v < n; v += 64) { c.jump[v] = c.nxt[v]; d0[v] = (v == SNK) ? 0 : 1; }
+            WSYNC();
+            int levels = 1;
+            for (int r = 0; (1 << r) < n && r + 1 < C3_JUMP_LEVELS; ++r) {
+              const int* Jr = c.jump + (size_t)r * c.Ncap; int* Jn = c.jump + (size_t)(r + 1) * c.Ncap;
+              for (int v = lane; v < n; v += 64) { const int u = Jr[v]; Jn[v] = Jr[u]; d1[v] = d0[v] + d0[u]; }
+              WSYNC();
+              int* tsw = d0; d0 = d1; d1 = tsw;
+              levels = r + 2;
+            }
+            const int hops = d0[SRC];                      // edges from SRC to SNK
+            C = hops - 1;
+            if (n > (1 << (C3_JUMP_LEVELS - 1))) C = -1;                           // graph larger than the tables reach
+            for (int p0 = 0; p0 < C; p0 += 64) {
+              const int pp = p0 + lane;
+              if (pp < C) {
+                int node = SRC; const int steps = pp + 1;
+                for (int r = 0; r < levels; ++r) if ((steps >> r) & 1) node = c.jump[(size_t)r * c.Ncap + node];
+                draft[pp] = c.base[node]; c.col2t[c.col[node]] = pp;
+              }
+            }
+            if (C < 0) { fail = 1; C = 0; }
+            WSYNC();
           }
-          WSYNC();
-          C = c.rem[0];
+
         }
         PH_MARK(6)
         // ---- subread -> draft coordinates
