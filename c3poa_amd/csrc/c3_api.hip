@@ -363,10 +363,10 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     wcap += (2 * h->sum[i].max_sub + WL - 1) / WL + 1;
   }
   const int NLcap = max_ns + 2, NWcap = (2 * max_q + WL - 1) / WL + 1;
-  const int64_t ecap = (int64_t)(max_dang + 2) * (2 * h->cfg.dang_band + 1);
-  const size_t per_slot_prep = (size_t)ecap * 5 + (size_t)NLcap * NWcap * 8;
+  const int64_t ecap = (int64_t)(max_dang + 2) * 512;          // direction bytes: 512 per piece row
+  const size_t per_slot_prep = (size_t)ecap + (size_t)NLcap * NWcap * 8;
   const int slots_p = auto_slots(h, h->cfg.slots_poa, per_slot_prep, nw, 16);
-  HIPCHK(h->s_eH.ensure(sizeof(int32_t) * (size_t)ecap * slots_p)); HIPCHK(h->s_eD.ensure((size_t)ecap * slots_p));
+  HIPCHK(h->s_eD.ensure((size_t)ecap * slots_p));
   HIPCHK(h->s_lw.ensure(sizeof(int) * (size_t)NLcap * NWcap * 2 * slots_p));
   HIPCHK(h->d_wrec.ensure(sizeof(WinRec) * (size_t)wcap)); HIPCHK(h->d_wlay.ensure(sizeof(WLayer) * (size_t)wcap * NLcap));
   HIPCHK(h->d_wbase.ensure(sizeof(int) * (size_t)h->n));

@@ -21,69 +21,106 @@
 
 
 
-// anchored banded extension alignment (oracle/c3o_polish.c: extend_align).  piece base k is
-// read position pb + dir_*k, draft base t is draft position db + dir_*t (dir_ = -1 for the front
-// piece: both sequences reversed).  Writes tpos for the aligned piece bases.
-__device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const uint8_t* draft, int C,
-                                  int pb, int n, int dir_, int32_t* tpos, int32_t* H, uint8_t* D, int lane) {
+// anchored banded extension alignment (oracle/c3o_polish.c: extend_align).  piece base k is read
+// position pb + dir_*k, draft base t is draft position db + dir_*t (dir_ = -1 for the front piece:
+// both sequences reversed).  Writes tpos for the aligned piece bases.
+//
+// Lane owns EC consecutive band offsets (bb = lane*EC + cc; cell (i, j = i - W + bb)); the previous
+// row lives in registers (diagonal = same offset, up = offset+1), the left gap is an in-lane prefix
+// plus one DPP max-scan, cells are KEY = score*4 + tag (3 diag, 2 up, 1 left) so one v_max per
+// candidate keeps the oracle's tie order.  Only the direction bytes go to memory (8 per lane per row);
+// the draft sits in LDS and the piece bases arrive 64 rows at a time, so the row loop has no loads.
+#define EC 5
+#define EXT_DCAP 4096        // draft bases kept in LDS; longer drafts read the global copy
+__device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const uint8_t* draft, const uint8_t* ldraft, int C,
+                                  int pb, int n, int dir_, int32_t* tpos, uint8_t* D, int lane) {
   const int W = a.p.dang_band, bw = 2 * W + 1;
-  const int mt = a.p.pol_match, mm = a.p.pol_mismatch, g = a.p.pol_gap;
+  const int mt4 = a.p.pol_match * 4, mm4 = a.p.pol_mismatch * 4, g4 = a.p.pol_gap * 4;
   const int db = dir_ > 0 ? 0 : C - 1;
+  const int NEGK = -(1 << 28);
   for (int k = lane; k < n; k += 64) tpos[pb + dir_ * k] = -1;
-  if ((long long)(n + 1) * bw > a.ecap) return -1;
-  int best = 0, bi = 0, bj = 0;
-  long long cells = 0;
-  for (int i = 0; i <= n; ++i) {
-    const int jlo = max(0, i - W), jhi = min(C, i + W);
-    const int pc = i > 0 ? c3_code_at(pk, pb + dir_ * (i - 1)) : 0;
-    int carry = C3_NEG2;          // max over previous chunks of (Hv - g*b)
-    for (int c0 = 0; c0 < bw; c0 += 64) {
-      const int bb = c0 + lane, j = i - W + bb;
-      const bool act = bb < bw && j >= jlo && j <= jhi;
-      int hv = C3_NEG2, dirv = 0;
-      if (act) {
-        if (i == 0) { hv = C3_NEG2; }
-        else {
-          // diag (i-1, j-1): same band offset; up (i-1, j): offset bb+1
-          const bool dok = j > 0 && (j - 1) >= max(0, i - 1 - W) && (j - 1) <= min(C, i - 1 + W);
-          const bool uok = j >= max(0, i - 1 - W) && j <= min(C, i - 1 + W);
-          int b2 = INT32_MIN;
-          if (dok) { b2 = H[(size_t)(i - 1) * bw + bb] + ((pc == (int)draft[db + dir_ * (j - 1)]) ? mt : mm); dirv = 0; }
-          if (uok) { int u = H[(size_t)(i - 1) * bw + bb + 1] + g; if (u > b2) { b2 = u; dirv = 1; } }
-          hv = b2 == INT32_MIN ? C3_NEG2 : b2;
-        }
-      }
-      int hh;
-      if (i == 0) { hh = j * g; dirv = 2; }
-      else {
-        // left neighbour through a max-scan: H[b] = max(hv[b], max_{b'<b, same row} hv[b'] + g*(b-b'))
-        const int x = act ? hv - g * bb : C3_NEG2;
-        const int s = wave_scan_max(x);
-        const int ex = max(wave_shr1(s, C3_NEG2), carry);
-        carry = max(carry, wave_bcast(s, 63));
-        const int lf = (j > jlo) ? ex + g * bb : INT32_MIN;
-        hh = hv;
-        if (lf > hv) { hh = lf; dirv = 2; }
-      }
-      if (act) {
-        H[(size_t)i * bw + bb] = hh; D[(size_t)i * bw + bb] = (uint8_t)dirv;
-        ++cells;
-        if (i > 0 && j > 0 && hh > best) { best = hh; bi = i; bj = j; }
-      }
-    }
-    WSYNC();
+  if (bw > 64 * EC || (long long)(n + 1) * 512 > a.ecap) return -1;
+  const bool dl = C <= EXT_DCAP;
+  int hprev[EC];
+#pragma unroll
+  for (int cc = 0; cc < EC; ++cc) {           // row 0: H[0][j] = j*g for 0 <= j <= min(C, W)
+    const int bb = lane * EC + cc, j = bb - W;
+    hprev[cc] = (bb < bw && j >= 0 && j <= C) ? j * g4 : NEGK;
   }
+  int best = 0, bi = 0, bj = 0;
+  long long cells = lane == 0 ? min(C, W) + 1 : 0;          // row 0
+  for (int ib = 1; ib <= n; ib += 64) {
+    int pcs = 0;                              // piece base of row ib+lane
+    if (ib + lane <= n) pcs = c3_code_at(pk, pb + dir_ * (ib + lane - 1));
+    asm volatile("" : "+v"(pcs));
+    const int cnt = min(64, n - ib + 1);
+    for (int li = 0; li < cnt; ++li) {
+      const int i = ib + li;
+      const int pc = __builtin_amdgcn_readlane(pcs, li);
+      const int jlo = max(0, i - W);
+      // up neighbour of the last owned offset = first offset of the next lane
+      const int nxt0 = __builtin_amdgcn_update_dpp(NEGK, hprev[0], 0x130, 0xf, 0xf, false);   // wave_shl:1
+      int key[EC], y[EC];
+      int run = NEGK;
+#pragma unroll
+      for (int cc = 0; cc < EC; ++cc) {
+        const int bb = lane * EC + cc, j = i - W + bb;
+        const bool val = bb < bw && j >= 0 && j <= C;
+        int k = INT32_MIN;
+        if (val) {
+          if (j > 0) {
+            const int dcode = dl ? (int)ldraft[db + dir_ * (j - 1)] : (int)draft[db + dir_ * (j - 1)];
+            k = hprev[cc] + ((pc == dcode) ? mt4 : mm4) + 3;
+          }
+          const int up = (cc + 1 < EC) ? hprev[cc + 1 < EC ? cc + 1 : cc] : nxt0;
+          if (bb + 1 < bw) k = max(k, up + g4 + 2);
+        }
+        key[cc] = val ? k : NEGK;
+        y[cc] = val ? (k & ~3) - g4 * bb : NEGK;
+        run = max(run, y[cc]);
+      }
+      const int s = wave_scan_max(run);
+      int ex = wave_shr1(s, NEGK);
+      unsigned d0 = 0, d1 = 0;
+#pragma unroll
+      for (int cc = 0; cc < EC; ++cc) {
+        const int bb = lane * EC + cc, j = i - W + bb;
+        const bool val = bb < bw && j >= 0 && j <= C;
+        int k2 = key[cc];
+        if (val && j > jlo) k2 = max(k2, ex + g4 * bb + 1);
+        ex = max(ex, y[cc]);
+        const int hh = k2 & ~3;
+        hprev[cc] = val ? hh : NEGK;
+        const unsigned dir = val ? (unsigned)(3 - (k2 & 3)) : 3u;      // 0 diag, 1 up, 2 left
+        if (cc < 4) d0 |= dir << (8 * cc); else d1 |= dir;
+        if (val) { ++cells; if (j > 0 && hh > best) { best = hh; bi = i; bj = j; } }
+      }
+      unsigned* drow = (unsigned*)(D + (size_t)i * 512) + lane * 2;
+      drow[0] = d0; drow[1] = d1;
+    }
+  }
+  WSYNC();
   // first maximum in row-major order
   const int gb = wave_max(best);
   const int gi = wave_min(best == gb ? bi : INT32_MAX / 2);
   const int gj = wave_min((best == gb && bi == gi) ? bj : INT32_MAX / 2);
-  if (gb > 0 && lane == 0) {
+  if (gb > 0) {
+    // traceback; diagonal runs keep the band offset, so 64 steps are checked per round
     int i = gi, j = gj;
     while (i > 0 || j > 0) {
-      const int d = D[(size_t)i * bw + (j - i + W)];
-      if (d == 0) { tpos[pb + dir_ * (i - 1)] = db + dir_ * (j - 1); --i; --j; }
-      else if (d == 1) --i;
-      else --j;
+      if (i == 0) break;                                   // row 0: only left moves, nothing to record
+      const int bb = j - i + W;
+      const int ik = i - lane;
+      int d = 3;
+      if (ik >= 1) d = D[(size_t)ik * 512 + (bb / EC) * 8 + bb % EC];
+      const unsigned long long bal = __ballot(ik >= 1 && d == 0 && j - lane >= 1);
+      const int m = (~bal) ? __builtin_ctzll(~bal) : 64;
+      if (lane < m) tpos[pb + dir_ * (ik - 1)] = db + dir_ * (j - lane - 1);
+      i -= m; j -= m;
+      if (m < 64 && i > 0) {
+        const int dbk = wave_bcast(d, m);
+        if (dbk == 1) --i; else if (dbk == 2) --j; else break;       // 0 here would mean j == 0: cannot happen
+      }
     }
   }
   WSYNC();
@@ -95,7 +132,7 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
 __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
   const int lane = wave_lane();
   const int slot = blockIdx.x;
-  int32_t* eH = a.eH + (size_t)slot * a.ecap;
+  __shared__ uint8_t ldraft[EXT_DCAP];
   uint8_t* eD = a.eD + (size_t)slot * a.ecap;
   int* lwf = a.lw_first + (size_t)slot * a.NLcap * a.NWcap;
   int* lwl = a.lw_last + (size_t)slot * a.NLcap * a.NWcap;
@@ -118,8 +155,9 @@ __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
     const int hf = info->has_front, ht = info->has_tail;
     long long cells = 0;
     // ---- dangling pieces (tail: anchored at the draft start; front: at the draft end)
-    if (ht) { long long r = extend_align(a, pk, draft, C, info->tail_beg, L - info->tail_beg, +1, tpos, eH, eD, lane); if (r > 0) cells += r; }
-    if (hf) { long long r = extend_align(a, pk, draft, C, info->front_end - 1, info->front_end, -1, tpos, eH, eD, lane); if (r > 0) cells += r; }
+    if ((ht || hf) && C <= EXT_DCAP) { for (int t = lane; t < C; t += 64) ldraft[t] = draft[t]; WSYNC(); }
+    if (ht) { long long r = extend_align(a, pk, draft, ldraft, C, info->tail_beg, L - info->tail_beg, +1, tpos, eD, lane); if (r > 0) cells += r; }
+    if (hf) { long long r = extend_align(a, pk, draft, ldraft, C, info->front_end - 1, info->front_end, -1, tpos, eD, lane); if (r > 0) cells += r; }
     // ---- layers: kept subreads, front, tail
     const int nl = ns + hf + ht;
     const int nwin = (C + WL - 1) / WL;
