@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""C3POa.py -- drop-in CLI of the MI355X-native R2C2 consensus caller.
+
+Same flags, inputs and output tree as rvolden/C3POa v2.2.3 (/root/reference/C3POa.py:26-63, 175-272):
+    python3 C3POa.py -r reads.fastq -s splint.fasta -o out -c config -l 1000 -d 500 -n N -g 1000 [-z] [-b] [-co]
+writes <out>/c3poa.log, <out>/tmp/splint_to_read_alignments.psl (reused when present),
+<out>/<splint>/R2C2_Consensus.fasta[.gz] and <out>/<splint>/R2C2_Subreads.fastq[.gz].
+
+Differences, all deliberate: the per-read hot path runs on the GPU(s) through
+libc3poa_hip.so instead of conk/pyabpoa/mappy/racon; -n selects how many GPUs share the groups;
+the last, short group is flushed (the reference never dispatches it);
+racon/blat config entries are accepted, racon is never executed.
+"""
+import argparse
+import gzip
+import os
+import shutil
+import sys
+from glob import glob
+
+PATH = os.path.dirname(os.path.realpath(__file__))
+sys.path.insert(0, PATH)
+
+from c3poa_amd import VERSION  # noqa: E402
+from c3poa_amd.seqio import fastx_read, revcomp  # noqa: E402
+
+
+def parse_args(argv=None):
+    parser = argparse.ArgumentParser(description="Makes consensus sequences from R2C2 reads.", add_help=True, prefix_chars="-")
+    parser.add_argument("--reads", "-r", type=str, action="store", help="FASTQ file that contains the long R2C2 reads.")
+    parser.add_argument("--splint_file", "-s", type=str, action="store", help="Path to the splint FASTA file.")
+    parser.add_argument("--out_path", "-o", type=str, action="store", default=os.getcwd(),
+                        help="Directory where all the files will end up. Defaults to your current directory.")
+    parser.add_argument("--config", "-c", type=str, action="store", default="",
+                        help="Config file with paths to racon and blat (tab separated).")
+    parser.add_argument("--lencutoff", "-l", type=int, action="store", default=1000,
+                        help="Sets the length cutoff for your raw sequences. Defaults to 1000.")
+    parser.add_argument("--mdistcutoff", "-d", type=int, action="store", default=500,
+                        help="Sets the median distance cutoff for consensus sequences. Defaults to 500.")
+    parser.add_argument("--zero", "-z", action="store_false", default=True,
+                        help="Use to exclude zero repeat reads. Defaults to True (includes zero repeats).")
+    parser.add_argument("--numThreads", "-n", type=int, default=1, help="Number of GPUs (workers) to use. Defaults to 1.")
+    parser.add_argument("--groupSize", "-g", type=int, default=1000,
+                        help="Number of reads processed by each worker in each iteration. Defaults to 1000.")
+    parser.add_argument("--blatThreads", "-b", action="store_true", default=False, help="Accepted for compatibility.")
+    parser.add_argument("--compress_output", "-co", action="store_true", default=False,
+                        help="Use to compress (gzip) both the consensus fasta and subread fastq output files.")
+    parser.add_argument("--version", "-v", action="version", version=VERSION, help="Prints the C3POa version.")
+    if argv is None and len(sys.argv) == 1:
+        parser.print_help()
+        sys.exit(0)
+    return parser.parse_args(argv)
+
+
+def configReader(path, configIn):
+    """C3POa.py:65-84: tab separated name<TAB>path, '#' comments, missing keys fall back to PATH"""
+    progs = {}
+    with open(configIn) as f:
+        for line in f:
+            if line.startswith("#") or not line.rstrip().split():
+                continue
+            line = line.rstrip().split("\t")
+            progs[line[0]] = line[1]
+    for missing in set(["racon", "blat"]) - set(progs):
+        progs[missing] = missing
+        sys.stderr.write("Using " + str(missing) + " from your path, not the config file.\n")
+    return progs
+
+
+def cat_files(path, pattern, output, compress):
+    """C3POa.py:86-99"""
+    if compress:
+        output += ".gz"
+        final_fh = gzip.open(output, "wb+")
+    else:
+        final_fh = open(output, "w+")
+    for f in sorted(glob(path + pattern)):
+        with open(f) as fh:
+            for line in fh:
+                final_fh.write(line.encode() if compress else line)
+    final_fh.close()
+
+
+def main(args):
+    from c3poa_amd.analyze import analyze_reads
+    from c3poa_amd.preprocess import preprocess
+    if not args.out_path.endswith("/"):
+        args.out_path += "/"
+    os.makedirs(args.out_path, exist_ok=True)
+    log_file = open(args.out_path + "c3poa.log", "w+")
+    if args.config:
+        progs = configReader(args.out_path, args.config)
+        racon, blat = progs["racon"], progs["blat"]
+    else:
+        racon, blat = "racon", "blat"
+    tmp_dir = args.out_path + "tmp/"
+    os.makedirs(tmp_dir, exist_ok=True)
+
+    total_reads, short_reads, tmp_adapter_dict = 0, 0, {}
+    for read in fastx_read(args.reads):
+        if len(read[1]) < args.lencutoff:
+            short_reads += 1
+            continue
+        tmp_adapter_dict[read[0]] = [[None, 1, None]]
+        total_reads += 1
+    adapter_dict, adapter_set, no_splint = preprocess(blat, args, tmp_dir, tmp_adapter_dict, total_reads)
+    for adapter in adapter_set:
+        os.makedirs(args.out_path + adapter, exist_ok=True)
+
+    all_reads = total_reads + short_reads
+    print("C3POa version:", VERSION, file=log_file)
+    print("Total reads:", all_reads, file=log_file)
+    print("No splint reads:", no_splint, "({:.2f}%)".format((no_splint / all_reads) * 100), file=log_file)
+    print("Under len cutoff:", short_reads, "({:.2f}%)".format((short_reads / all_reads) * 100), file=log_file)
+    print("Total thrown away reads:", short_reads + no_splint,
+          "({:.2f}%)".format(((short_reads + no_splint) / all_reads) * 100), file=log_file)
+    print("Reads after preprocessing:", all_reads - (short_reads + no_splint), file=log_file)
+    log_file.close()
+
+    splint_dict = {}
+    for splint in fastx_read(args.splint_file):
+        splint_dict[splint[0]] = [splint[1], revcomp(splint[1])]
+
+    n_dev = max(1, args.numThreads)
+    try:
+        import torch
+        n_dev = max(1, min(n_dev, torch.cuda.device_count()))
+    except Exception:
+        n_dev = 1
+    iteration, tmp_reads = 1, []
+    for read in fastx_read(args.reads):
+        if len(read[1]) < args.lencutoff:
+            continue
+        tmp_reads.append(read)
+        if len(tmp_reads) == args.groupSize:
+            analyze_reads(args, tmp_reads, splint_dict, adapter_dict, adapter_set, iteration, racon, device=(iteration - 1) % n_dev)
+            iteration += 1
+            tmp_reads = []
+    if tmp_reads:                                     # flush the tail (deliberate fix of App. A.12)
+        analyze_reads(args, tmp_reads, splint_dict, adapter_dict, adapter_set, iteration, racon, device=(iteration - 1) % n_dev)
+
+    for adapter in adapter_set:
+        cat_files(args.out_path + adapter, "/tmp*/R2C2_Consensus.fasta", args.out_path + adapter + "/R2C2_Consensus.fasta", args.compress_output)
+        cat_files(args.out_path + adapter, "/tmp*/subreads.fastq", args.out_path + adapter + "/R2C2_Subreads.fastq", args.compress_output)
+        for d in glob(args.out_path + adapter + "/tmp*"):
+            shutil.rmtree(d)
+
+
+if __name__ == "__main__":
+    args = parse_args()
+    if not args.reads or not args.splint_file:
+        print("Reads (--reads/-r) and splint (--splint_file/-s) are required", file=sys.stderr)
+        sys.exit(1)
+    main(args)

@@ -18,7 +18,7 @@ ST_OK, ST_NOT_ASSIGNED, ST_NO_PEAKS, ST_NO_CONSENSUS, ST_TOO_SHORT, ST_LIMIT = r
 EXPORTS = ["c3_default_config", "c3_version", "c3_create", "c3_destroy", "c3_last_error", "c3_set_splints",
            "c3_batch_upload", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_timing",
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
-           "c3_poa_msa", "c3_determine_consensus"]
+           "c3_call_peaks", "c3_poa_msa", "c3_determine_consensus"]
 
 
 class Config(C.Structure):
@@ -81,6 +81,7 @@ def load():
     lib.c3_fetch_raw_peaks.argtypes = [vp, C.c_int, vp, C.c_int]
     lib.c3_fetch_draft.argtypes = [vp, C.c_int, vp, C.c_int]
     lib.c3_fetch_msa2.argtypes = [vp, C.c_int, vp, vp, C.c_int]
+    lib.c3_call_peaks.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
     lib.c3_poa_msa.argtypes = [vp, C.c_int, C.POINTER(cp), ip, vp, C.c_int, ip, vp, C.c_int64, ip]
     lib.c3_determine_consensus.argtypes = [vp, C.c_int, C.POINTER(cp), C.POINTER(cp), ip, cp, cp, C.c_int,
                                            cp, cp, C.c_int, vp, C.c_int, ip, vp, C.c_int, ip]
@@ -212,6 +213,16 @@ class Handle:
         buf = C.create_string_buffer(L)
         n = self._chk(self.lib.c3_fetch_draft(self.h, i, buf, L))
         return buf.raw[:n].decode()
+
+    def call_peaks(self, scores, min_dist, return_smoothed=False):
+        s = np.ascontiguousarray(scores, dtype=np.int32)
+        pk = np.zeros(MAX_PEAKS, dtype=np.int32)
+        sm = np.zeros(len(s), dtype=np.float64) if return_smoothed else None
+        n = self._chk(self.lib.c3_call_peaks(self.h, s.ctypes.data, len(s), int(min_dist), pk.ctypes.data, MAX_PEAKS,
+                                             sm.ctypes.data if sm is not None else None))
+        self.n = 0
+        out = pk[:n].astype(np.int64)
+        return (out, sm) if return_smoothed else out
 
     def poa_msa(self, seqs, out_cons=True, out_msa=True):
         n = len(seqs)

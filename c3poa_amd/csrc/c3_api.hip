@@ -605,6 +605,28 @@ static int inject(c3_handle* h, int n, const char* const* subs, const char* cons
   return 0;
 }
 
+extern "C" int c3_call_peaks(c3_handle* h, const int32_t* scores, int n, int min_dist, int32_t* peaks, int cap, double* smoothed) {
+  if (!h || !scores || n <= 0 || !peaks) return C3_E_ARG;
+  if (h->n_spl <= 0) { const char sp[] = "ACGT"; int64_t o[2] = {0, 4}; int rc = c3_set_splints(h, 1, sp, o); if (rc) return rc; }
+  std::string seq((size_t)n, 'A'), ql((size_t)n, 'I');
+  int64_t off[2] = {0, n};
+  int16_t sid = 0; char st = '+';
+  int rc = c3_batch_upload(h, 1, seq.data(), ql.data(), off, &sid, &st);
+  if (rc) return rc;
+  HIPCHK(h->d_track.ensure(sizeof(int32_t) * (size_t)n + 64));
+  HIPCHK(hipMemcpy(h->d_track.p, scores, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+  h->stages_done |= C3_STAGE_CONK;
+  const int md0 = h->cfg.mdistcutoff;
+  h->cfg.mdistcutoff = min_dist;
+  rc = c3_batch_run(h, C3_STAGE_PEAKS);
+  h->cfg.mdistcutoff = md0;
+  if (rc) return rc;
+  int np = c3_fetch_raw_peaks(h, 0, peaks, cap);
+  if (np < 0) return np;
+  if (smoothed) { int r2 = c3_fetch_smoothed(h, 0, smoothed, n); if (r2 < 0) return r2; }
+  return np;
+}
+
 extern "C" int c3_poa_msa(c3_handle* h, int n, const char* const* seqs, const int* lens,
                           char* cons, int cons_cap, int* cons_len, char* msa, int64_t msa_cap, int* msa_len) {
   if (!h) return C3_E_ARG;

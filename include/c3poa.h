@@ -131,6 +131,10 @@ int c3_fetch_msa2(c3_handle* h, int read, char* rowA, char* rowB, int cap);
 
 /* stand-alone stage entry points used by the per-stage Python shims.  Each one uploads its
  * arguments, runs the corresponding kernels and returns the result. */
+/* call_peaks(scores, min_dist, iters, window, order) (bin/call_peaks.py:8-16; iters/window/order are the
+ * handle's sg_* settings): returns the number of peaks written to `peaks` (0 = gated / none);
+ * smoothed (optional, n doubles) receives the smoothed track. */
+int c3_call_peaks(c3_handle* h, const int32_t* scores, int n, int min_dist, int32_t* peaks, int cap, double* smoothed);
 /* pyabpoa.msa_aligner(match=5).msa(seqs, out_cons, out_msa) (determine_consensus.py:30,34,43):
  * msa receives n rows of *msa_len chars (row-major).  quals may be NULL. */
 int c3_poa_msa(c3_handle* h, int n, const char* const* seqs, const int* lens,
