@@ -90,7 +90,9 @@ def main():
     quals = [r[1] for r in recs] * reps
     strands = [r[2] for r in recs] * reps
     seqs, quals, strands = seqs[:a.reads], quals[:a.reads], strands[:a.reads]
+    t_up = time.perf_counter()
     h.upload(seqs, quals, strands)              # H2D + 2-bit pack: outside the timed region
+    t_up = time.perf_counter() - t_up
     lens = np.array([len(s) for s in seqs], dtype=np.int64)
     del seqs, quals
 
@@ -139,7 +141,9 @@ def main():
             "config": {"workload": "%s: %d reads/GPU/step, 5 kb, 3x1.5 kb repeats, Splint1, 10%% error" % (a.cfg, a.reads)
                        if a.cfg == "cfg2" else "%s: %d reads/GPU/step" % (a.cfg, a.reads),
                        "stages": "conk+peaks/split+POA+polish", "reads_per_gpu_step": a.reads,
-                       "consensus_ok": int(ok.sum()), "mean_read_len": float(lens.mean())},
+                       "consensus_ok": int(ok.sum()), "mean_read_len": float(lens.mean()),
+                       "upload_ms": round(t_up * 1e3, 1),
+                       "pcie_inclusive_reads_per_s": round(a.reads * world / (dt / a.steps + t_up), 1)},
             "roofline": {"bound": "hbm", "kernel": dom.replace("ms_", "k_"), "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": None, "alg_bytes_per_launch": alg_bytes,
