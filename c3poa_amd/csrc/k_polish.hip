@@ -505,7 +505,7 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
   }
 }
 
-__global__ __launch_bounds__(64) void k_window(WinArgs a) {
+__global__ __launch_bounds__(64, 3) void k_window(WinArgs a) {
   const int lane = wave_lane();
   const int slot = blockIdx.x;
   WCtx c;
