@@ -10,6 +10,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include "c3o_mem.h"
 
 #define C3O_NEG  (-(1 << 28))   /* out-of-band / unreachable score */
 #define C3O_NEG2 (-(1 << 30))   /* "no left neighbour" for the horizontal-gap state */

@@ -8,6 +8,7 @@
 #include "c3o_internal.h"
 #include <stdlib.h>
 #include <string.h>
+#include "c3o_mem.h"
 
 /* bin/consensus.py:50-74 */
 int c3o_normalize_len(const char* row, int msa_len, const char* qual, int qlen, char* out) {
@@ -26,7 +27,7 @@ int c3o_normalize_len(const char* row, int msa_len, const char* qual, int qlen, 
 
 /* bin/consensus.py:4-44,76-81.  avgQual(A) > avgQual(B) over the same slice and the same
  * divisor is equivalent to comparing the integer sums. */
-int c3o_pairwise_consensus_cols(const char* A, const char* B, int n,
+static int c3o_pairwise_consensus_cols_impl(const char* A, const char* B, int n,
                                 const char* subA, int lenA, const char* qualA,
                                 const char* subB, int lenB, const char* qualB,
                                 char* out, int cap, int* out_col) {
@@ -69,4 +70,11 @@ int c3o_pairwise_consensus(const char* A, const char* B, int n,
                            const char* subB, int lenB, const char* qualB,
                            char* out, int cap) {
   return c3o_pairwise_consensus_cols(A, B, n, subA, lenA, qualA, subB, lenB, qualB, out, cap, 0);
+}
+
+int c3o_pairwise_consensus_cols(const char* A, const char* B, int n,
+                                const char* subA, int lenA, const char* qualA,
+                                const char* subB, int lenB, const char* qualB,
+                                char* out, int cap, int* out_col) {
+  c3o_enter(); int r_ = c3o_pairwise_consensus_cols_impl(A, B, n, subA, lenA, qualA, subB, lenB, qualB, out, cap, out_col); c3o_leave(); return r_;
 }

@@ -11,11 +11,12 @@
 #include <malloc.h>
 #ifdef _OPENMP
 #include <omp.h>
+#include "c3o_mem.h"
 #endif
 
 #define C3O_MAX_SUB 250
 
-int c3o_process_read(const char* splint, int S, const char* seq, const char* qual, int L,
+static int c3o_process_read_impl(const char* splint, int S, const char* seq, const char* qual, int L,
                      const c3o_params* P, c3o_read_result* r, char* cons, int cons_cap) {
   memset(r, 0, sizeof(*r));
   int half = (P->sg_window - 1) / 2;
@@ -55,9 +56,11 @@ int c3o_process_batch(const char* splint_fwd, const char* splint_rc, int S,
                       c3o_read_result* results, char* cons, const int64_t* cons_off) {
   /* keep multi-MB DP buffers on the heap: with the default thresholds every malloc/free of them is
    * an mmap/munmap, which serialises many-core runs on the kernel's address-space lock */
-  mallopt(M_MMAP_THRESHOLD, 1 << 30);
-  mallopt(M_TRIM_THRESHOLD, 1 << 30);
-  mallopt(M_ARENA_MAX, 1024);
+  if (getenv("C3O_MALLOPT")) {
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_ARENA_MAX, 1024);
+  }
 #ifdef _OPENMP
   if (threads > 0) omp_set_num_threads(threads);
 #endif
@@ -70,4 +73,9 @@ int c3o_process_batch(const char* splint_fwd, const char* splint_rc, int S,
                      cons + cons_off[i], (int)(cons_off[i + 1] - cons_off[i]));
   }
   return 0;
+}
+
+int c3o_process_read(const char* splint, int S, const char* seq, const char* qual, int L,
+                     const c3o_params* P, c3o_read_result* r, char* cons, int cons_cap) {
+  c3o_enter(); int r_ = c3o_process_read_impl(splint, S, seq, qual, L, P, r, cons, cons_cap); c3o_leave(); return r_;
 }

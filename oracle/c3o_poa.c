@@ -15,6 +15,7 @@
 #include "c3o_graph.h"
 #include "c3o_internal.h"
 #include <limits.h>
+#include "c3o_mem.h"
 
 #define SRC 0
 #define SNK 1
@@ -323,7 +324,7 @@ int c3o_poa_make_consensus(c3o_poa_state* st) {
   return st->cons_len;
 }
 
-int c3o_poa_msa(const char* const* seqs, const int* lens, int n, const c3o_params* P,
+static int c3o_poa_msa_impl(const char* const* seqs, const int* lens, int n, const c3o_params* P,
                 char* cons, int cons_cap, int* cons_len,
                 char* msa, int64_t msa_cap, int* msa_len, int64_t* cells) {
   int64_t cl = 0;
@@ -353,4 +354,10 @@ int c3o_poa_msa(const char* const* seqs, const int* lens, int n, const c3o_param
   }
   c3o_poa_free(&st);
   return rc;
+}
+
+int c3o_poa_msa(const char* const* seqs, const int* lens, int n, const c3o_params* P,
+                char* cons, int cons_cap, int* cons_len,
+                char* msa, int64_t msa_cap, int* msa_len, int64_t* cells) {
+  c3o_enter(); int r_ = c3o_poa_msa_impl(seqs, lens, n, P, cons, cons_cap, cons_len, msa, msa_cap, msa_len, cells); c3o_leave(); return r_;
 }

@@ -19,6 +19,7 @@
 #include "c3o_internal.h"
 #include <limits.h>
 #include <stdio.h>
+#include "c3o_mem.h"
 
 static const char ACGT[] = "ACGT";
 
@@ -284,7 +285,7 @@ static int window_polish(const uint8_t* bb, int blen, const wlayer* L, int nl, i
 /* ---------- determine_consensus (repeats >= 1) ---------- */
 typedef struct { const char* seq; const char* qual; int len; int* tpos; uint8_t* code; } layer;
 
-int c3o_determine_consensus(const char* const* subs, const char* const* quals,
+static int c3o_determine_consensus_impl(const char* const* subs, const char* const* quals,
                             const int* lens, int n,
                             const char* front, const char* front_q, int front_len,
                             const char* tail, const char* tail_q, int tail_len,
@@ -422,4 +423,13 @@ int c3o_determine_consensus(const char* const* subs, const char* const* quals,
   free(Ls); free(draft);
   if (cells) { cells[0] += cl_poa; cells[1] += cl_pol; }
   return rc ? 0 : olen;
+}
+
+int c3o_determine_consensus(const char* const* subs, const char* const* quals,
+                            const int* lens, int n,
+                            const char* front, const char* front_q, int front_len,
+                            const char* tail, const char* tail_q, int tail_len,
+                            const c3o_params* P, char* out, int cap,
+                            char* draft_out, int draft_cap, int* draft_len, int64_t* cells) {
+  c3o_enter(); int r_ = c3o_determine_consensus_impl(subs, quals, lens, n, front, front_q, front_len, tail, tail_q, tail_len, P, out, cap, draft_out, draft_cap, draft_len, cells); c3o_leave(); return r_;
 }

@@ -14,6 +14,9 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include "c3o_mem.h"
+
+__thread c3o_arena c3o_tls_arena;
 
 void c3o_default_params(c3o_params* p) {
   p->conk_match = 5; p->conk_mismatch = -4; p->conk_penalty = 20;
@@ -42,7 +45,7 @@ int c3o_code(char c) {
  *                    H[i-1][j] - penalty, H[i][j-1] - penalty),   H[-1][*]=H[*][-1]=0
  *   track[d] = sum over cells with j - i == d, for d in [0, L)
  * splint indexes rows (i), read indexes columns (j). */
-int64_t c3o_conk(const char* splint, int S, const char* read, int L,
+static int64_t c3o_conk_impl(const char* splint, int S, const char* read, int L,
                  int match, int mismatch, int penalty, int32_t* track) {
   int32_t* prev = (int32_t*)calloc((size_t)L + 1, sizeof(int32_t));
   int32_t* cur = (int32_t*)calloc((size_t)L + 1, sizeof(int32_t));
@@ -87,7 +90,7 @@ int c3o_savgol_coeffs(int window, int order, double* c) {
  *   acc = 0; for k in 0..half-1: acc = fma(c[k], ypad[i+k] + ypad[i+window-1-k], acc);
  *   acc = fma(c[half], ypad[i+half], acc)
  * which keeps exactly mirror-symmetric inputs exactly symmetric (plateau midpoints as scipy). */
-int c3o_savgol(const double* y, int n, int window, int order, double* out) {
+static int c3o_savgol_impl(const double* y, int n, int window, int order, double* out) {
   double c[257];
   if (window > 257 || c3o_savgol_coeffs(window, order, c)) return -1;
   int half = (window - 1) / 2;
@@ -122,7 +125,7 @@ static int cmp_prio(const void* a, const void* b) {
 }
 
 /* scipy.signal.find_peaks(x, height=height, distance=distance)[0] */
-int c3o_find_peaks(const double* x, int n, double height, int distance,
+static int c3o_find_peaks_impl(const double* x, int n, double height, int distance,
                    int64_t* peaks, int cap) {
   int* cand = (int*)malloc(sizeof(int) * (size_t)(n / 2 + 2));
   int nc = 0;
@@ -166,7 +169,7 @@ int c3o_find_peaks(const double* x, int n, double height, int distance,
 }
 
 /* bin/call_peaks.py:8-16 */
-int c3o_call_peaks(const int32_t* scores, int n, int min_dist, int iters,
+static int c3o_call_peaks_impl(const int32_t* scores, int n, int min_dist, int iters,
                    int window, int order, int64_t* peaks, int cap, double* smoothed) {
   int half = (window - 1) / 2;
   if (n < half + 1) return -1;
@@ -200,7 +203,7 @@ int c3o_rounding(int x, int base) {
 }
 
 /* C3POa.py:127-155 */
-int c3o_split(const int64_t* peaks_in, int n_in, int S, int L,
+static int c3o_split_impl(const int64_t* peaks_in, int n_in, int S, int L,
               int64_t* peaks_out, int* sub_beg, int* sub_end, c3o_split_info* info) {
   memset(info, 0, sizeof(*info));
   int np = 0;
@@ -234,4 +237,28 @@ int c3o_split(const int64_t* peaks_in, int n_in, int S, int L,
     info->has_tail = 1; info->tail_beg = (int)peaks_out[0];
   }
   return np;
+}
+
+int64_t c3o_conk(const char* splint, int S, const char* read, int L,
+                 int match, int mismatch, int penalty, int32_t* track) {
+  c3o_enter(); int64_t r_ = c3o_conk_impl(splint, S, read, L, match, mismatch, penalty, track); c3o_leave(); return r_;
+}
+
+int c3o_savgol(const double* y, int n, int window, int order, double* out) {
+  c3o_enter(); int r_ = c3o_savgol_impl(y, n, window, order, out); c3o_leave(); return r_;
+}
+
+int c3o_find_peaks(const double* x, int n, double height, int distance,
+                   int64_t* peaks, int cap) {
+  c3o_enter(); int r_ = c3o_find_peaks_impl(x, n, height, distance, peaks, cap); c3o_leave(); return r_;
+}
+
+int c3o_call_peaks(const int32_t* scores, int n, int min_dist, int iters,
+                   int window, int order, int64_t* peaks, int cap, double* smoothed) {
+  c3o_enter(); int r_ = c3o_call_peaks_impl(scores, n, min_dist, iters, window, order, peaks, cap, smoothed); c3o_leave(); return r_;
+}
+
+int c3o_split(const int64_t* peaks_in, int n_in, int S, int L,
+              int64_t* peaks_out, int* sub_beg, int* sub_end, c3o_split_info* info) {
+  c3o_enter(); int r_ = c3o_split_impl(peaks_in, n_in, S, L, peaks_out, sub_beg, sub_end, info); c3o_leave(); return r_;
 }

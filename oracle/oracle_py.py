@@ -196,6 +196,7 @@ def process_batch(splint, reads, strands, params=None, threads=1):
     lib().c3o_process_batch(sp, _b(revcomp(splint)), len(sp), seqs, quals, off.ctypes.data_as(C.c_void_p), n,
                             st, C.byref(P), threads, res, cons, off.ctypes.data_as(C.c_void_p))
     outs = []
+    raw = cons.raw          # one copy (cons.raw copies the whole buffer on every access)
     for i in range(n):
-        outs.append(cons.raw[off[i]:off[i] + res[i].cons_len].decode() if res[i].status == 0 else "")
+        outs.append(raw[off[i]:off[i] + res[i].cons_len].decode() if res[i].status == 0 else "")
     return res, outs
