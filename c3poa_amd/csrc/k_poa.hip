@@ -85,6 +85,7 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 #define PR 8        // ring rows
 #define PQW 112     // packed query words kept in LDS (1792 bases); longer subreads read the packed read
 struct PoaLds { int H[PR][PW], E1[PR][PW], E2[PR][PW]; int beg[PR], end[PR], rl[PR], rr[PR], inl[PR]; unsigned qpk[PQW]; };
+__shared__ PoaLds L;     // file scope: accesses stay in the LDS address space (ds_*, lgkmcnt only)
 
 // scores are carried as score*512 (+ a 9-bit tag while candidates compete): one v_max per candidate
 // implements "highest score, first candidate in order".  Unreachable cells use -(2^20) score units.
@@ -113,7 +114,7 @@ __device__ void poa_build_desc(Ctx& c, int lane) {
 
 // banded global alignment of subread [qb, qb+Q) against the graph; ops are written BACKWARDS
 // into opn/opq, returns their count (or <0 on failure)
-__device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, long long* cells, PoaLds& L PHA) {
+__device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, long long* cells PHA) {
   const int K = c.K, n = c.n;
   const int mt9 = S9(P.poa_match), mm9 = S9(-P.poa_mismatch);
   const int e1_9 = S9(P.e1), e2_9 = S9(P.e2), o1_9 = S9(P.o1), o2_9 = S9(P.o2), oe1_9 = S9(P.o1 + P.e1), oe2_9 = S9(P.o2 + P.e2);
@@ -158,6 +159,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   WSYNC();
   PH_MARK(0)
   int ncell = 0;
+  int pv_idx = -9, pv_beg = 0, pv_end = -1, pv_left = 0, pv_right = 0, pv_inl = 0;   // previous row, kept in scalars
   for (int ib = 0; ib < n; ib += 64) {
   uint4 dA = c.descA[min(ib + lane, n - 1)], dB = c.descB[min(ib + lane, n - 1)];
   asm volatile("" : "+v"(dA.x), "+v"(dA.y), "+v"(dA.z), "+v"(dB.x), "+v"(dB.y), "+v"(dB.z), "+v"(dB.w));   // wait here, not in the row loop
@@ -170,9 +172,67 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     const int fl = __builtin_amdgcn_readlane(dA.z, li);
     const int vb = fl & 0xff, nin = (fl >> 8) & 0xff;
     const bool far = (fl >> 16) & 1, ovf = (fl >> 17) & 1;
-    int pidx[4];
-    pidx[0] = __builtin_amdgcn_readlane(dB.x, li); pidx[1] = __builtin_amdgcn_readlane(dB.y, li);
-    pidx[2] = __builtin_amdgcn_readlane(dB.z, li); pidx[3] = __builtin_amdgcn_readlane(dB.w, li);
+    const int p0 = __builtin_amdgcn_readlane(dB.x, li), p1 = __builtin_amdgcn_readlane(dB.y, li);
+    const int p2 = __builtin_amdgcn_readlane(dB.z, li), p3 = __builtin_amdgcn_readlane(dB.w, li);
+#define PRED_IDX(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index[c.in_from[v * K + (k)]])
+    // ---- FAST ROW: one predecessor = the previous row, still in the LDS ring, band fits one 64-lane chunk.
+    // Same arithmetic as the general path below, minus the predecessor loop, the tag bookkeeping
+    // (ordinal 0 everywhere) and every LDS metadata read (the previous row's band is in scalars).
+    if (nin == 1 && p0 == idx - 1 && pv_idx == idx - 1 && pv_inl && v != SRC) {
+      const int qr = Q - remv;
+      const int b = pv_beg, e = pv_end;
+      const int mplv = e >= b ? pv_left + 1 : INT32_MAX / 2, mprv = e >= b ? pv_right + 1 : 0;
+      int beg = max(max(0, min(mplv, qr) - w), b);
+      int end = min(min(Q, max(mprv, qr) + w), e + 1);
+      if (end < beg) end = beg - 1;
+      const int wd = end - beg + 1;
+      if (wd > 0 && wd <= 64) {
+        if (ncell + wd > c.cells_cap) return -4;
+        const int slot = idx & (PR - 1), sl = (idx - 1) & (PR - 1);
+        const int ro = ncell;
+        ncell += wd;
+        const int j = beg + lane, o = j - b;
+        const bool act = j <= end;
+        int hd = NEGS, hp = NEGS, e1p = NEGS, e2p = NEGS;
+        if (act && o >= 1) hd = L.H[sl][o - 1];
+        if (act && j <= e) { hp = L.H[sl][o]; e1p = L.E1[sl][o]; e2p = L.E2[sl][o]; }
+        int qc = 7;
+        if (act && j > 0) qc = qlds ? (int)((L.qpk[(j - 1) >> 4] >> (((j - 1) & 15) * 2)) & 3) : c3_code_at(c.pk, qb + j - 1);
+        const int M9 = (j > 0) ? hd + ((vb == qc) ? mt9 : mm9) : NEGS;
+        const int a1 = hp - oe1_9, x1 = e1p - e1_9, a2 = hp - oe2_9, x2 = e2p - e2_9;
+        const int E1v = max(a1, x1), E2v = max(a2, x2);
+        const int k2 = max(max(M9 + 2, E1v + 1), E2v);
+        const int ht9 = k2 & ~511;
+        unsigned d = ((unsigned)(x1 > a1) << 8) | ((unsigned)(x2 > a2) << 17) | ((unsigned)(2 - (k2 & 3)) << 26);
+        const int htm = act ? ht9 : NEG2S;
+        const int s1 = wave_scan_max(htm + e1_9 * j), s2 = wave_scan_max(htm + e2_9 * j);
+        const int px1 = wave_shr1(s1, NEG2S), px2 = wave_shr1(s2, NEG2S);
+        const int htl = wave_shr1(htm, NEGS);
+        int f1 = NEG2S, f2 = NEG2S; unsigned f1x = 0, f2x = 0;
+        if (lane != 0) {
+          f1 = px1 - o1_9 - e1_9 * j; f2 = px2 - o2_9 - e2_9 * j;
+          f1x = f1 != htl - oe1_9; f2x = f2 != htl - oe2_9;
+        }
+        const int k3 = max(max(ht9 + 2, f1 + 1), f2);
+        const int h9 = k3 & ~511;
+        d |= ((unsigned)(2 - (k3 & 3)) << 28) | (f1x << 30) | (f2x << 31);
+        if (act) {
+          c.D[ro + lane] = d;
+          L.H[slot][lane] = h9; L.E1[slot][lane] = E1v; L.E2[slot][lane] = E2v;
+          if (far) { c.H[ro + lane] = h9; c.E1[ro + lane] = E1v; c.E2[ro + lane] = E2v; }
+        }
+        const int hb = act ? h9 : INT32_MIN;
+        const int rb = wave_max(hb);
+        const int left = wave_min(hb == rb ? j : INT32_MAX / 2), right = wave_max(hb == rb ? j : -1);
+        if (lane == 0) {
+          L.beg[slot] = beg; L.end[slot] = end; L.rl[slot] = left; L.rr[slot] = right; L.inl[slot] = 1;
+          c.rbeg[idx] = beg; c.rend[idx] = end; c.roff[idx] = ro;
+          if (far) { c.mpl[idx] = left; c.mpr[idx] = right; }
+        }
+        pv_idx = idx; pv_beg = beg; pv_end = end; pv_left = left; pv_right = right; pv_inl = 1;
+        continue;
+      }
+    }
     // ---- adaptive band: gather the hints of the predecessors (abPOA scatters them to the successors)
     int beg, end;
     const int qr = Q - remv;
@@ -180,7 +240,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     else {
       int mplv = INT32_MAX / 2, mprv = 0, minb = INT32_MAX, maxe = INT32_MIN;
       for (int k = 0; k < nin; ++k) {
-        const int pi = (!ovf || k < 4) ? pidx[k < 4 ? k : 0] : c.index[c.in_from[v * K + k]];
+        const int pi = PRED_IDX(k);
         int b, e, l, r;
         if (idx - pi < PR) { const int sl = pi & (PR - 1); b = L.beg[sl]; e = L.end[sl]; l = L.rl[sl]; r = L.rr[sl]; }
         else { b = c.rbeg[pi]; e = c.rend[pi]; l = c.mpl[pi]; r = c.mpr[pi]; }
@@ -209,7 +269,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       else {
         int kM = INT32_MIN, kE1 = INT32_MIN, kE2 = INT32_MIN;
         for (int k = 0; k < nin; ++k) {
-          const int pi = (!ovf || k < 4) ? pidx[k < 4 ? k : 0] : c.index[c.in_from[v * K + k]];
+          const int pi = PRED_IDX(k);
           int hd = NEGS, hp = NEGS, e1p = NEGS, e2p = NEGS;
           const int sl = pi & (PR - 1);
           if (idx - pi < PR && L.inl[sl]) {
@@ -272,6 +332,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       c.rbeg[idx] = beg; c.rend[idx] = end; c.roff[idx] = ro;
       if (far) { c.mpl[idx] = left; c.mpr[idx] = right; }
     }
+    pv_idx = idx; pv_beg = beg; pv_end = end; pv_left = left; pv_right = right; pv_inl = inl;
   }
   }
   WSYNC();
@@ -421,7 +482,6 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
   c.H = a.H + (size_t)slot * a.cells_cap; c.E1 = a.E1 + (size_t)slot * a.cells_cap; c.E2 = a.E2 + (size_t)slot * a.cells_cap;
   c.D = a.D + (size_t)slot * a.cells_cap; c.rows2 = a.rows2 + slot * 4 * N;
   c.descA = a.desc + (size_t)slot * 2 * N; c.descB = c.descA + N; c.jump = a.jump + (size_t)slot * C3_JUMP_LEVELS * N;
-  __shared__ PoaLds L;
   c.K = a.K; c.Ncap = a.Ncap; c.cells_cap = a.cells_cap;
   PH_DECL
 
@@ -455,7 +515,7 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
       int poff = 0;
       for (int s = 0; s < ns && !fail; ++s) {
         const int qb = info->sub_beg[s], Q = info->sub_end[s] - qb;
-        if (s > 0) { if (poa_align(c, a.p, qb, Q, lane, &cells, L PHP) < 0) { fail = 1; break; } }
+        if (s > 0) { if (poa_align(c, a.p, qb, Q, lane, &cells PHP) < 0) { fail = 1; break; } }
         if (poa_fuse(c, s == 0, qb, Q, c.path + poff, lane PHP) < 0) { fail = 1; break; }
         poff += Q;
       }
