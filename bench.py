@@ -132,6 +132,15 @@ def main():
         alg_bytes = float(np.sum((lens + 3) // 4 + lens) + np.sum(res["cons_len"][ok]) + 4 * np.sum(res["n_peaks"]))
         achieved = alg_bytes / (avg[dom] * 1e-3) / 1e9
         cells = tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish"]
+        # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process;
+        # the number comes from the committed rocprofv3 pass of THIS command when the workload matches
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_cfg2_100k.json")))
+            if a.cfg == "cfg2" and a.reads == 100000:
+                traffic = pm["kernels"][dom.replace("ms_", "k_")]["hbm_bytes_per_launch"]
+        except Exception:
+            traffic = None
         out = {
             "metric": "R2C2 reads->consensus/sec", "value": round(value, 1), "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -146,7 +155,8 @@ def main():
                        "pcie_inclusive_reads_per_s": round(a.reads * world / (dt / a.steps + t_up), 1)},
             "roofline": {"bound": "hbm", "kernel": dom.replace("ms_", "k_"), "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": None, "alg_bytes_per_launch": alg_bytes,
+                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic_cfg2_100k.json (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024)" if traffic else None,
+                         "alg_bytes_per_launch": alg_bytes,
                          "kernel_ms": {k: round(v, 3) for k, v in avg.items()},
                          "gcups": round(cells / (sum(avg.values()) * 1e-3) / 1e9, 2)},
             "gen_s": round(t_gen, 1),

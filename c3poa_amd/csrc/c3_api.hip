@@ -500,6 +500,28 @@ extern "C" int c3_batch_results(c3_handle* h, c3_read_result* res, char* cons, i
   return C3_E_OK;
 }
 
+// PMC calibration: read `bytes` with one dword per lane, write `bytes` with one dword per
+// lane -- the access width the DP kernels use -- so FETCH_SIZE / WRITE_SIZE can be checked against a
+// known byte count on this device before they are trusted for k_window / k_poa.
+__global__ void k_calib_rw(const uint32_t* in, uint32_t* out, size_t nwords) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+  uint32_t acc = 0;
+  for (size_t k = i; k < nwords; k += st) acc += in[k];
+  for (size_t k = i; k < nwords; k += st) out[k] = acc + (uint32_t)k;
+}
+extern "C" int c3_debug_calibrate(c3_handle* h, long long bytes) {
+  if (!h || bytes < 4096) return C3_E_ARG;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  uint32_t *a = nullptr, *b = nullptr;
+  HIPCHK(hipMalloc(&a, (size_t)bytes)); HIPCHK(hipMalloc(&b, (size_t)bytes));
+  HIPCHK(hipMemsetAsync(a, 1, (size_t)bytes, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  hipLaunchKernelGGL(k_calib_rw, dim3(h->n_cus * 8), dim3(256), 0, h->stream, a, b, (size_t)bytes / 4);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipFree(a)); HIPCHK(hipFree(b));
+  return C3_E_OK;
+}
+
 // diagnostic builds (-DC3_PHASE_PROF) only: per-phase cycle sums of k_poa (which=0) / k_window (which=1)
 extern "C" int c3_debug_phases(c3_handle* h, int which, unsigned long long* out) {
   if (!h || !out) return C3_E_ARG;
