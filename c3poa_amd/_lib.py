@@ -18,7 +18,7 @@ ST_OK, ST_NOT_ASSIGNED, ST_NO_PEAKS, ST_NO_CONSENSUS, ST_TOO_SHORT, ST_LIMIT = r
 EXPORTS = ["c3_default_config", "c3_version", "c3_create", "c3_destroy", "c3_last_error", "c3_set_splints",
            "c3_batch_upload", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_timing",
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
-           "c3_call_peaks", "c3_poa_msa", "c3_determine_consensus"]
+           "c3_call_peaks", "c3_poa_msa", "c3_determine_consensus", "c3_zero_repeats"]
 
 
 class Config(C.Structure):
@@ -27,7 +27,7 @@ class Config(C.Structure):
                  ("poa_match", C.c_int), ("poa_mismatch", C.c_int), ("poa_o1", C.c_int), ("poa_e1", C.c_int),
                  ("poa_o2", C.c_int), ("poa_e2", C.c_int), ("poa_band_b", C.c_int), ("poa_band_f", C.c_double),
                  ("pol_match", C.c_int), ("pol_mismatch", C.c_int), ("pol_gap", C.c_int), ("pol_window", C.c_int),
-                 ("pol_q", C.c_int), ("dang_band", C.c_int), ("slots_poa", C.c_int), ("slots_win", C.c_int)])
+                 ("pol_q", C.c_int), ("dang_band", C.c_int), ("slots_poa", C.c_int), ("slots_win", C.c_int), ("zero", C.c_int)])
 
 
 class ReadResult(C.Structure):
@@ -83,6 +83,7 @@ def load():
     lib.c3_fetch_msa2.argtypes = [vp, C.c_int, vp, vp, C.c_int]
     lib.c3_call_peaks.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
     lib.c3_poa_msa.argtypes = [vp, C.c_int, C.POINTER(cp), ip, vp, C.c_int, ip, vp, C.c_int64, ip]
+    lib.c3_zero_repeats.argtypes = [vp, cp, cp, C.c_int, cp, cp, C.c_int, C.c_int, vp, C.c_int, ip]
     lib.c3_determine_consensus.argtypes = [vp, C.c_int, C.POINTER(cp), C.POINTER(cp), ip, cp, cp, C.c_int,
                                            cp, cp, C.c_int, vp, C.c_int, ip, vp, C.c_int, ip]
     _lib = lib
@@ -239,6 +240,14 @@ class Handle:
         c = [cons.raw[:cl.value].decode()] if out_cons and cl.value else []
         m = [msa.raw[i * ml.value:(i + 1) * ml.value].decode() for i in range(n)] if out_msa and ml.value else []
         return c, m
+
+    def zero_repeats(self, d0, q0, d1, q1, min_len=0):
+        b0, b1 = _b(d0), _b(d1)
+        cap = len(b0) + len(b1) + 16
+        out = C.create_string_buffer(cap)
+        ol = C.c_int(0)
+        self._chk(self.lib.c3_zero_repeats(self.h, b0, _b(q0), len(b0), b1, _b(q1), len(b1), int(min_len), out, cap, C.byref(ol)))
+        return out.raw[:ol.value].decode()
 
     def determine_consensus(self, subs, quals, front=None, tail=None, return_draft=False):
         n = len(subs)

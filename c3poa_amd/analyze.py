@@ -15,10 +15,10 @@ from .records import consensus_record, subread_records, zero_repeat_records
 _HANDLES = {}
 
 
-def get_handle(device=0, mdistcutoff=500):
-    key = (device, mdistcutoff)
+def get_handle(device=0, mdistcutoff=500, zero=True):
+    key = (device, mdistcutoff, bool(zero))
     if key not in _HANDLES:
-        _HANDLES[key] = _lib.Handle(device=device, mdistcutoff=mdistcutoff)
+        _HANDLES[key] = _lib.Handle(device=device, mdistcutoff=mdistcutoff, zero=1 if zero else 0)
     return _HANDLES[key]
 
 
@@ -41,7 +41,7 @@ def analyze_reads(args, reads, splint_dict, adapter_dict, adapter_set, iteration
     if not reads:
         return
     splint_names = sorted(splint_dict)
-    h = get_handle(device, args.mdistcutoff)
+    h = get_handle(device, args.mdistcutoff, getattr(args, "zero", True))
     h.set_splints([splint_dict[n][0] for n in splint_names])
     res, cons = run_batch(h, reads, splint_names, splint_dict, adapter_dict)
     write_group(args, reads, res, cons, adapter_dict, iteration)
@@ -76,6 +76,8 @@ def write_group(args, reads, res, cons, adapter_dict, iteration):
             # determine_consensus.py:14-18: zero-repeat pieces are written before the rescue is tried
             if getattr(args, "zero", True) and len(dang) == 2:
                 fh(splint, "subreads.fastq").write(zero_repeat_records(name, dang, dqual))
+                if r["status"] == _lib.ST_OK and cons[i]:      # rescue succeeded: repeats == 0 (determine_consensus.py:18)
+                    fh(splint, "R2C2_Consensus.fasta").write(consensus_record(name, qual, len(seq), 0, cons[i]))
             continue
         if r["status"] == _lib.ST_LIMIT:
             continue

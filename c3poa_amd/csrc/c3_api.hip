@@ -15,6 +15,8 @@ extern "C" void c3k_launch_poa(const PoaArgs*, int, hipStream_t);
 extern "C" void c3k_launch_prep(const PrepArgs*, int, hipStream_t);
 extern "C" void c3k_launch_window(const WinArgs*, int, hipStream_t);
 extern "C" void c3k_launch_stitch(const StitchArgs*, int, hipStream_t);
+extern "C" void c3k_launch_zero(const ZeroArgs*, int, hipStream_t);
+extern "C" void c3k_launch_zero_finish(const ZeroArgs*, int, hipStream_t);
 
 // ---- small kernels ----------------------------------------------------------------------
 __global__ void k_pack(const uint8_t* ascii, const int64_t* off, const int64_t* woff, int n, uint32_t* pk) {
@@ -43,7 +45,7 @@ __global__ void k_init_info(C3Info* info, int n) {
   if (i < n) { C3Info* p = &info[i]; p->status = C3_ST_OK; p->n_peaks = 0; p->n_sub = 0; p->has_front = p->has_tail = 0;
                p->front_end = p->tail_beg = 0; p->cons_len = 0; p->draft_len = 0; p->n_win = 0; }
 }
-struct Summary { int status, n_sub, max_sub, sum_sub, max_dang; };
+struct Summary { int status, n_sub, max_sub, sum_sub, max_dang, front, tail; };
 __global__ void k_summary(const C3Info* info, const int64_t* off, int n, Summary* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -51,10 +53,13 @@ __global__ void k_summary(const C3Info* info, const int64_t* off, int n, Summary
   Summary s; s.status = p->status; s.n_sub = p->n_sub; s.max_sub = 0; s.sum_sub = 0; s.max_dang = 0;
   for (int k = 0; k < p->n_sub; ++k) { int l = p->sub_end[k] - p->sub_beg[k]; s.sum_sub += l; if (l > s.max_sub) s.max_sub = l; }
   int L = (int)(off[i + 1] - off[i]);
+  s.front = p->has_front ? p->front_end : 0; s.tail = p->has_tail ? L - p->tail_beg : 0;
   if (p->has_front) s.max_dang = p->front_end;
   if (p->has_tail && L - p->tail_beg > s.max_dang) s.max_dang = L - p->tail_beg;
   out[i] = s;
 }
+
+#define DBG(...) do { if (getenv("C3_DEBUG")) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
 
 // ---- handle -----------------------------------------------------------------------------
 struct DBuf {
@@ -83,7 +88,8 @@ struct c3_handle {
   DBuf d_raw, d_nraw, d_sum, d_work, d_bufA, d_bufB, d_cand, d_cst, d_msa, d_msa_off, d_msa_len;
   DBuf s_poa_i, s_poa_nk, s_poa_cells, s_poa_b, s_poa_sc, s_poa_desc, s_poa_jump;      // POA scratch
   DBuf s_eH, s_eD, s_lw, d_wrec, d_wlay, d_wbase, d_wout;       // prep / windows
-  DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc;  // window scratch
+  DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc;
+  DBuf s_zero_d, d_zinfo, d_zflag, d_zwork; std::vector<int> zwork;  // window scratch
   std::vector<Summary> sum; std::vector<int> work;
   int peaks_grid = 0; bool debug_msa = false; bool injected = false;
   int n_windows = 0;
@@ -108,7 +114,7 @@ extern "C" void c3_default_config(c3_config* c) {
   c->poa_match = 5; c->poa_mismatch = 4; c->poa_o1 = 4; c->poa_e1 = 2; c->poa_o2 = 24; c->poa_e2 = 1;
   c->poa_band_b = 10; c->poa_band_f = 0.01;
   c->pol_match = 3; c->pol_mismatch = -5; c->pol_gap = -4; c->pol_window = 500; c->pol_q = 5; c->dang_band = 128;
-  c->slots_poa = 0; c->slots_win = 0;
+  c->slots_poa = 0; c->slots_win = 0; c->zero = 1;
 }
 extern "C" const char* c3_version(void) { return "c3poa_amd 0.1 (gfx950)"; }
 
@@ -146,7 +152,7 @@ extern "C" void c3_destroy(c3_handle* h) {
                  &h->d_info, &h->d_track, &h->d_draft, &h->d_tpos, &h->d_cons, &h->d_counter, &h->d_raw, &h->d_nraw, &h->d_sum,
                  &h->d_work, &h->d_bufA, &h->d_bufB, &h->d_cand, &h->d_cst, &h->d_msa, &h->d_msa_off, &h->d_msa_len,
                  &h->s_poa_i, &h->s_poa_nk, &h->s_poa_cells, &h->s_poa_b, &h->s_poa_sc, &h->s_poa_desc, &h->s_poa_jump, &h->s_eH, &h->s_eD, &h->s_lw, &h->d_wrec,
-                 &h->d_wlay, &h->d_wbase, &h->d_wout, &h->s_win_i, &h->s_win_nk, &h->s_win_h, &h->s_win_d, &h->s_win_b, &h->s_win_sc, &h->s_win_desc};
+                 &h->d_wlay, &h->d_wbase, &h->d_wout, &h->s_win_i, &h->s_win_nk, &h->s_win_h, &h->s_win_d, &h->s_win_b, &h->s_win_sc, &h->s_win_desc, &h->s_zero_d, &h->d_zinfo, &h->d_zflag, &h->d_zwork};
   for (DBuf* b : all) b->release();
   for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(h->ev[i]);
   (void)hipStreamDestroy(h->stream);
@@ -194,6 +200,7 @@ static C3Params dev_params(const c3_config& c) {
   p.band_b = c.poa_band_b; p.band_f = c.poa_band_f;
   p.pol_match = c.pol_match; p.pol_mismatch = c.pol_mismatch; p.pol_gap = c.pol_gap; p.pol_window = c.pol_window; p.pol_q = c.pol_q;
   p.dang_band = c.dang_band;
+  p.zero = c.zero; p.zr_match = 2; p.zr_mismatch = 4; p.zr_gapo = 4; p.zr_gape = 2; p.zr_min_score = 80; p.zr_max_cells = 16 << 20;
   return p;
 }
 
@@ -283,13 +290,60 @@ static int run_peaks(c3_handle* h) {
 }
 
 // summary of the split -> work list + capacities
-static int fetch_summary(c3_handle* h) {
+static int copy_summary(c3_handle* h) {
   const int n = h->n;
   HIPCHK(h->d_sum.ensure(sizeof(Summary) * (size_t)n));
   hipLaunchKernelGGL(k_summary, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), h->d_off.as<int64_t>(), n, h->d_sum.as<Summary>());
   h->sum.resize(n);
   HIPCHK(hipMemcpyAsync(h->sum.data(), h->d_sum.p, sizeof(Summary) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  return 0;
+}
+
+static void fill_zero_args(c3_handle* h, ZeroArgs& z, int nz) {
+  memset(&z, 0, sizeof(z));
+  z.b = dev_batch(h); z.info = h->d_info.as<C3Info>(); z.p = dev_params(h->cfg); z.counter = h->d_counter.as<int>();
+  z.work = h->d_zwork.as<int>(); z.n_work = nz;
+  z.D = h->s_zero_d.as<uint8_t>(); z.zinfo = h->d_zinfo.as<int4>(); z.zflag = h->d_zflag.as<uint8_t>();
+  z.draft = h->d_draft.as<uint8_t>(); z.cons = h->d_cons.as<char>();
+}
+
+// zero-repeat rescue, first half (bin/determine_consensus.py:14-18,106-128): reads whose split kept no
+// subread but has both dangling pieces get their overlap located and become 2-subread POA jobs
+static int run_zero(c3_handle* h) {
+  h->zwork.clear();
+  HIPCHK(h->d_zflag.ensure((size_t)h->n + 16));
+  HIPCHK(hipMemsetAsync(h->d_zflag.p, 0, (size_t)h->n, h->stream));
+  if (!h->cfg.zero || h->injected) return 0;
+  long long dmax = 0;
+  for (int i = 0; i < h->n; ++i) {
+    const Summary& s = h->sum[i];
+    if (s.status == C3_ST_NO_CONSENSUS && s.n_sub == 0 && s.front > 0 && s.tail > 0 && s.front <= 4096 &&
+        (long long)s.front * s.tail <= (16 << 20)) {
+      h->zwork.push_back(i);
+      dmax = std::max(dmax, (long long)(s.front + 1) * (s.tail + 1));
+    }
+  }
+  const int nz = (int)h->zwork.size();
+  if (nz == 0) return 0;
+  const int grid = std::min(nz, 512);
+  HIPCHK(h->d_zwork.ensure(sizeof(int) * (size_t)nz)); HIPCHK(h->d_zinfo.ensure(sizeof(int4) * (size_t)h->n));
+  HIPCHK(h->s_zero_d.ensure((size_t)dmax * grid + 64));
+  HIPCHK(hipMemcpyAsync(h->d_zwork.p, h->zwork.data(), sizeof(int) * (size_t)nz, hipMemcpyHostToDevice, h->stream));
+  ZeroArgs z; fill_zero_args(h, z, nz); z.dcap = dmax;
+  DBG("zero: nz=%d grid=%d dmax=%lld\n", nz, grid, dmax);
+  c3k_launch_zero(&z, grid, h->stream);
+  HIPCHK(hipGetLastError());
+  { int r_ = copy_summary(h); DBG("zero done\n"); return r_; }              // the rescued reads now carry 2 pseudo-subreads
+}
+
+static int fetch_summary(c3_handle* h) {
+  int rc = copy_summary(h);
+  DBG("summary copied\n");
+  if (rc) return rc;
+  HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 64, h->stream));
+  if ((rc = run_zero(h))) return rc;
+  const int n = h->n;
   h->work.clear();
   for (int i = 0; i < n; ++i) if (h->sum[i].status == C3_ST_OK && h->sum[i].n_sub >= 1) h->work.push_back(i);
   // longest first: better tail behaviour of the dynamic work queues
@@ -303,6 +357,7 @@ static int fetch_summary(c3_handle* h) {
 static int run_poa(c3_handle* h) {
   const int nw = (int)h->work.size();
   HIPCHK(h->d_draft.ensure((size_t)h->total + 64)); HIPCHK(h->d_tpos.ensure(sizeof(int32_t) * (size_t)h->total + 64));
+  HIPCHK(h->d_cons.ensure((size_t)h->total + 64));
   HIPCHK(hipMemsetAsync(h->d_tpos.p, 0xff, sizeof(int32_t) * (size_t)h->total, h->stream));
   if (nw == 0) return 0;
   int max_sum = 0, max_ns = 0, max_q = 0;
@@ -344,16 +399,23 @@ static int run_poa(c3_handle* h) {
     HIPCHK(hipStreamSynchronize(h->stream));
     a.msa_dbg = h->d_msa.as<uint8_t>(); a.msa_off = h->d_msa_off.as<int64_t>(); a.msa_len = h->d_msa_len.as<int>();
   }
-  HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 256, h->stream));
+  HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));                       // work queue only: [2..3] already holds the zero-repeat cells
+  HIPCHK(hipMemsetAsync(h->d_counter.as<char>() + 64, 0, 192, h->stream));
   a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
   c3k_launch_poa(&a, slots, h->stream);
   HIPCHK(hipGetLastError());
+  if (!h->zwork.empty()) {             // zero-repeat rescue, second half: stitch left + overlap consensus + right
+    ZeroArgs z; fill_zero_args(h, z, (int)h->zwork.size());
+    c3k_launch_zero_finish(&z, std::min((int)h->zwork.size(), 512), h->stream);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipMemcpyAsync(h->phase_poa, h->d_counter.as<char>() + 64, 96, hipMemcpyDeviceToHost, h->stream));
   return 0;
 }
 
 static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st) {
   const int nw = (int)h->work.size();
+  DBG("polish: nw=%d\n", nw);
   HIPCHK(h->d_cons.ensure((size_t)h->total + 64));
   if (nw == 0) return 0;
   const int WL = h->cfg.pol_window;
@@ -380,6 +442,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   p.n_windows = h->d_counter.as<int>() + 8; p.wcap = (int)std::min<long long>(wcap, 0x7fffffff);
   HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 64, h->stream));
   HIPCHK(hipEventRecord(h->ev[5], h->stream));
+  DBG("prep: slots=%d ecap=%lld NL=%d NW=%d wcap=%lld\n", slots_p, (long long)ecap, NLcap, NWcap, (long long)wcap);
   c3k_launch_prep(&p, slots_p, h->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev[6], h->stream));
@@ -389,6 +452,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   h->tm.cells_polish += *(long long*)(cnt + 2);
   const int n_win = cnt[8];
   h->n_windows = n_win;
+  DBG("prep done: n_win=%d\n", n_win);
   const int wout_cap = 3 * WL + 64;
   HIPCHK(hipEventRecord(h->ev[7], h->stream));
   if (n_win > 0) {
@@ -421,7 +485,8 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   StitchArgs s; memset(&s, 0, sizeof(s));
   s.b = dev_batch(h); s.info = h->d_info.as<C3Info>(); s.work = h->d_work.as<int>(); s.n_work = nw;
   s.wrec = h->d_wrec.as<WinRec>(); s.win_base = h->d_wbase.as<int>(); s.wout = h->d_wout.as<uint8_t>(); s.wout_cap = wout_cap;
-  s.cons = h->d_cons.as<char>();
+  s.cons = h->d_cons.as<char>(); s.zflag = h->d_zflag.as<uint8_t>();
+  DBG("stitch\n");
   c3k_launch_stitch(&s, std::min(nw, h->n_cus * 16), h->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev[9], h->stream));
@@ -670,6 +735,35 @@ extern "C" int c3_poa_msa(c3_handle* h, int n, const char* const* seqs, const in
   if (rc == 0 && msa) { int ml = 0; rc = fetch_msa_rows(h, 0, n, msa, msa_cap, &ml); if (rc == 0 && msa_len) *msa_len = ml; }
   h->debug_msa = dbg0;
   return rc;
+}
+
+extern "C" int c3_zero_repeats(c3_handle* h, const char* d0, const char* q0, int n0, const char* d1, const char* q1, int n1,
+                               int min_len, char* out, int cap, int* out_len) {
+  if (!h || !d0 || !d1 || n0 <= 0 || n1 <= 0 || !out || !out_len) return C3_E_ARG;
+  *out_len = 0;
+  if (h->n_spl <= 0) { const char sp[] = "ACGT"; int64_t o[2] = {0, 4}; int rc = c3_set_splints(h, 1, sp, o); if (rc) return rc; }
+  std::string seq(d0, n0), ql;
+  seq.append(d1, n1);
+  if (q0) ql.append(q0, n0); else ql.append(n0, 'I');
+  if (q1) ql.append(q1, n1); else ql.append(n1, 'I');
+  int64_t off[2] = {0, (int64_t)seq.size()};
+  int16_t sid = 0; char st = '+';
+  int rc = c3_batch_upload(h, 1, seq.data(), ql.data(), off, &sid, &st);
+  if (rc) return rc;
+  c3_read_result r; memset(&r, 0, sizeof(r));
+  r.status = C3_ST_NO_CONSENSUS; r.n_peaks = 1; r.has_front = 1; r.has_tail = 1; r.front_end = n0; r.tail_beg = n0;
+  HIPCHK(hipMemcpy(h->d_info.p, &r, sizeof(r), hipMemcpyHostToDevice));
+  const int md0 = h->cfg.mdistcutoff, z0 = h->cfg.zero;
+  h->cfg.mdistcutoff = min_len; h->cfg.zero = 1;
+  rc = c3_batch_run(h, C3_STAGE_POA | C3_STAGE_POLISH);
+  h->cfg.mdistcutoff = md0; h->cfg.zero = z0;
+  if (rc) return rc;
+  std::vector<c3_read_result> res(1);
+  int64_t co[2];
+  rc = c3_batch_results(h, res.data(), out, cap, co);
+  if (rc) return rc;
+  *out_len = (res[0].status == C3_ST_OK) ? res[0].cons_len : 0;
+  return C3_E_OK;
 }
 
 extern "C" int c3_determine_consensus(c3_handle* h, int n, const char* const* subs, const char* const* quals,

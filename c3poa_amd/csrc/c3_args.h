@@ -34,4 +34,11 @@ struct WinArgs {
 };
 struct StitchArgs {
   C3Batch b; C3Info* info; const int* work; int n_work; const WinRec* wrec; const int* win_base; const uint8_t* wout; int wout_cap; char* cons;
+  const uint8_t* zflag;
+};
+struct ZeroArgs {
+  C3Batch b; C3Info* info; C3Params p; int* counter; const int* work; int n_work;
+  uint8_t* D; long long dcap;           // [grid][dcap] direction bytes
+  int4* zinfo; uint8_t* zflag;          // per read: r_st, r_en, q_st, q_en; rescue in progress / done
+  const uint8_t* draft; char* cons;
 };

@@ -30,6 +30,7 @@ struct C3Params {
   int poa_match, poa_mismatch, o1, e1, o2, e2, band_b;
   double band_f;
   int pol_match, pol_mismatch, pol_gap, pol_window, pol_q, dang_band;
+  int zero, zr_match, zr_mismatch, zr_gapo, zr_gape, zr_min_score, zr_max_cells;
 };
 
 __device__ __forceinline__ int c3_code_at(const uint32_t* pk, int64_t i) {

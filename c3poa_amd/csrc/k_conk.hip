@@ -51,7 +51,9 @@ __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
     const int64_t off = a.b.off[rid];
     const int L = (int)(a.b.off[rid + 1] - off);
     const int st = a.b.strand[rid];
-    if (st != '+' && st != '-') { if (lane == 0) a.info[rid].status = C3_ST_NOT_ASSIGNED; continue; }
+    // (stored by every lane: a divergent `if (lane == 0)` right before `continue` can livelock the
+    // persistent loop -- see prep_one in k_polish.hip)
+    if (st != '+' && st != '-') { a.info[rid].status = C3_ST_NOT_ASSIGNED; continue; }
     const int sid = a.b.splint_id[rid];
     const int S = a.sp_len[sid];
     const uint8_t* sp = a.sp_codes + ((size_t)sid * 2 + (st == '-')) * C3_SPLINT_MAX;

@@ -129,22 +129,14 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
   return tot;
 }
 
-__global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
-  const int lane = wave_lane();
-  const int slot = blockIdx.x;
-  __shared__ uint8_t ldraft[EXT_DCAP];
-  uint8_t* eD = a.eD + (size_t)slot * a.ecap;
-  int* lwf = a.lw_first + (size_t)slot * a.NLcap * a.NWcap;
-  int* lwl = a.lw_last + (size_t)slot * a.NLcap * a.NWcap;
-  const int WL = a.p.pol_window;
-  for (;;) {
-    int wi = 0;
-    if (lane == 0) wi = atomicAdd(a.counter, 1);
-    wi = wave_first(wi);
-    if (wi >= a.n_work) break;
+// one read of k_prep.  Kept as a function with early returns: a `continue` straight after the work-queue
+// pop made hipcc re-enter the persistent loop with a partial EXEC mask (lane 0 missing), so the
+// readfirstlane of the queue index never advanced -- the kernel hung on the first skipped read.
+__device__ __forceinline__ void prep_one(const PrepArgs& a, int wi, int lane, uint8_t* ldraft, uint8_t* eD, int* lwf, int* lwl, int WL) {
     const int rid = a.work[wi];
     C3Info* info = &a.info[rid];
-    if (info->status != C3_ST_OK || info->draft_len <= 0) { if (lane == 0) { info->n_win = 0; a.win_base[rid] = 0; } continue; }
+    // skip paths store from every lane (same value): no divergent branch right before the early return
+    if (info->status != C3_ST_OK || info->draft_len <= 0) { info->n_win = 0; a.win_base[rid] = 0; return; }
     const int64_t off = a.b.off[rid];
     const int L = (int)(a.b.off[rid + 1] - off);
     const uint32_t* pk = a.b.pk + a.b.woff[rid];
@@ -161,7 +153,7 @@ __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
     // ---- layers: kept subreads, front, tail
     const int nl = ns + hf + ht;
     const int nwin = (C + WL - 1) / WL;
-    if (nwin > a.NWcap || nl > a.NLcap) { if (lane == 0) { info->status = C3_ST_LIMIT; info->n_win = 0; a.win_base[rid] = 0; } continue; }
+    if (nwin > a.NWcap || nl > a.NLcap) { info->status = C3_ST_LIMIT; info->n_win = 0; a.win_base[rid] = 0; return; }
     long tl = 0;
     for (int i = 0; i < nl; ++i) {
       int lb, le;
@@ -174,7 +166,7 @@ __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
     int wbase = 0;
     if (lane == 0) wbase = atomicAdd(a.n_windows, nwin);
     wbase = wave_first(wbase);
-    if (wbase + nwin > a.wcap) { if (lane == 0) { info->status = C3_ST_LIMIT; info->n_win = 0; a.win_base[rid] = 0; } continue; }
+    if (wbase + nwin > a.wcap) { info->status = C3_ST_LIMIT; info->n_win = 0; a.win_base[rid] = 0; return; }
     for (int i = lane; i < nl * nwin; i += 64) { lwf[i] = INT32_MAX; lwl[i] = -1; }
     for (int w = lane; w < nwin; w += 64) {
       WinRec r; r.rid = rid; r.w = w; r.n_layers = 0; r.blen = (w * WL + WL <= C) ? WL : C - w * WL; r.tgs = tgs; r.out_len = 0; r.polished = 0; r.pad_ = 0;
@@ -221,6 +213,22 @@ __global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
       atomicAdd((unsigned long long*)(a.counter + 2), (unsigned long long)cells);
     }
     WSYNC();
+}
+
+__global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
+  const int lane = wave_lane();
+  const int slot = blockIdx.x;
+  __shared__ uint8_t ldraft[EXT_DCAP];
+  uint8_t* eD = a.eD + (size_t)slot * a.ecap;
+  int* lwf = a.lw_first + (size_t)slot * a.NLcap * a.NWcap;
+  int* lwl = a.lw_last + (size_t)slot * a.NLcap * a.NWcap;
+  const int WL = a.p.pol_window;
+  for (;;) {
+    int wi = 0;
+    if (lane == 0) wi = atomicAdd(a.counter, 1);
+    wi = wave_first(wi);
+    if (wi >= a.n_work) break;
+    prep_one(a, wi, lane, ldraft, eD, lwf, lwl, WL);
   }
 }
 
@@ -821,6 +829,7 @@ __global__ __launch_bounds__(64) void k_stitch(StitchArgs a) {
     const int rid = a.work[wi];
     C3Info* info = &a.info[rid];
     if (info->status != C3_ST_OK) continue;
+    if (a.zflag && a.zflag[rid]) continue;             // zero-repeat rescue: already final, never polished
     const int64_t off = a.b.off[rid];
     const int L = (int)(a.b.off[rid + 1] - off);
     const int nwin = info->n_win, wb = a.win_base[rid];

@@ -70,7 +70,18 @@ def determine_consensus(args, read, subreads, sub_qual, dangling_subreads, qual_
     name, seq, qual = read[0], read[1], read[2]
     repeats = len(subreads)
     if repeats == 0:
-        return "", 0                      # zero-repeat rescue: not accelerated yet
+        # determine_consensus.py:14-18 / zero_repeats :106-136
+        if getattr(args, "zero", True) and len(dangling_subreads) == 2:
+            if subread_file:
+                from .records import zero_repeat_records
+                with open(subread_file, "a+") as fh:
+                    fh.write(zero_repeat_records(name, dangling_subreads, qual_dangling_subreads))
+            h = _handle(mdistcutoff=getattr(args, "mdistcutoff", 500))
+            cons = h.zero_repeats(dangling_subreads[0], qual_dangling_subreads[0], dangling_subreads[1],
+                                  qual_dangling_subreads[1], getattr(args, "mdistcutoff", 500))
+            if cons:
+                return cons, 0
+        return "", 0
     front = tail = None
     d = list(zip(dangling_subreads, qual_dangling_subreads))
     if len(d) == 2:

@@ -57,6 +57,7 @@ typedef struct {
   int pol_window, pol_q;                        /* racon window 500; -q 5: determine_consensus.py:92 */
   int dang_band;                                /* half band of the dangling-piece extension, 128 */
   int slots_poa, slots_win;                     /* resident wave slots (0 = auto) */
+  int zero;                                     /* args.zero (C3POa.py:48-49): attempt the zero-repeat rescue (default 1) */
 } c3_config;
 
 typedef struct {
@@ -145,6 +146,12 @@ int c3_determine_consensus(c3_handle* h, int n, const char* const* subs, const c
                            const int* lens, const char* front, const char* front_q, int front_len,
                            const char* tail, const char* tail_q, int tail_len,
                            char* out, int cap, int* out_len, char* draft, int draft_cap, int* draft_len);
+
+/* zero_repeats(name, seq, qual, dangling, qual_dangling, subread_file) (determine_consensus.py:106-136):
+ * d0 = first dangling piece, d1 = second; *out_len = 0 when there is no acceptable overlap or the
+ * stitched sequence is shorter than min_len (args.mdistcutoff, determine_consensus.py:17). */
+int c3_zero_repeats(c3_handle* h, const char* d0, const char* q0, int n0, const char* d1, const char* q1, int n1,
+                    int min_len, char* out, int cap, int* out_len);
 
 #ifdef __cplusplus
 }

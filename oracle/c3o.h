@@ -55,6 +55,9 @@ typedef struct {
   int pol_match, pol_mismatch, pol_gap;             /* racon: 3,-5,-4 */
   int pol_window; int pol_q;                        /* 500, 5 (-q 5) */
   int dang_band;                                    /* dangling extension half band, 128 */
+  int zero;                                         /* args.zero (C3POa.py:48): attempt the zero-repeat rescue */
+  int zr_match, zr_mismatch, zr_gapo, zr_gape;      /* overlap finder: map-ont base scoring 2,4,4,2 */
+  int zr_min_score, zr_max_cells;                   /* accept threshold (80 = 40 matches), DP size cap (16M cells) */
 } c3o_params;
 
 void c3o_default_params(c3o_params* p);
@@ -122,6 +125,11 @@ int c3o_determine_consensus(const char* const* subs, const char* const* quals,
                             const c3o_params* P, char* out, int cap,
                             char* draft_out, int draft_cap, int* draft_len,
                             int64_t* cells);
+
+/* zero-repeat rescue (bin/determine_consensus.py:106-136): d0 = read[:front_end], d1 = read[tail_beg:].
+ * returns the stitched length (0 = no rescue). */
+int c3o_zero_repeats(const char* d0, const char* q0, int n0, const char* d1, const char* q1, int n1,
+                     const c3o_params* P, char* out, int cap, int64_t* cells);
 
 /* whole per-read path.  returns status; on C3O_OK cons/cons_len are set. */
 typedef struct {

@@ -35,7 +35,16 @@ static int c3o_process_read_impl(const char* splint, int S, const char* seq, con
   r->n_peaks = si.n_peaks; r->n_sub = si.n_sub;
   r->has_front = si.has_front; r->has_tail = si.has_tail; r->front_end = si.front_end; r->tail_beg = si.tail_beg;
   if (!ok) { r->status = C3O_NO_PEAKS; return r->status; }
-  if (si.n_sub == 0) { r->status = C3O_NO_CONSENSUS; return r->status; }
+  if (si.n_sub == 0) {
+    /* determine_consensus.py:14-18: zero-repeat rescue, accepted when len >= mdistcutoff */
+    if (P->zero && si.has_front && si.has_tail) {
+      int64_t zc = 0;
+      int zl = c3o_zero_repeats(seq, qual, si.front_end, seq + si.tail_beg, qual + si.tail_beg, L - si.tail_beg, P, cons, cons_cap, &zc);
+      r->cells_poa += zc;
+      if (zl > 0 && zl >= P->mdistcutoff) { r->cons_len = zl; r->status = C3O_OK; return r->status; }
+    }
+    r->status = C3O_NO_CONSENSUS; return r->status;
+  }
   if (si.n_sub > C3O_MAX_SUB) { r->status = C3O_ERR_LIMIT; return r->status; }
   const char* subs[C3O_MAX_SUB]; const char* quals[C3O_MAX_SUB]; int lens[C3O_MAX_SUB];
   for (int i = 0; i < si.n_sub; ++i) { subs[i] = seq + r->sub_beg[i]; quals[i] = qual + r->sub_beg[i]; lens[i] = r->sub_end[i] - r->sub_beg[i]; }

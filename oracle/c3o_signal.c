@@ -28,6 +28,8 @@ void c3o_default_params(c3o_params* p) {
   p->pol_match = 3; p->pol_mismatch = -5; p->pol_gap = -4;
   p->pol_window = 500; p->pol_q = 5;
   p->dang_band = 128;
+  p->zero = 1; p->zr_match = 2; p->zr_mismatch = 4; p->zr_gapo = 4; p->zr_gape = 2;
+  p->zr_min_score = 80; p->zr_max_cells = 16 << 20;
 }
 
 int c3o_code(char c) {

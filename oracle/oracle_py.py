@@ -17,7 +17,8 @@ class Params(C.Structure):
         "conk_match", "conk_mismatch", "conk_penalty", "sg_iters", "sg_window", "sg_order",
         "mdistcutoff", "poa_match", "poa_mismatch", "poa_o1", "poa_e1", "poa_o2", "poa_e2",
         "poa_band_b")] + [("poa_band_f", C.c_double)] + [(n, C.c_int) for n in (
-        "pol_match", "pol_mismatch", "pol_gap", "pol_window", "pol_q", "dang_band")]
+        "pol_match", "pol_mismatch", "pol_gap", "pol_window", "pol_q", "dang_band", "zero", "zr_match", "zr_mismatch",
+        "zr_gapo", "zr_gape", "zr_min_score", "zr_max_cells")]
 
 
 class ReadResult(C.Structure):
@@ -177,6 +178,15 @@ def determine_consensus(subs, quals, front=None, tail=None, params=None, return_
     if return_draft:
         return res, draft.raw[:dl.value].decode(), (cells[0], cells[1])
     return res
+
+
+def zero_repeats(d0, q0, d1, q1, params=None):
+    P = params or default_params()
+    b0, b1 = _b(d0), _b(d1)
+    out = C.create_string_buffer(len(b0) + len(b1) + 16)
+    cells = C.c_int64(0)
+    n = lib().c3o_zero_repeats(b0, _b(q0), len(b0), b1, _b(q1), len(b1), C.byref(P), out, len(b0) + len(b1) + 16, C.byref(cells))
+    return out.raw[:n].decode()
 
 
 def process_batch(splint, reads, strands, params=None, threads=1):

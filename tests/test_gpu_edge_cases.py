@@ -155,3 +155,77 @@ def test_stage_masks_and_state_errors():
     res, cons = h.results()
     assert res[0]["status"] == 0 and abs(len(cons[0]) - len(d)) < 60
     h.close()
+
+
+def _zero_read(rng, a, b, err=True):
+    ins = _rand(rng, 1300)
+    clean = ins[a:] + synth.SPLINT1 + ins[:b]
+    if not err:
+        return clean, "I" * len(clean), ins
+    s, q = synth._mutate(rng, np.frombuffer(clean.encode(), dtype=np.uint8))
+    return s.decode(), q.decode(), ins
+
+
+def test_zero_repeat_rescue(O):
+    """bin/determine_consensus.py:106-136: one splint, overlapping dangling pieces -> stitched consensus,
+    repeats == 0, never polished; no overlap or -z -> NO_CONSENSUS."""
+    from c3poa_amd import _lib
+    rng = np.random.default_rng(21)
+    reads, truths = [], []
+    for a, b in ((686, 1040), (212, 1230), (376, 1006), (260, 424), (300, 983), (700, 600), (100, 1299)):
+        s, q, ins = _zero_read(rng, a, b)
+        reads.append((s, q)); truths.append(ins)
+    s, q, ins = _zero_read(rng, 500, 900, err=False)
+    reads.append((s, q)); truths.append(ins)
+    reads.append((revcomp(reads[0][0]), reads[0][1][::-1])); truths.append(None)
+    strands = ["+"] * 8 + ["-"]
+    res, cons = _compare(O, [synth.SPLINT1], reads, strands, [0] * len(reads))
+    assert [int(x) for x in res["status"]] == [0, 0, 0, 0, 0, 3, 0, 0, 0]
+    assert all(int(r["n_sub"]) == 0 for r in res)
+    h2 = len(synth.SPLINT1) // 2
+    for i in (0, 1, 2, 4, 7):
+        truth = synth.SPLINT1[h2:] + truths[i] + synth.SPLINT1[:h2]
+        assert synth.identity(cons[i], truth) > (0.99 if i == 7 else 0.86)
+    # -z : rescue disabled on both sides
+    h = _lib.Handle(zero=0)
+    h.set_splints([synth.SPLINT1])
+    h.upload([r[0] for r in reads[:3]], [r[1] for r in reads[:3]], strands[:3])
+    h.run()
+    r2, c2 = h.results()
+    assert [int(x) for x in r2["status"]] == [3, 3, 3] and c2 == ["", "", ""]
+    P = O.default_params(zero=0)
+    ores, ocons = O.process_batch(synth.SPLINT1, reads[:3], strands[:3], params=P, threads=1)
+    assert [x.status for x in ores] == [3, 3, 3]
+    h.close()
+
+
+def test_zero_repeat_mixed_with_normal_reads(O):
+    rng = np.random.default_rng(22)
+    recs = list(synth.generate("cfg1", n_reads=6))
+    reads = [(r[1], r[2]) for r in recs]
+    strands = [r[3] for r in recs]
+    for a, b in ((400, 800), (650, 700)):
+        s, q, _ = _zero_read(rng, a, b)
+        reads.insert(2, (s, q)); strands.insert(2, "+")
+    res, cons = _compare(O, [synth.SPLINT1], reads, strands, [0] * len(reads))
+    assert sum(int(r["n_sub"]) == 0 and int(r["status"]) == 0 for r in res) >= 1
+
+
+def test_zero_repeats_entry_point_and_shim(O):
+    from c3poa_amd import _lib, shims
+    import types
+    rng = np.random.default_rng(23)
+    s, q, _ = _zero_read(rng, 450, 950)
+    ores, _c = O.process_batch(synth.SPLINT1, [(s, q)], ["+"], threads=1)
+    p = ores[0].front_end
+    d0, q0, d1, q1 = s[:p], q[:p], s[p:], q[p:]
+    ref = O.zero_repeats(d0, q0, d1, q1)
+    h = _lib.Handle()
+    assert h.zero_repeats(d0, q0, d1, q1, 500) == ref and len(ref) > 1400
+    assert h.zero_repeats(d0, q0, d1, q1, 5000) == ""                    # shorter than the cutoff
+    assert h.zero_repeats(_rand(rng, 700), "I" * 700, _rand(rng, 650), "I" * 650, 0) == ""   # no overlap
+    h.close()
+    args = types.SimpleNamespace(mdistcutoff=500, zero=True)
+    assert shims.determine_consensus(args, ("rd", s, q), [], [], [d0, d1], [q0, q1]) == (ref, 0)
+    args.zero = False
+    assert shims.determine_consensus(args, ("rd", s, q), [], [], [d0, d1], [q0, q1]) == ("", 0)
