@@ -42,6 +42,9 @@ def parse_args(argv=None):
     parser.add_argument("--numThreads", "-n", type=int, default=1, help="Number of GPUs (workers) to use. Defaults to 1.")
     parser.add_argument("--groupSize", "-g", type=int, default=1000,
                         help="Number of reads processed by each worker in each iteration. Defaults to 1000.")
+    parser.add_argument("--splint-finder", dest="splint_finder", choices=["gpu", "blat"], default="gpu",
+                        help="How reads are assigned to splints when the PSL does not exist yet: the GPU finder "
+                             "(default) or the blat binary of the config file, as upstream.")
     parser.add_argument("--blatThreads", "-b", action="store_true", default=False, help="Accepted for compatibility.")
     parser.add_argument("--compress_output", "-co", action="store_true", default=False,
                         help="Use to compress (gzip) both the consensus fasta and subread fastq output files.")

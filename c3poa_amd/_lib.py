@@ -18,7 +18,7 @@ ST_OK, ST_NOT_ASSIGNED, ST_NO_PEAKS, ST_NO_CONSENSUS, ST_TOO_SHORT, ST_LIMIT = r
 EXPORTS = ["c3_default_config", "c3_version", "c3_create", "c3_destroy", "c3_last_error", "c3_set_splints",
            "c3_batch_upload", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_timing",
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
-           "c3_call_peaks", "c3_poa_msa", "c3_determine_consensus", "c3_zero_repeats"]
+           "c3_call_peaks", "c3_poa_msa", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints"]
 
 
 class Config(C.Structure):
@@ -84,6 +84,7 @@ def load():
     lib.c3_call_peaks.argtypes = [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
     lib.c3_poa_msa.argtypes = [vp, C.c_int, C.POINTER(cp), ip, vp, C.c_int, ip, vp, C.c_int64, ip]
     lib.c3_zero_repeats.argtypes = [vp, cp, cp, C.c_int, cp, cp, C.c_int, C.c_int, vp, C.c_int, ip]
+    lib.c3_scan_splints.argtypes = [vp, vp, vp, vp]
     lib.c3_determine_consensus.argtypes = [vp, C.c_int, C.POINTER(cp), C.POINTER(cp), ip, cp, cp, C.c_int,
                                            cp, cp, C.c_int, vp, C.c_int, ip, vp, C.c_int, ip]
     _lib = lib
@@ -143,6 +144,7 @@ class Handle:
         off = np.zeros(len(bs) + 1, dtype=np.int64)
         np.cumsum([len(b) for b in bs], out=off[1:])
         self._chk(self.lib.c3_set_splints(self.h, len(bs), b"".join(bs), off.ctypes.data))
+        self.n_splints = len(bs)
 
     def upload(self, seqs, quals, strands, splint_ids=None):
         """seqs/quals: lists of str/bytes (or pre-joined bytes with `lens`), strands: '+'/'-' per read"""
@@ -240,6 +242,16 @@ class Handle:
         c = [cons.raw[:cl.value].decode()] if out_cons and cl.value else []
         m = [msa.raw[i * ml.value:(i + 1) * ml.value].decode() for i in range(n)] if out_msa and ml.value else []
         return c, m
+
+    def scan_splints(self):
+        """splint/strand finder over the resident batch (replaces blat, bin/preprocess.py:61-77).
+        returns (table[n][n_splints][2][4] = max, argmax, mean, L; splint_id[n] (-1 = none); strand bytes)"""
+        n = self.n
+        tab = np.zeros((n, self.n_splints, 2, 4), dtype=np.int32)
+        sid = np.zeros(n, dtype=np.int16)
+        st = np.zeros(n, dtype=np.uint8)
+        self._chk(self.lib.c3_scan_splints(self.h, tab.ctypes.data, sid.ctypes.data, st.ctypes.data))
+        return tab, sid, st.tobytes()
 
     def zero_repeats(self, d0, q0, d1, q1, min_len=0):
         b0, b1 = _b(d0), _b(d1)

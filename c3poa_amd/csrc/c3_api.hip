@@ -9,7 +9,7 @@
 #include <vector>
 
 // ---- kernel launchers (one translation unit per kernel family) --------------------------
-extern "C" void c3k_launch_conk(const ConkArgs*, int, int, hipStream_t);
+extern "C" void c3k_launch_conk(const ConkArgs*, int, int, int, hipStream_t);
 extern "C" void c3k_launch_peaks(const PeaksArgs*, int, hipStream_t);
 extern "C" void c3k_launch_poa(const PoaArgs*, int, hipStream_t);
 extern "C" void c3k_launch_prep(const PrepArgs*, int, hipStream_t);
@@ -257,9 +257,9 @@ static int run_conk(c3_handle* h) {
   HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 64, h->stream));
   ConkArgs a; a.b = dev_batch(h); a.sp_codes = h->d_sp_codes.as<uint8_t>(); a.sp_len = h->d_sp_len.as<int>();
   a.track = h->d_track.as<int32_t>(); a.info = h->d_info.as<C3Info>(); a.counter = h->d_counter.as<int>();
-  a.match = h->cfg.conk_match; a.mismatch = h->cfg.conk_mismatch; a.penalty = h->cfg.conk_penalty;
+  a.match = h->cfg.conk_match; a.mismatch = h->cfg.conk_mismatch; a.penalty = h->cfg.conk_penalty; a.n_spl = h->n_spl; a.scan = nullptr;
   int waves = std::min(h->n, h->n_cus * 32);
-  c3k_launch_conk(&a, h->max_spl, (waves + 3) / 4, h->stream);
+  c3k_launch_conk(&a, h->max_spl, (waves + 3) / 4, 0, h->stream);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -690,6 +690,43 @@ static int inject(c3_handle* h, int n, const char* const* subs, const char* cons
   HIPCHK(hipMemcpy(h->d_info.p, &r, sizeof(r), hipMemcpyHostToDevice));
   h->injected = true;
   return 0;
+}
+
+// splint / strand finder (replaces the blat step of bin/preprocess.py:12-45,61-77): every read of the resident
+// batch is scored against every splint on both strands with the conk kernel; out[i*n_spl*2 + s*2 + rc] =
+// {max of the track, its offset, mean of the track, read length}.  assign_* picks the best candidate and
+// accepts it when max >= 6 * mean (the same contrast test call_peaks applies later, bin/call_peaks.py:13) and
+// max >= match*51*52/2 (a perfect 51-base match: the `matches > 50` filter of bin/preprocess.py:32).
+extern "C" int c3_scan_splints(c3_handle* h, int32_t* out /* [n][n_spl][2][4] */, int16_t* assign_splint, char* assign_strand) {
+  if (!h || h->n <= 0 || h->n_spl <= 0) return C3_E_STATE;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t items = (size_t)h->n * h->n_spl * 2;
+  DBuf scan;
+  HIPCHK(scan.ensure(sizeof(int32_t) * 4 * items));
+  HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 64, h->stream));
+  ConkArgs a; memset(&a, 0, sizeof(a));
+  a.b = dev_batch(h); a.sp_codes = h->d_sp_codes.as<uint8_t>(); a.sp_len = h->d_sp_len.as<int>();
+  a.track = nullptr; a.info = h->d_info.as<C3Info>(); a.counter = h->d_counter.as<int>();
+  a.match = h->cfg.conk_match; a.mismatch = h->cfg.conk_mismatch; a.penalty = h->cfg.conk_penalty;
+  a.n_spl = h->n_spl; a.scan = scan.as<int32_t>();
+  const int waves = (int)std::min<size_t>(items, (size_t)h->n_cus * 32);
+  c3k_launch_conk(&a, h->max_spl, (waves + 3) / 4, 1, h->stream);
+  HIPCHK(hipGetLastError());
+  std::vector<int32_t> tmp(4 * items);
+  HIPCHK(hipMemcpyAsync(tmp.data(), scan.p, sizeof(int32_t) * 4 * items, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  scan.release();
+  if (out) memcpy(out, tmp.data(), sizeof(int32_t) * 4 * items);
+  for (int i = 0; i < h->n; ++i) {
+    int best = -1, bs = -1;
+    for (int c = 0; c < h->n_spl * 2; ++c) { const int32_t* e = &tmp[((size_t)i * h->n_spl * 2 + c) * 4]; if (e[0] > bs) { bs = e[0]; best = c; } }
+    // matches > 50 of bin/preprocess.py:32, as the diagonal sum of a perfect 51-base match
+    const long long floor51 = (long long)h->cfg.conk_match * 51 * 52 / 2;
+    bool ok = best >= 0 && bs >= floor51 && (long long)bs >= 6LL * tmp[((size_t)i * h->n_spl * 2 + best) * 4 + 2];
+    if (assign_splint) assign_splint[i] = ok ? (int16_t)(best >> 1) : (int16_t)-1;
+    if (assign_strand) assign_strand[i] = ok ? ((best & 1) ? '-' : '+') : '?';
+  }
+  return C3_E_OK;
 }
 
 extern "C" int c3_call_peaks(c3_handle* h, const int32_t* scores, int n, int min_dist, int32_t* peaks, int cap, double* smoothed) {

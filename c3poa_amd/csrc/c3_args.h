@@ -5,6 +5,7 @@
 struct ConkArgs {
   C3Batch b; const uint8_t* sp_codes; const int* sp_len; int32_t* track; C3Info* info; int* counter;
   int match, mismatch, penalty;
+  int n_spl; int32_t* scan;      // scan mode: [n * n_spl * 2][4] = max, argmax, mean, L
 };
 struct PeaksArgs {
   C3Batch b; const int32_t* track; C3Info* info; double* bufA; double* bufB; int32_t* cand; uint8_t* cstate;

@@ -40,21 +40,26 @@ __device__ __forceinline__ void conk_step(int rc, bool kill, int (&hprev)[R], in
   W = wn;
 }
 
-template <int R>
+// SCAN = false: the track of every read against ITS splint/strand is written (the hot path).
+// SCAN = true : work item = (read, splint, strand) for every splint on both strands; only max, argmax and
+//               sum of the track are kept -- the splint/strand finder that replaces blat (preprocess.py).
+template <int R, bool SCAN>
 __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
   const int lane = wave_lane();
+  const int n_items = SCAN ? a.b.n * a.n_spl * 2 : a.b.n;
   for (;;) {
-    int rid = 0;
-    if (lane == 0) rid = atomicAdd(a.counter, 1);
-    rid = wave_first(rid);
-    if (rid >= a.b.n) break;
+    int item = 0;
+    if (lane == 0) item = atomicAdd(a.counter, 1);
+    item = wave_first(item);
+    if (item >= n_items) break;
+    const int rid = SCAN ? item / (a.n_spl * 2) : item;
     const int64_t off = a.b.off[rid];
     const int L = (int)(a.b.off[rid + 1] - off);
-    const int st = a.b.strand[rid];
+    const int st = SCAN ? ((item & 1) ? '-' : '+') : a.b.strand[rid];
     // (stored by every lane: a divergent `if (lane == 0)` right before `continue` can livelock the
     // persistent loop -- see prep_one in k_polish.hip)
-    if (st != '+' && st != '-') { a.info[rid].status = C3_ST_NOT_ASSIGNED; continue; }
-    const int sid = a.b.splint_id[rid];
+    if (!SCAN && st != '+' && st != '-') { a.info[rid].status = C3_ST_NOT_ASSIGNED; continue; }
+    const int sid = SCAN ? (item >> 1) % a.n_spl : a.b.splint_id[rid];
     const int S = a.sp_len[sid];
     const uint8_t* sp = a.sp_codes + ((size_t)sid * 2 + (st == '-')) * C3_SPLINT_MAX;
     const uint32_t* pk = a.b.pk + a.b.woff[rid];
@@ -68,6 +73,7 @@ __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
       hprev[k] = 0; P[k] = 0;
     }
     int W = 0, up_prev = 0;
+    int smax = -1, sarg = 0; long long ssum = 0;          // SCAN accumulators (meaningful in lane 63)
     // lane 63 finishes diagonal d = t - c0 at step t
     const int c0 = 63 * (R + 1) + (R - 1) - pad;
     const int T_end = L + c0;                 // last useful step is L-1+c0
@@ -82,7 +88,8 @@ __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
           int rc = (x >> (2 * s)) & 3;
           conk_step<R, false>(rc, false, hprev, P, W, up_prev, code, a.match, a.mismatch, a.penalty);
           int d = t0 + s - c0;
-          if (lane == 63 && d >= 0 && d < L) track[d] = P[R - 1];
+          if (SCAN) { if (d >= 0 && d < L) { ssum += P[R - 1]; if (P[R - 1] > smax) { smax = P[R - 1]; sarg = d; } } }
+          else if (lane == 63 && d >= 0 && d < L) track[d] = P[R - 1];
         }
       } else {
         for (int s = 0; s < 16; ++s) {
@@ -91,24 +98,29 @@ __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
           int rc = oob ? 4 : c3_code_at(pk, j);
           conk_step<R, true>(rc, oob, hprev, P, W, up_prev, code, a.match, a.mismatch, a.penalty);
           int d = t0 + s - c0;
-          if (lane == 63 && d >= 0 && d < L) track[d] = P[R - 1];
+          if (SCAN) { if (d >= 0 && d < L) { ssum += P[R - 1]; if (P[R - 1] > smax) { smax = P[R - 1]; sarg = d; } } }
+          else if (lane == 63 && d >= 0 && d < L) track[d] = P[R - 1];
         }
       }
+    }
+    if (SCAN) {
+      // broadcast lane 63's accumulators and store from EVERY lane: a divergent `if (lane == 63)` right before
+      // the back edge of the persistent loop live-locks (same hipcc pitfall as in k_prep)
+      const int mean = (int)(ssum / (L > 0 ? L : 1));
+      int4 v = make_int4(__builtin_amdgcn_readlane(smax, 63), __builtin_amdgcn_readlane(sarg, 63),
+                         __builtin_amdgcn_readlane(mean, 63), L);
+      *reinterpret_cast<int4*>(a.scan + (size_t)item * 4) = v;
     }
   }
 }
 
-extern "C" void c3k_launch_conk(const ConkArgs* a, int max_splint, int grid, hipStream_t stream) {
+extern "C" void c3k_launch_conk(const ConkArgs* a, int max_splint, int grid, int scan, hipStream_t stream) {
   int R = (max_splint + 63) / 64;
   dim3 g(grid), b(256);
+#define LC(r) if (scan) hipLaunchKernelGGL((k_conk<r, true>), g, b, 0, stream, *a); else hipLaunchKernelGGL((k_conk<r, false>), g, b, 0, stream, *a); break;
   switch (R) {
-    case 1: hipLaunchKernelGGL(k_conk<1>, g, b, 0, stream, *a); break;
-    case 2: hipLaunchKernelGGL(k_conk<2>, g, b, 0, stream, *a); break;
-    case 3: hipLaunchKernelGGL(k_conk<3>, g, b, 0, stream, *a); break;
-    case 4: hipLaunchKernelGGL(k_conk<4>, g, b, 0, stream, *a); break;
-    case 5: hipLaunchKernelGGL(k_conk<5>, g, b, 0, stream, *a); break;
-    case 6: hipLaunchKernelGGL(k_conk<6>, g, b, 0, stream, *a); break;
-    case 7: hipLaunchKernelGGL(k_conk<7>, g, b, 0, stream, *a); break;
-    default: hipLaunchKernelGGL(k_conk<8>, g, b, 0, stream, *a); break;
+    case 1: LC(1) case 2: LC(2) case 3: LC(3) case 4: LC(4) case 5: LC(5) case 6: LC(6) case 7: LC(7)
+    default: LC(8)
   }
+#undef LC
 }

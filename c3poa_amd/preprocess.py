@@ -37,14 +37,67 @@ def parse_psl(align_psl, tmp_adapter_dict):
     return adapter_dict, adapter_set, no_splint
 
 
+def equivalent_matches(score, match=5):
+    """length m of the perfect ungapped match whose diagonal sum match*m*(m+1)/2 equals `score` -- the figure
+    written to PSL column 0 so that the reference's `matches > 50` filter (bin/preprocess.py:32) keeps its meaning"""
+    return int(((1.0 + 8.0 * max(0, int(score)) / match) ** 0.5 - 1.0) / 2.0)
+
+
+def psl_row(read_name, read_len, splint_name, splint_len, strand, score, offset, match=5):
+    m = min(equivalent_matches(score, match), splint_len)
+    q_start = max(0, min(int(offset), read_len))
+    q_end = min(read_len, q_start + splint_len)
+    cols = [m, splint_len - m, 0, 0, 0, 0, 0, 0, strand, read_name, read_len, q_start, q_end,
+            splint_name, splint_len, 0, splint_len, 1, "%d," % splint_len, "%d," % q_start, "0,"]
+    return "\t".join(str(c) for c in cols)
+
+
+def gpu_find_splints(args, align_psl, batch_reads=16384, handle=None):
+    """GPU splint/strand finder: one PSL row per accepted read (best candidate only, like the reference keeps the
+    best row per read, bin/preprocess.py:39).  Reads are streamed in batches; the handle is reused."""
+    from . import _lib
+    from .seqio import fastx_read
+    splints = [(s[0], s[1]) for s in fastx_read(args.splint_file)]
+    h = handle or _lib.Handle()
+    h.set_splints([s[1] for s in splints])
+    n_rows = 0
+    with open(align_psl + ".part", "w") as out:
+        def flush(names, seqs):
+            nonlocal n_rows
+            if not names:
+                return
+            h.upload(seqs, ["!" * len(s) for s in seqs], "?" * len(seqs))
+            tab, sid, st = h.scan_splints()
+            for i, name in enumerate(names):
+                if sid[i] < 0:
+                    continue
+                e = tab[i, sid[i], 1 if st[i:i + 1] == b"-" else 0]
+                out.write(psl_row(name, len(seqs[i]), splints[sid[i]][0], len(splints[sid[i]][1]),
+                                  st[i:i + 1].decode(), e[0], e[1], h.cfg.conk_match) + "\n")
+                n_rows += 1
+        names, seqs = [], []
+        for rd in fastx_read(args.reads):
+            if len(rd[1]) < args.lencutoff:
+                continue
+            names.append(rd[0]); seqs.append(rd[1])
+            if len(names) >= batch_reads:
+                flush(names, seqs); names, seqs = [], []
+        flush(names, seqs)
+    os.replace(align_psl + ".part", align_psl)
+    if handle is None:
+        h.close()
+    return n_rows
+
+
 def preprocess(blat, args, tmp_dir, tmp_adapter_dict, num_reads):
     align_psl = tmp_dir + "splint_to_read_alignments.psl"
-    if not os.path.exists(align_psl) or os.stat(align_psl).st_size == 0:
+    finder = getattr(args, "splint_finder", "gpu")
+    if (not os.path.exists(align_psl) or os.stat(align_psl).st_size == 0) and finder == "gpu":
+        print("Assigning splints to reads on the GPU", file=sys.stderr)
+        gpu_find_splints(args, align_psl)
+    elif not os.path.exists(align_psl) or os.stat(align_psl).st_size == 0:
         if shutil.which(blat) is None:
-            raise RuntimeError(
-                "no %s and no blat binary (%r): the splint/strand assignment step is outside the accelerated "
-                "path; provide the PSL (c3poa_amd.synth.write_psl does for synthetic data) or install blat"
-                % (align_psl, blat))
+            raise RuntimeError("no %s and no blat binary (%r); use --splint-finder gpu" % (align_psl, blat))
         print("Aligning splints to reads with blat", file=sys.stderr)
         fa = tmp_dir + "R2C2_temp_for_BLAT.fasta"
         from .seqio import fastx_read

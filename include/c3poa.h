@@ -147,6 +147,14 @@ int c3_determine_consensus(c3_handle* h, int n, const char* const* subs, const c
                            const char* tail, const char* tail_q, int tail_len,
                            char* out, int cap, int* out_len, char* draft, int draft_cap, int* draft_len);
 
+/* splint / strand assignment of the resident batch (replaces the blat step of bin/preprocess.py:12-45,61-77):
+ * every read is scored against every splint on both strands with the conk kernel.
+ * out (optional) [n][n_splints][2][4] = {max of the track, its offset, mean of the track, read length};
+ * assign_splint[i] = best splint (-1 = none), assign_strand[i] = '+', '-' or '?'; a candidate is accepted when
+ * max >= 6 * mean (the contrast call_peaks demands later, bin/call_peaks.py:13) and max >= match*51*52/2
+ * (the diagonal sum of a perfect 51-base match: `matches > 50`, bin/preprocess.py:32). */
+int c3_scan_splints(c3_handle* h, int32_t* out, int16_t* assign_splint, char* assign_strand);
+
 /* zero_repeats(name, seq, qual, dangling, qual_dangling, subread_file) (determine_consensus.py:106-136):
  * d0 = first dangling piece, d1 = second; *out_len = 0 when there is no acceptable overlap or the
  * stitched sequence is shorter than min_len (args.mdistcutoff, determine_consensus.py:17). */

@@ -68,6 +68,31 @@ def conk(splint, seq, penalty=20, match=5, mismatch=-4):
     return out
 
 
+def scan_splints(seqs, splints, penalty=20, match=5, mismatch=-4):
+    """ORACLE of c3_scan_splints: conk track of every read against every splint on both strands;
+    table[n][n_splints][2][4] = max, first argmax, floor(mean), L and the assignment rule
+    (best max; accepted when max >= 6 * mean and max >= match*51*52/2)."""
+    comp = bytes.maketrans(b"ACGTUacgtu", b"TGCAAtgcaa")
+    n = len(seqs)
+    tab = np.zeros((n, len(splints), 2, 4), dtype=np.int32)
+    sid = np.full(n, -1, dtype=np.int16)
+    strand = bytearray(b"?" * n)
+    for i, rd in enumerate(seqs):
+        best, bs = -1, -1
+        for s, sp in enumerate(splints):
+            for rc in (0, 1):
+                q = _b(sp) if rc == 0 else _b(sp).translate(comp)[::-1]
+                t = conk(q, rd, penalty, match, mismatch)
+                L = len(t)
+                tab[i, s, rc] = (int(t.max()), int(t.argmax()), int(t.astype(np.int64).sum() // max(L, 1)), L) if L else (-1, 0, 0, 0)
+                if tab[i, s, rc, 0] > bs:
+                    bs, best = int(tab[i, s, rc, 0]), s * 2 + rc
+        if best >= 0 and bs >= match * 51 * 52 // 2 and bs >= 6 * int(tab[i, best >> 1, best & 1, 2]):
+            sid[i] = best >> 1
+            strand[i] = ord("-" if best & 1 else "+")
+    return tab, sid, bytes(strand)
+
+
 def savgol(y, window=41, order=2):
     y = np.ascontiguousarray(y, dtype=np.float64)
     out = np.empty_like(y)

@@ -229,3 +229,59 @@ def test_zero_repeats_entry_point_and_shim(O):
     assert shims.determine_consensus(args, ("rd", s, q), [], [], [d0, d1], [q0, q1]) == (ref, 0)
     args.zero = False
     assert shims.determine_consensus(args, ("rd", s, q), [], [], [d0, d1], [q0, q1]) == ("", 0)
+
+
+def test_splint_finder_matches_oracle_and_truth(O):
+    """c3_scan_splints (GPU replacement of the blat step) == oracle table bit for bit; assignment == ground truth"""
+    from c3poa_amd import _lib
+    rng = np.random.default_rng(77)
+    splints = [synth.SPLINT1, _rand(rng, 200), _rand(rng, 97)]
+    reads, truth = [], []
+    for i in range(36):
+        s = i % 3
+        seq, _q = _concatemer(rng, splints[s], 700 + 40 * i, 2 + i % 3, 60, 60)
+        st = "+-"[(i // 3) % 2]
+        if st == "-":
+            seq = revcomp(seq)
+        reads.append(seq); truth.append((s, st))
+    reads += [_rand(rng, 3000), _rand(rng, 500), "A" * 300, _rand(rng, 20)]      # nothing to find
+    truth += [(-1, "?")] * 4
+    h = _lib.Handle()
+    h.set_splints(splints)
+    h.upload(reads, ["I" * len(r) for r in reads], "?" * len(reads))
+    tab, sid, st = h.scan_splints()
+    otab, osid, ost = O.scan_splints(reads, splints)
+    assert np.array_equal(tab, otab)
+    assert np.array_equal(sid, osid) and st == ost
+    assert [(int(a), chr(b)) for a, b in zip(sid, st)] == truth
+    # a '-' strand read scores on the revcomp row: strand semantics of conk.conk(splint_dict[name][1], seq) (C3POa.py:119-122)
+    assert tab[3, 0, 1, 0] > 4 * tab[3, 0, 0, 0]
+
+
+def test_cli_gpu_splint_finder(tmp_path):
+    """no PSL, no blat: the CLI assigns splints on the GPU, writes the PSL and reuses it on the next run"""
+    import os
+    import C3POa
+    from c3poa_amd.seqio import fastx_read
+    recs = list(synth.generate("cfg1", n_reads=12))
+    rng = np.random.default_rng(5)
+    out = str(tmp_path / "out")
+    fq = str(tmp_path / "reads.fastq")
+    with open(fq, "w") as fh:
+        for r in recs:
+            fh.write("@%s\n%s\n+\n%s\n" % (r[0], r[1], r[2]))
+        fh.write("@junk\n%s\n+\n%s\n" % (_rand(rng, 2000), "I" * 2000))
+    fa = str(tmp_path / "splint.fasta")
+    open(fa, "w").write(">Splint1\n%s\n>Other\n%s\n" % (synth.SPLINT1, _rand(rng, 240)))
+    C3POa.main(C3POa.parse_args(["-r", fq, "-s", fa, "-o", out]))
+    psl = open(out + "/tmp/splint_to_read_alignments.psl").read().splitlines()
+    assert len(psl) == 12 and all(len(l.split("\t")) == 21 for l in psl)
+    assert [(l.split("\t")[9], l.split("\t")[8], l.split("\t")[13]) for l in psl] == [(r[0], r[3], "Splint1") for r in recs]
+    log = open(out + "/c3poa.log").read().splitlines()
+    assert log[2].startswith("No splint reads: 1 ")
+    first = sorted(fastx_read(out + "/Splint1/R2C2_Consensus.fasta"))
+    assert len(first) == 12
+    mtime = os.stat(out + "/tmp/splint_to_read_alignments.psl").st_mtime_ns
+    C3POa.main(C3POa.parse_args(["-r", fq, "-s", fa, "-o", out]))                 # resume: PSL reused
+    assert os.stat(out + "/tmp/splint_to_read_alignments.psl").st_mtime_ns == mtime
+    assert sorted(fastx_read(out + "/Splint1/R2C2_Consensus.fasta")) == first

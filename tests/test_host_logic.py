@@ -52,9 +52,22 @@ def test_psl_parse_and_reuse(tmp_path):
 
 
 def test_missing_psl_without_blat_fails_loudly(tmp_path):
-    args = types.SimpleNamespace(reads=None, lencutoff=1000, splint_file=None)
+    args = types.SimpleNamespace(reads=None, lencutoff=1000, splint_file=None, splint_finder="blat")
     with pytest.raises(RuntimeError):
         preprocess.preprocess("definitely-not-a-binary", args, str(tmp_path) + "/", {}, 0)
+
+
+def test_gpu_finder_psl_rows_pass_the_reference_filter(tmp_path):
+    """rows written by the GPU splint finder are 21-column PSL and survive matches > 50 / qBaseInsert < 50"""
+    assert preprocess.equivalent_matches(5 * 51 * 52 // 2) == 51 and preprocess.equivalent_matches(5 * 51 * 52 // 2 - 1) == 50
+    assert preprocess.equivalent_matches(0) == 0
+    row = preprocess.psl_row("r1", 5000, "Splint1", 284, "-", 120000, 430)
+    cols = row.split("\t")
+    assert len(cols) == 21 and cols[8] == "-" and cols[9] == "r1" and cols[13] == "Splint1"
+    psl = tmp_path / "a.psl"
+    psl.write_text(row + "\n" + preprocess.psl_row("r2", 900, "Splint1", 284, "+", 6000, 10) + "\n")
+    ad, aset, none = preprocess.parse_psl(str(psl), {"r1": [[None, 1, None]], "r2": [[None, 1, None]]})
+    assert ad == {"r1": ["Splint1", "-"]} and none == 1          # r2: equivalent matches 48 <= 50
 
 
 def test_cli_flags_and_defaults():
