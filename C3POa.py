@@ -99,16 +99,18 @@ def main(args):
     tmp_dir = args.out_path + "tmp/"
     os.makedirs(tmp_dir, exist_ok=True)
 
-    total_reads, short_reads, tmp_adapter_dict = 0, 0, {}
-    for read in fastx_read(args.reads):
-        if len(read[1]) < args.lencutoff:
-            short_reads += 1
-            continue
-        tmp_adapter_dict[read[0]] = [[None, 1, None]]
-        total_reads += 1
+    from c3poa_amd import stream
+    import time
+    t_main = [time.perf_counter()]
+    names, short_reads = stream.scan_names(args.reads, args.lencutoff)      # native reader (C3POa.py:200-207)
+    t_main.append(time.perf_counter())
+    tmp_adapter_dict = {name: [[None, 1, None]] for name in names}
+    total_reads = len(names)
+    del names
     adapter_dict, adapter_set, no_splint = preprocess(blat, args, tmp_dir, tmp_adapter_dict, total_reads)
     for adapter in adapter_set:
         os.makedirs(args.out_path + adapter, exist_ok=True)
+    t_main.append(time.perf_counter())
 
     all_reads = total_reads + short_reads
     print("C3POa version:", VERSION, file=log_file)
@@ -124,29 +126,14 @@ def main(args):
     for splint in fastx_read(args.splint_file):
         splint_dict[splint[0]] = [splint[1], revcomp(splint[1])]
 
-    n_dev = max(1, args.numThreads)
-    try:
-        import torch
-        n_dev = max(1, min(n_dev, torch.cuda.device_count()))
-    except Exception:
-        n_dev = 1
-    iteration, tmp_reads = 1, []
-    for read in fastx_read(args.reads):
-        if len(read[1]) < args.lencutoff:
-            continue
-        tmp_reads.append(read)
-        if len(tmp_reads) == args.groupSize:
-            analyze_reads(args, tmp_reads, splint_dict, adapter_dict, adapter_set, iteration, racon, device=(iteration - 1) % n_dev)
-            iteration += 1
-            tmp_reads = []
-    if tmp_reads:                                     # flush the tail (deliberate fix of App. A.12)
-        analyze_reads(args, tmp_reads, splint_dict, adapter_dict, adapter_set, iteration, racon, device=(iteration - 1) % n_dev)
-
-    for adapter in adapter_set:
-        cat_files(args.out_path + adapter, "/tmp*/R2C2_Consensus.fasta", args.out_path + adapter + "/R2C2_Consensus.fasta", args.compress_output)
-        cat_files(args.out_path + adapter, "/tmp*/subreads.fastq", args.out_path + adapter + "/R2C2_Subreads.fastq", args.compress_output)
-        for d in glob(args.out_path + adapter + "/tmp*"):
-            shutil.rmtree(d)
+    from c3poa_amd import _lib
+    n_dev = max(1, min(max(1, args.numThreads), _lib.device_count()))        # -n = GPUs that share the groups
+    # streaming pipeline: native reader -> GPU batches -> native writer (c3poa_amd/stream.py); the tail group is
+    # processed too (deliberate fix of SURVEY.md App. A.12)
+    stream.run(args, splint_dict, adapter_dict, adapter_set, n_dev)
+    if os.environ.get("C3_STREAM_STATS"):
+        t_main.append(time.perf_counter())
+        print("main: scan_names=%.3f preprocess=%.3f consensus=%.3f" % tuple(b - a for a, b in zip(t_main, t_main[1:])), file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -15,10 +15,11 @@ MAX_PEAKS = 256
 STAGE_CONK, STAGE_PEAKS, STAGE_POA, STAGE_POLISH, STAGES_ALL = 1, 2, 4, 8, 15
 ST_OK, ST_NOT_ASSIGNED, ST_NO_PEAKS, ST_NO_CONSENSUS, ST_TOO_SHORT, ST_LIMIT = range(6)
 
-EXPORTS = ["c3_default_config", "c3_version", "c3_create", "c3_destroy", "c3_last_error", "c3_set_splints",
+EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_create", "c3_destroy", "c3_last_error", "c3_set_splints",
            "c3_batch_upload", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_timing",
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
-           "c3_call_peaks", "c3_poa_msa", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints"]
+           "c3_call_peaks", "c3_poa_msa", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
+           "c3_reader_open", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_write_group"]
 
 
 class Config(C.Structure):
@@ -48,6 +49,11 @@ class Timing(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("ms_pack", "ms_conk", "ms_peaks", "ms_poa", "ms_prep", "ms_window",
                                          "ms_stitch", "ms_total")] + \
                [(n, C.c_int64) for n in ("n_reads", "n_bases", "n_windows", "cells_conk", "cells_poa", "cells_polish")]
+
+
+class HostBatchStruct(C.Structure):
+    _fields_ = [("n", C.c_int32), ("n_short", C.c_int64), ("names", C.c_void_p), ("name_off", C.c_void_p),
+                ("seqs", C.c_void_p), ("quals", C.c_void_p), ("off", C.c_void_p)]
 
 
 _lib = None
@@ -85,6 +91,15 @@ def load():
     lib.c3_poa_msa.argtypes = [vp, C.c_int, C.POINTER(cp), ip, vp, C.c_int, ip, vp, C.c_int64, ip]
     lib.c3_zero_repeats.argtypes = [vp, cp, cp, C.c_int, cp, cp, C.c_int, C.c_int, vp, C.c_int, ip]
     lib.c3_scan_splints.argtypes = [vp, vp, vp, vp]
+    lib.c3_reader_open.argtypes = [cp, C.c_int, C.POINTER(vp)]
+    lib.c3_reader_close.argtypes = [vp]
+    lib.c3_reader_close.restype = None
+    lib.c3_reader_error.argtypes = [vp]
+    lib.c3_reader_names_only.argtypes = [vp, C.c_int]
+    lib.c3_reader_names_only.restype = None
+    lib.c3_reader_error.restype = C.c_char_p
+    lib.c3_reader_next.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.POINTER(HostBatchStruct)]
+    lib.c3_write_group.argtypes = [C.POINTER(HostBatchStruct), vp, vp, vp, vp, C.c_int, C.POINTER(cp), C.POINTER(cp), C.c_int]
     lib.c3_determine_consensus.argtypes = [vp, C.c_int, C.POINTER(cp), C.POINTER(cp), ip, cp, cp, C.c_int,
                                            cp, cp, C.c_int, vp, C.c_int, ip, vp, C.c_int, ip]
     _lib = lib
@@ -172,8 +187,32 @@ class Handle:
         self.n = n
         self.off = off
 
+    def upload_host(self, hb, strands, splint_ids):
+        """upload a HostBatch of the native reader straight from its (page-locked) buffers: no Python copies"""
+        st = np.frombuffer(_b(strands), dtype=np.uint8)
+        sid = np.ascontiguousarray(splint_ids, dtype=np.int16)
+        assert len(st) == hb.n == len(sid)
+        self._chk(self.lib.c3_batch_upload(self.h, hb.n, hb.c.seqs, hb.c.quals, hb.c.off, sid.ctypes.data, st.ctypes.data))
+        self.n = hb.n
+        self.off = hb.off
+
     def run(self, stages=STAGES_ALL):
         self._chk(self.lib.c3_batch_run(self.h, stages))
+
+    def results_raw(self):
+        """(results structured array, consensus byte buffer, cons_off[n+1]) without building Python strings"""
+        coff = np.zeros(self.n + 1, dtype=np.int64)
+        cap = int(self.off[-1]) + 16
+        pool = self.__dict__.setdefault("_cons_pool", [[None, None] for _ in range(4)])   # the 3 previous results stay valid
+        k = self.__dict__["_cons_k"] = (self.__dict__.get("_cons_k", -1) + 1) % len(pool)
+        buf, rbuf = pool[k]
+        if buf is None or len(buf) < cap:                      # grow-only: no page faults per batch
+            buf = pool[k][0] = np.empty(cap + cap // 4, dtype=np.uint8)
+        if rbuf is None or len(rbuf) < self.n:
+            rbuf = pool[k][1] = np.empty(self.n + self.n // 4 + 1, dtype=RESULT_DTYPE)
+        res = rbuf[:self.n]
+        self._chk(self.lib.c3_batch_results(self.h, res.ctypes.data, buf.ctypes.data, len(buf), coff.ctypes.data))
+        return res, buf, coff
 
     def results(self, with_consensus=True):
         res = np.zeros(self.n, dtype=RESULT_DTYPE)
@@ -276,3 +315,76 @@ class Handle:
         if return_draft:
             return out.raw[:ol.value].decode(), draft.raw[:dl.value].decode()
         return out.raw[:ol.value].decode()
+
+
+def device_count():
+    return int(load().c3_device_count())
+
+
+class HostBatch:
+    """one group of reads held by the native reader (valid until the reader reuses its buffer set)"""
+
+    def __init__(self, c, owner=None):
+        self.c = c
+        self.owner = owner                       # keeps the reader (and its buffers) alive
+        self.n = int(c.n)
+        self.n_short = int(c.n_short)
+        self.off = np.ctypeslib.as_array(C.cast(c.off, C.POINTER(C.c_int64)), shape=(self.n + 1,)).copy()
+        self.name_off = np.ctypeslib.as_array(C.cast(c.name_off, C.POINTER(C.c_int64)), shape=(self.n + 1,)).copy()
+
+    def names(self):
+        raw = C.string_at(self.c.names, int(self.name_off[-1])) if self.n else b""
+        no = self.name_off
+        return [raw[no[i]:no[i + 1]].decode() for i in range(self.n)]
+
+    def read(self, i):
+        """(name, seq, qual) of read i as str -- for tests and small inputs"""
+        no, o = self.name_off, self.off
+        return (C.string_at(self.c.names + int(no[i]), int(no[i + 1] - no[i])).decode(),
+                C.string_at(self.c.seqs + int(o[i]), int(o[i + 1] - o[i])).decode(),
+                C.string_at(self.c.quals + int(o[i]), int(o[i + 1] - o[i])).decode())
+
+
+class Reader:
+    """native streaming FASTA/FASTQ(.gz) reader (c3_reader_*): mm.fastx_read replacement that yields SoA groups"""
+
+    def __init__(self, path, n_sets=3, names_only=False):
+        self.lib = load()
+        self.r = C.c_void_p()
+        if self.lib.c3_reader_open(_b(str(path)), n_sets, C.byref(self.r)) != 0:
+            raise OSError("cannot open %s" % path)
+        if names_only:
+            self.lib.c3_reader_names_only(self.r, 1)
+
+    def next(self, max_reads, min_len=0, max_bases=0):
+        c = HostBatchStruct()
+        rc = self.lib.c3_reader_next(self.r, int(max_reads), int(max_bases), int(min_len), C.byref(c))
+        if rc != 0:
+            raise ValueError("c3_reader_next: %s" % self.lib.c3_reader_error(self.r).decode())
+        return HostBatch(c, self)
+
+    def close(self):
+        if self.r:
+            self.lib.c3_reader_close(self.r)
+            self.r = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def write_group(hb, res, cons_buf, cons_off, splint_ids, cons_paths, sub_paths, zero=True):
+    """c3_write_group: append the consensus / subread records of one group to the per-splint files"""
+    lib = load()
+    n_spl = len(cons_paths)
+    cp = (C.c_char_p * n_spl)(*[_b(p) for p in cons_paths])
+    sp = (C.c_char_p * n_spl)(*[_b(p) for p in sub_paths])
+    sid = np.ascontiguousarray(splint_ids, dtype=np.int16)
+    res = np.ascontiguousarray(res)
+    coff = np.ascontiguousarray(cons_off, dtype=np.int64)
+    rc = lib.c3_write_group(C.byref(hb.c), res.ctypes.data, cons_buf.ctypes.data if cons_buf is not None else None,
+                            coff.ctypes.data, sid.ctypes.data, n_spl, cp, sp, 1 if zero else 0)
+    if rc != 0:
+        raise OSError("c3_write_group failed (%d)" % rc)

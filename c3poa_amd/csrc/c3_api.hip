@@ -19,25 +19,45 @@ extern "C" void c3k_launch_zero(const ZeroArgs*, int, hipStream_t);
 extern "C" void c3k_launch_zero_finish(const ZeroArgs*, int, hipStream_t);
 
 // ---- small kernels ----------------------------------------------------------------------
-__global__ void k_pack(const uint8_t* ascii, const int64_t* off, const int64_t* woff, int n, uint32_t* pk) {
-  // one block per read slice: word w of read r packs bases 16w..16w+15
-  for (int r = blockIdx.y; r < n; r += gridDim.y) {
+__device__ __forceinline__ uint32_t pack_code(uint32_t b) {
+  // A/a=0 C/c=1 G/g=2 T/t/U/u=3, every other byte 0 (c3poa.h conventions)
+  const uint32_t u = b & 0xDFu;                                // upper case
+  const uint32_t c = (u >> 1) & 3u;                            // A0 C1 G3 T2 U2
+  const bool ok = (u == 'A') | (u == 'C') | (u == 'G') | (u == 'T') | (u == 'U');
+  return ok ? (c ^ (c >> 1)) : 0u;
+}
+__global__ __launch_bounds__(256) void k_pack(const uint8_t* ascii, const int64_t* off, const int64_t* woff, int n, uint32_t* pk) {
+  // one wave per read (grid-stride); lane l packs word w = 64*it + l from 16 consecutive bytes (one 16-byte load per
+  // lane -> a wave reads 1 KiB contiguous).  The tail word is assembled byte by byte.
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (int r = wave; r < n; r += n_waves) {
     const int64_t L = off[r + 1] - off[r];
     const int64_t nw = woff[r + 1] - woff[r];
     const uint8_t* s = ascii + off[r];
-    for (int64_t w = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; w < nw; w += (int64_t)gridDim.x * blockDim.x) {
+    uint32_t* dst = pk + woff[r];
+    for (int64_t w = lane; w < nw; w += 64) {
       uint32_t x = 0;
-      for (int k = 0; k < 16; ++k) {
-        int64_t i = w * 16 + k;
-        int c = 0;
-        if (i < L) {
-          switch (s[i]) { case 'C': case 'c': c = 1; break; case 'G': case 'g': c = 2; break;
-                          case 'T': case 't': case 'U': case 'u': c = 3; break; default: c = 0; }
-        }
-        x |= (uint32_t)c << (2 * k);
+      if (w * 16 + 16 <= L) {
+        uint32_t v[4];
+        __builtin_memcpy(v, s + w * 16, 16);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) x |= pack_code((v[k >> 2] >> (8 * (k & 3))) & 0xFFu) << (2 * k);
+      } else {
+        for (int k = 0; k < 16; ++k) { int64_t i = w * 16 + k; if (i < L) x |= pack_code(s[i]) << (2 * k); }
       }
-      pk[woff[r] + w] = x;
+      dst[w] = x;
     }
+  }
+}
+// consensus of read r lives at arena[off[r] ..]; compact copies go to out[coff[r] .. coff[r+1]) (one wave per read)
+__global__ __launch_bounds__(256) void k_gather_cons(const char* arena, const int64_t* off, const int64_t* coff, int n, char* out) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = (gridDim.x * blockDim.x) >> 6;
+  for (int r = wave; r < n; r += n_waves) {
+    const int64_t len = coff[r + 1] - coff[r];
+    const char* src = arena + off[r]; char* dst = out + coff[r];
+    for (int64_t k = lane; k < len; k += 64) dst[k] = src[k];
   }
 }
 __global__ void k_init_info(C3Info* info, int n) {
@@ -84,7 +104,7 @@ struct c3_handle {
   int n_spl = 0, max_spl = 0; std::vector<int> sp_len; DBuf d_sp_codes, d_sp_len;
   // batch
   int n = 0; int64_t total = 0, words = 0, maxL = 0; std::vector<int64_t> off, woff;
-  DBuf d_ascii, d_pk, d_woff, d_qual, d_off, d_strand, d_sid, d_info, d_track, d_draft, d_tpos, d_cons, d_counter;
+  DBuf d_ascii, d_pk, d_woff, d_qual, d_off, d_strand, d_sid, d_info, d_track, d_draft, d_tpos, d_cons, d_counter, d_gather, d_gather_off;
   DBuf d_raw, d_nraw, d_sum, d_work, d_bufA, d_bufB, d_cand, d_cst, d_msa, d_msa_off, d_msa_len;
   DBuf s_poa_i, s_poa_nk, s_poa_cells, s_poa_b, s_poa_sc, s_poa_desc, s_poa_jump;      // POA scratch
   DBuf s_eH, s_eD, s_lw, d_wrec, d_wlay, d_wbase, d_wout;       // prep / windows
@@ -117,6 +137,7 @@ extern "C" void c3_default_config(c3_config* c) {
   c->slots_poa = 0; c->slots_win = 0; c->zero = 1;
 }
 extern "C" const char* c3_version(void) { return "c3poa_amd 0.1 (gfx950)"; }
+extern "C" int c3_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 
 static thread_local std::string g_create_err;
 extern "C" const char* c3_last_error(const c3_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
@@ -152,7 +173,7 @@ extern "C" void c3_destroy(c3_handle* h) {
                  &h->d_info, &h->d_track, &h->d_draft, &h->d_tpos, &h->d_cons, &h->d_counter, &h->d_raw, &h->d_nraw, &h->d_sum,
                  &h->d_work, &h->d_bufA, &h->d_bufB, &h->d_cand, &h->d_cst, &h->d_msa, &h->d_msa_off, &h->d_msa_len,
                  &h->s_poa_i, &h->s_poa_nk, &h->s_poa_cells, &h->s_poa_b, &h->s_poa_sc, &h->s_poa_desc, &h->s_poa_jump, &h->s_eH, &h->s_eD, &h->s_lw, &h->d_wrec,
-                 &h->d_wlay, &h->d_wbase, &h->d_wout, &h->s_win_i, &h->s_win_nk, &h->s_win_h, &h->s_win_d, &h->s_win_b, &h->s_win_sc, &h->s_win_desc, &h->s_zero_d, &h->d_zinfo, &h->d_zflag, &h->d_zwork};
+                 &h->d_wlay, &h->d_wbase, &h->d_wout, &h->s_win_i, &h->s_win_nk, &h->s_win_h, &h->s_win_d, &h->s_win_b, &h->s_win_sc, &h->s_win_desc, &h->s_zero_d, &h->d_zinfo, &h->d_zflag, &h->d_zwork, &h->d_gather, &h->d_gather_off};
   for (DBuf* b : all) b->release();
   for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(h->ev[i]);
   (void)hipStreamDestroy(h->stream);
@@ -232,7 +253,7 @@ extern "C" int c3_batch_upload(c3_handle* h, int n, const char* seqs, const char
   HIPCHK(hipMemcpyAsync(h->d_woff.p, h->woff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d_strand.p, strand, n, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d_sid.p, sid.data(), sizeof(int16_t) * n, hipMemcpyHostToDevice, h->stream));
-  dim3 g(64, (unsigned)std::min(n, 1024));
+  dim3 g((unsigned)std::min((n + 3) / 4, h->n_cus * 32));
   hipLaunchKernelGGL(k_pack, g, dim3(256), 0, h->stream, h->d_ascii.as<uint8_t>(), h->d_off.as<int64_t>(), h->d_woff.as<int64_t>(), n, h->d_pk.as<uint32_t>());
   hipLaunchKernelGGL(k_init_info, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), n);
   HIPCHK(hipEventRecord(h->ev[1], h->stream));
@@ -556,12 +577,17 @@ extern "C" int c3_batch_results(c3_handle* h, c3_read_result* res, char* cons, i
   if (!cons) return C3_E_OK;
   if (cons_off[h->n] > cons_cap) return c3_fail(h, C3_E_LIMIT, "consensus buffer too small");
   if (!(h->stages_done & C3_STAGE_POLISH)) return C3_E_OK;
-  // gather: one device->host copy of the arena, then compaction on the host
-  std::vector<char> arena((size_t)h->total + 1);
-  HIPCHK(hipMemcpyAsync(arena.data(), h->d_cons.p, (size_t)h->total, hipMemcpyDeviceToHost, h->stream));
+  // gather on the device (one wave per read), then ONE device->host copy of the compact bytes into the caller's buffer
+  const int64_t tot = cons_off[h->n];
+  if (tot == 0) return C3_E_OK;
+  DBuf& d_coff = h->d_gather_off; DBuf& d_out = h->d_gather;
+  HIPCHK(d_coff.ensure(sizeof(int64_t) * (size_t)(h->n + 1))); HIPCHK(d_out.ensure((size_t)tot + 64));
+  HIPCHK(hipMemcpyAsync(d_coff.p, cons_off, sizeof(int64_t) * (size_t)(h->n + 1), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(k_gather_cons, dim3((unsigned)std::min((h->n + 3) / 4, h->n_cus * 32)), dim3(256), 0, h->stream,
+                     h->d_cons.as<char>(), h->d_off.as<int64_t>(), d_coff.as<int64_t>(), h->n, d_out.as<char>());
+  HIPCHK(hipMemcpyAsync(cons, d_out.p, (size_t)tot, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  for (int i = 0; i < h->n; ++i)
-    if (res[i].status == C3_ST_OK && res[i].cons_len > 0) memcpy(cons + cons_off[i], arena.data() + h->off[i], (size_t)res[i].cons_len);
+  HIPCHK(hipGetLastError());
   return C3_E_OK;
 }
 

@@ -1,0 +1,340 @@
+// c3_io.cpp -- native host I/O either side of the hot path: streaming FASTA/FASTQ(.gz) reader that
+// fills structure-of-arrays host batches in page-locked memory (so c3_batch_upload copies them by DMA), and the writer
+// of the reference's two per-group output files.  Host code only: no kernels here, nothing here touches the oracle.
+//
+//   c3_reader_*      replaces mm.fastx_read(args.reads, read_comment=False)   (C3POa.py:201,239; kseq.h semantics)
+//   c3_write_group   replaces the file side effects of analyze_reads + determine_consensus
+//                    (C3POa.py:141-173, bin/determine_consensus.py:57-77,108-114)
+#include <hip/hip_runtime.h>
+#include <zlib.h>
+
+#include <fcntl.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/c3poa.h"
+
+namespace {
+
+// ---- growable host buffer, page-locked when a GPU runtime is present (plain malloc otherwise: pinning is a transfer
+//      optimisation, not a compute path) -------------------------------------------------------------------------
+struct HostBuf {
+  char* p = nullptr; size_t cap = 0; bool pinned = false;
+  ~HostBuf() { release(); }
+  void release() {
+    if (!p) return;
+    if (pinned) (void)hipHostFree(p); else free(p);
+    p = nullptr; cap = 0;
+  }
+  bool reserve(size_t need, size_t keep) {
+    if (need <= cap) return true;
+    size_t ncap = cap ? cap : (size_t)1 << 20;
+    while (ncap < need) ncap += ncap / 2;
+    char* q = nullptr; bool pin = false;
+    static int can_pin = -1;
+    if (can_pin < 0) { int n = 0; can_pin = (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? 1 : 0; (void)hipGetLastError(); }
+    if (can_pin && hipHostMalloc((void**)&q, ncap, hipHostMallocDefault) == hipSuccess) pin = true;
+    else { (void)hipGetLastError(); q = (char*)malloc(ncap); }
+    if (getenv("C3_DEBUG")) fprintf(stderr, "[c3_io] host buffer %zu MiB %s\n", ncap >> 20, pin ? "page-locked" : "pageable");
+    if (!q) return false;
+    if (keep) memcpy(q, p, keep);
+    release();
+    p = q; cap = ncap; pinned = pin;
+    return true;
+  }
+};
+
+struct BatchSet {
+  HostBuf names, seqs, quals;
+  std::vector<int64_t> name_off, off;
+  size_t n_names = 0, n_bases = 0;
+};
+
+}  // namespace
+
+struct c3_reader {
+  FILE* fp = nullptr; gzFile gz = nullptr;
+  std::vector<char> buf; size_t beg = 0, end = 0; bool eof = false;
+  std::vector<BatchSet> sets; int cur = -1;
+  std::string err;
+  bool have_line = false; const char* lp = nullptr; size_t ll = 0;   // one line of look-ahead
+  int64_t n_records = 0;
+  bool names_only = false;
+  size_t file_bytes = 0, hint_bases = 0;
+};
+
+namespace {
+
+bool refill(c3_reader* r) {
+  if (r->eof) return false;
+  if (r->beg > 0) { memmove(r->buf.data(), r->buf.data() + r->beg, r->end - r->beg); r->end -= r->beg; r->beg = 0; }
+  if (r->end == r->buf.size()) r->buf.resize(r->buf.size() * 2);
+  size_t room = r->buf.size() - r->end;
+  long got = r->gz ? (long)gzread(r->gz, r->buf.data() + r->end, (unsigned)std::min<size_t>(room, 1u << 30))
+                   : (long)fread(r->buf.data() + r->end, 1, room, r->fp);
+  if (got <= 0) { r->eof = true; return false; }
+  r->end += (size_t)got;
+  return true;
+}
+
+// next line without its terminator ('\n', optional '\r'); pointer valid until the next call
+bool next_line(c3_reader* r, const char** p, size_t* len) {
+  if (r->have_line) { r->have_line = false; *p = r->lp; *len = r->ll; return true; }
+  size_t scanned = 0;                             // bytes from beg already known to hold no newline
+  for (;;) {
+    char* base = r->buf.data() + r->beg;
+    const size_t avail = r->end - r->beg;
+    const char* nl = (const char*)memchr(base + scanned, '\n', avail - scanned);
+    if (nl) {
+      size_t l = (size_t)(nl - base);
+      *p = base; r->beg += l + 1;
+      if (l && base[l - 1] == '\r') --l;
+      *len = l;
+      return true;
+    }
+    scanned = avail;
+    if (!refill(r)) {                             // refill keeps [beg,end) intact (moved to the front)
+      if (r->end > r->beg) {                      // last line without terminator
+        base = r->buf.data() + r->beg;
+        size_t l = r->end - r->beg;
+        *p = base; r->beg = r->end;
+        if (l && base[l - 1] == '\r') --l;
+        *len = l;
+        return true;
+      }
+      return false;
+    }
+  }
+}
+void unget_line(c3_reader* r, const char* p, size_t len) { r->have_line = true; r->lp = p; r->ll = len; }
+
+int fail(c3_reader* r, const char* msg) { r->err = msg; return C3_E_ARG; }
+
+}  // namespace
+
+extern "C" int c3_reader_open(const char* path, int n_sets, c3_reader** out) {
+  if (!path || !out) return C3_E_ARG;
+  c3_reader* r = new c3_reader();
+  size_t n = strlen(path);
+  if (n > 3 && strcmp(path + n - 3, ".gz") == 0) { r->gz = gzopen(path, "rb"); if (r->gz) gzbuffer(r->gz, 1 << 20); }
+  else r->fp = fopen(path, "rb");
+  if (!r->gz && !r->fp) { delete r; return C3_E_ARG; }
+  { FILE* f = fopen(path, "rb"); if (f) { fseek(f, 0, SEEK_END); long z = ftell(f); r->file_bytes = z > 0 ? (size_t)z : 0; fclose(f); } }
+  r->buf.resize((size_t)16 << 20);
+  r->sets.resize((size_t)std::max(1, n_sets));
+  *out = r;
+  return C3_E_OK;
+}
+
+extern "C" void c3_reader_close(c3_reader* r) {
+  if (!r) return;
+  if (r->gz) gzclose(r->gz);
+  if (r->fp) fclose(r->fp);
+  delete r;
+}
+
+// names_only != 0: sequences and qualities are parsed (lengths, offsets and the short-read count stay exact) but not
+// stored -- the first pass of C3POa.py:200-207 only needs names
+extern "C" void c3_reader_names_only(c3_reader* r, int names_only) { if (r) r->names_only = names_only != 0; }
+
+extern "C" const char* c3_reader_error(const c3_reader* r) { return r ? r->err.c_str() : "null reader"; }
+
+// One group of reads.  Records shorter than min_len are skipped and counted in out->n_short (C3POa.py:202-204,240-241).
+// Stops after max_reads kept reads or once max_bases kept bases are exceeded (0 = no limit).  out->n == 0 at end of file.
+extern "C" int c3_reader_next(c3_reader* r, int max_reads, int64_t max_bases, int min_len, c3_host_batch* out) {
+  if (!r || !out || max_reads <= 0) return C3_E_ARG;
+  r->cur = (r->cur + 1) % (int)r->sets.size();
+  BatchSet& s = r->sets[(size_t)r->cur];
+  s.name_off.assign(1, 0); s.off.assign(1, 0);
+  if (!r->names_only && r->hint_bases) {
+    // later sets are allocated once, with the size the previous groups needed (growth by copying only for the first)
+    const size_t want = r->hint_bases + r->hint_bases / 8 + 4096;
+    if (!s.seqs.reserve(want, 0) || !s.quals.reserve(want, 0)) return C3_E_NOMEM;
+  }
+  size_t nn = 0, nb = 0; int n = 0; int64_t n_short = 0;
+  const char* p; size_t l;
+  while (n < max_reads && (max_bases <= 0 || (int64_t)nb < max_bases)) {
+    if (!next_line(r, &p, &l)) break;
+    if (l == 0) continue;
+    if (p[0] != '>' && p[0] != '@') return fail(r, "not FASTA/FASTQ: record does not start with '>' or '@'");
+    // name = header up to the first blank (read_comment=False)
+    size_t nl = 1; while (nl < l && p[nl] != ' ' && p[nl] != '\t') ++nl;
+    if (!s.names.reserve(nn + nl, nn)) return C3_E_NOMEM;
+    memcpy(s.names.p + nn, p + 1, nl - 1);
+    const size_t name_len = nl - 1;
+    // sequence lines until a line that starts with '>', '@' or '+' (kseq.h)
+    const size_t sb = nb; size_t sl = 0; bool plus = false;
+    while (next_line(r, &p, &l)) {
+      if (l && (p[0] == '>' || p[0] == '@')) { unget_line(r, p, l); break; }
+      if (l && p[0] == '+') { plus = true; break; }
+      if (!r->names_only) {
+        if (!s.seqs.reserve(sb + sl + l + 16, sb + sl)) return C3_E_NOMEM;
+        memcpy(s.seqs.p + sb + sl, p, l);
+      }
+      sl += l;
+    }
+    if (!r->names_only && !s.quals.reserve(sb + sl + 16, sb)) return C3_E_NOMEM;
+    if (plus) {
+      size_t ql = 0;
+      while (ql < sl && next_line(r, &p, &l)) {
+        if (ql + l > sl) return fail(r, "quality string longer than the sequence");
+        if (!r->names_only) memcpy(s.quals.p + sb + ql, p, l);
+        ql += l;
+      }
+      if (ql != sl) return fail(r, "truncated quality string");
+    } else if (!r->names_only) {
+      memset(s.quals.p + sb, '!', sl);           // FASTA record: no qualities -> Phred 0
+    }
+    ++r->n_records;
+    if ((int64_t)sl < (int64_t)min_len) { ++n_short; continue; }     // dropped: buffers are simply overwritten
+    nn += name_len; nb += sl; ++n;
+    s.name_off.push_back((int64_t)nn); s.off.push_back((int64_t)nb);
+  }
+  s.n_names = nn; s.n_bases = nb;
+  r->hint_bases = std::max(r->hint_bases, nb);
+  out->n = n; out->n_short = n_short;
+  out->names = s.names.p; out->name_off = s.name_off.data();
+  out->seqs = s.seqs.p; out->quals = s.quals.p; out->off = s.off.data();
+  return C3_E_OK;
+}
+
+// ---- writer ------------------------------------------------------------------------------------------------------
+namespace {
+
+// str(round(sum / n, 2)) of Python: correctly rounded to 2 decimals, then the shortest repr (trailing zeros dropped,
+// one decimal kept) -- C3POa.py:168
+void avg_qual_text(const char* q, int64_t n, std::string& out) {
+  long long sum = 0;
+  for (int64_t i = 0; i < n; ++i) sum += (unsigned char)q[i] - 33;
+  char tmp[64];
+  int k = snprintf(tmp, sizeof(tmp), "%.2f", (double)sum / (double)n);
+  while (k > 0 && tmp[k - 1] == '0' && k >= 2 && tmp[k - 2] != '.') --k;
+  out.append(tmp, (size_t)k);
+}
+
+void fastq(std::string& o, const char* name, size_t nl, long idx, const char* s, const char* q, int64_t b, int64_t e) {
+  o.push_back('@'); o.append(name, nl); o.push_back('_'); o += std::to_string(idx); o.push_back('\n');
+  o.append(s + b, (size_t)(e - b)); o.append("\n+\n", 3); o.append(q + b, (size_t)(e - b)); o.push_back('\n');
+}
+
+}  // namespace
+
+namespace {
+
+// records of reads [i0, i1) appended to fa[s] / fq[s] (one string pair per splint)
+void format_range(const c3_host_batch* b, const c3_read_result* res, const char* cons, const int64_t* cons_off,
+                  const int16_t* splint_id, int n_splints, int zero, int i0, int i1,
+                  std::vector<std::string>& oc, std::vector<std::string>& os) {
+  for (int i = i0; i < i1; ++i) {
+    const c3_read_result& r = res[i];
+    const int s = splint_id[i];
+    if (s < 0 || s >= n_splints) continue;
+    if (r.status == C3_ST_NOT_ASSIGNED || r.status == C3_ST_NO_PEAKS || r.status == C3_ST_TOO_SHORT) continue;   // C3POa.py:115,125,131
+    const char* name = b->names + b->name_off[i]; const size_t nl = (size_t)(b->name_off[i + 1] - b->name_off[i]);
+    const char* seq = b->seqs + b->off[i]; const char* qual = b->quals + b->off[i];
+    const int64_t L = b->off[i + 1] - b->off[i];
+    const int64_t clen = cons ? cons_off[i + 1] - cons_off[i] : 0;
+    const int ns = r.n_sub, nd = (r.has_front ? 1 : 0) + (r.has_tail ? 1 : 0);
+    std::string& fq = os[(size_t)s];
+    bool emit = false;
+    if (ns == 0) {
+      if (!(zero && nd == 2)) continue;
+      fastq(fq, name, nl, 0, seq, qual, 0, r.front_end);
+      fastq(fq, name, nl, 1, seq, qual, r.tail_beg, L);
+      emit = (r.status == C3_ST_OK && clen > 0);
+    } else {
+      if (r.status == C3_ST_LIMIT) continue;
+      for (int k = 0; k < ns; ++k) fastq(fq, name, nl, k + 1, seq, qual, r.sub_beg[k], r.sub_end[k]);
+      int j = 0;
+      if (r.has_front) { fastq(fq, name, nl, 0, seq, qual, 0, r.front_end); ++j; }
+      if (r.has_tail) fastq(fq, name, nl, j == 0 ? 0 : ns + 1, seq, qual, r.tail_beg, L);
+      emit = (r.status == C3_ST_OK && clen > 0);
+    }
+    if (emit) {
+      std::string& fa = oc[(size_t)s];
+      fa.push_back('>'); fa.append(name, nl); fa.push_back('_');
+      avg_qual_text(qual, L, fa);
+      fa.push_back('_'); fa += std::to_string((long long)L); fa.push_back('_'); fa += std::to_string(ns);
+      fa.push_back('_'); fa += std::to_string((long long)clen); fa.push_back('\n');
+      fa.append(cons + cons_off[i], (size_t)clen); fa.push_back('\n');
+    }
+  }
+}
+
+bool pwrite_all(int fd, const char* p, size_t n, off_t at) {
+  while (n) {
+    ssize_t w = pwrite(fd, p, n, at);
+    if (w < 0) { if (errno == EINTR) continue; return false; }
+    p += w; n -= (size_t)w; at += w;
+  }
+  return true;
+}
+
+}  // namespace
+
+// Appends the records of one group to <cons_paths[s]> / <sub_paths[s]> (s = splint_id[i]; reads with splint_id < 0 or a
+// status that produces no output are skipped).  Record formats and the subread naming asymmetry follow the reference:
+// kept subreads _1.._n, first dangling piece _0, second _<n+1> (determine_consensus.py:57-62,69-77); zero-repeat pieces
+// _0,_1 are written before the rescue is tried (:108-114); consensus header name_avgQ_rawLen_repeats_consLen (C3POa.py:168-171).
+// The group is cut into contiguous read ranges that are formatted and written (pwrite at precomputed offsets) by a few
+// threads: record order in the files is read order, exactly as with one thread.
+extern "C" int c3_write_group(const c3_host_batch* b, const c3_read_result* res, const char* cons, const int64_t* cons_off,
+                              const int16_t* splint_id, int n_splints, const char* const* cons_paths,
+                              const char* const* sub_paths, int zero) {
+  if (!b || !res || !cons_off || !splint_id || n_splints <= 0 || !cons_paths || !sub_paths) return C3_E_ARG;
+  int T = 1;
+  if (b->n >= 4096) { T = 6; if (const char* e = getenv("C3_WRITER_THREADS")) T = std::max(1, std::min(32, atoi(e))); }
+  typedef std::vector<std::string> Strs;
+  std::vector<Strs> oc((size_t)T, Strs((size_t)n_splints)), os((size_t)T, Strs((size_t)n_splints));
+  // phase 1: format (parallel)
+  {
+    std::vector<std::thread> th;
+    for (int k = 0; k < T; ++k) {
+      const int i0 = (int)((int64_t)b->n * k / T), i1 = (int)((int64_t)b->n * (k + 1) / T);
+      auto fn = [&, k, i0, i1]() { format_range(b, res, cons, cons_off, splint_id, n_splints, zero, i0, i1, oc[(size_t)k], os[(size_t)k]); };
+      if (k + 1 < T) th.emplace_back(fn); else fn();
+    }
+    for (auto& x : th) x.join();
+  }
+  // phase 2: one pwrite stream per (thread, file), offsets from the current file size
+  struct Job { int fd; const std::string* txt; off_t at; };
+  std::vector<std::vector<Job>> jobs((size_t)T);
+  std::vector<int> fds;
+  bool ok = true;
+  for (int s = 0; s < n_splints && ok; ++s) {
+    for (int kind = 0; kind < 2 && ok; ++kind) {
+      const char* path = kind ? sub_paths[s] : cons_paths[s];
+      size_t total = 0;
+      for (int k = 0; k < T; ++k) total += (kind ? os : oc)[(size_t)k][(size_t)s].size();
+      if (!total || !path) continue;
+      int fd = open(path, O_WRONLY | O_CREAT, 0644);
+      if (fd < 0) { ok = false; break; }
+      fds.push_back(fd);
+      off_t at = lseek(fd, 0, SEEK_END);
+      for (int k = 0; k < T; ++k) {
+        const std::string& x = (kind ? os : oc)[(size_t)k][(size_t)s];
+        if (!x.empty()) { jobs[(size_t)k].push_back({fd, &x, at}); at += (off_t)x.size(); }
+      }
+    }
+  }
+  if (ok) {
+    std::vector<char> good((size_t)T, 1);
+    std::vector<std::thread> th;
+    for (int k = 0; k < T; ++k) {
+      auto fn = [&, k]() { for (const Job& j : jobs[(size_t)k]) if (!pwrite_all(j.fd, j.txt->data(), j.txt->size(), j.at)) good[(size_t)k] = 0; };
+      if (k + 1 < T) th.emplace_back(fn); else fn();
+    }
+    for (auto& x : th) x.join();
+    for (char g : good) ok = ok && g;
+  }
+  for (int fd : fds) if (close(fd) != 0) ok = false;
+  return ok ? C3_E_OK : C3_E_ARG;
+}

@@ -1,0 +1,166 @@
+"""Streaming driver of the CLI: native FASTQ reader -> GPU batches -> native writer.
+
+Replaces the read loop / mp.Pool dispatch / per-group temp files of /root/reference/C3POa.py:236-271 with a software
+pipeline that keeps every GPU busy: while batch i runs on the device (c3_batch_run is asynchronous), the host parses
+batch i+1 and writes the records of batch i-1.  No per-read Python objects are created for sequences or qualities: the
+reader fills page-locked SoA buffers that c3_batch_upload copies by DMA and c3_write_group slices for the subread file.
+
+The reference's -g (group size) only decides how reads are partitioned into <splint>/tmp<k>/ directories that are
+concatenated and deleted at the end (C3POa.py:259-271); here a GPU batch is max(-g, GPU_BATCH_READS) reads and records
+are appended to the final files directly (same output tree, no double write).
+"""
+import gzip
+import os
+import queue
+import shutil
+import sys
+import threading
+import time
+
+import numpy as np
+
+from . import _lib
+
+GPU_BATCH_READS = 131072         # enough reads to fill 256 CUs many times over (bench.py runs 100 000 per step)
+HANDLES_PER_GPU = 1              # measured: two handles per GPU make the persistent kernels fight for CUs (0.55x)
+GPU_BATCH_BASES = 1 << 30        # bound on host/device memory per batch
+
+
+def scan_names(path, lencutoff):
+    """first pass of C3POa.py:200-207: names of the reads that pass the length cut-off, number of short reads"""
+    rd = _lib.Reader(path, n_sets=1, names_only=True)
+    names, short = [], 0
+    while True:
+        hb = rd.next(GPU_BATCH_READS, lencutoff, GPU_BATCH_BASES)
+        short += hb.n_short
+        if hb.n == 0:
+            break
+        names.extend(hb.names())
+    rd.close()
+    return names, short
+
+
+def assign(hb, adapter_dict, sid_of):
+    """per-read splint row / strand of a host batch from the PSL assignment (C3POa.py:115-122)"""
+    n = hb.n
+    sid = np.full(n, -1, dtype=np.int16)
+    st = bytearray(b"?" * n)
+    for i, name in enumerate(hb.names()):
+        ad = adapter_dict.get(name)
+        if ad:
+            sid[i] = sid_of[ad[0]]
+            st[i] = 45 if ad[1] == "-" else 43
+    return sid, bytes(st)
+
+
+def run(args, splint_dict, adapter_dict, adapter_set=None, n_dev=1, stats=None):
+    """the second pass of C3POa.py:236-271.  returns the number of reads sent to the GPUs."""
+    splint_names = sorted(splint_dict)
+    sid_of = {n: i for i, n in enumerate(splint_names)}
+    compress = bool(getattr(args, "compress_output", False))
+    cons_paths = [args.out_path + n + "/R2C2_Consensus.fasta" for n in splint_names]
+    sub_paths = [args.out_path + n + "/R2C2_Subreads.fastq" for n in splint_names]
+    used = set(v[0] for v in adapter_dict.values()) | set(adapter_set or ())   # cat_files runs per adapter_set entry (C3POa.py:259)
+    for n, cp, sp in zip(splint_names, cons_paths, sub_paths):
+        if n in used:
+            os.makedirs(args.out_path + n, exist_ok=True)
+            for p in (cp, sp):                                   # "w+" semantics of cat_files (C3POa.py:88-92)
+                open(p, "w").close()
+                if os.path.exists(p + ".gz"):
+                    os.remove(p + ".gz")
+    batch_reads = max(int(args.groupSize), GPU_BATCH_READS)
+    n_work = n_dev * int(os.environ.get("C3_HANDLES_PER_GPU", HANDLES_PER_GPU))
+    n_sets = 2 * n_work + 3
+    rd = _lib.Reader(args.reads, n_sets=n_sets)
+    tokens = threading.Semaphore(n_sets - 1)        # a buffer set is reused only after its group has been written
+    parsed, to_write = queue.Queue(maxsize=n_work), queue.Queue(maxsize=n_work)
+    t = dict(parse=0.0, assign=0.0, upload=0.0, upload_dev=0.0, run=0.0, run_dev=0.0, fetch=0.0, write=0.0, reads=0, batches=0)
+    errors, lock = [], threading.Lock()
+
+    def reader_thread():                            # parse + splint/strand lookup, ahead of the GPUs
+        try:
+            while not errors:
+                tokens.acquire()
+                t0 = time.perf_counter()
+                hb = rd.next(batch_reads, args.lencutoff, GPU_BATCH_BASES)
+                t1 = time.perf_counter()
+                if hb.n == 0:
+                    break
+                sid, st = assign(hb, adapter_dict, sid_of)
+                t["parse"] += t1 - t0; t["assign"] += time.perf_counter() - t1
+                t["reads"] += hb.n; t["batches"] += 1
+                parsed.put((hb, sid, st))
+        except Exception as e:                      # noqa: BLE001 -- re-raised by the caller's thread
+            errors.append(e)
+        for _ in range(n_work):
+            parsed.put(None)
+
+    def device_thread(dev):                         # one per GPU: c3_batch_run sizes its stages on the host, so it blocks
+        try:
+            h = _lib.Handle(device=dev, mdistcutoff=args.mdistcutoff, zero=1 if getattr(args, "zero", True) else 0)
+            h.set_splints([splint_dict[n][0] for n in splint_names])
+            while True:
+                item = parsed.get()
+                if item is None:
+                    break
+                if errors:
+                    continue
+                hb, sid, st = item
+                t0 = time.perf_counter()
+                h.upload_host(hb, st, np.maximum(sid, 0))
+                t1 = time.perf_counter()
+                up_dev = h.timing()["ms_pack"] * 1e-3
+                h.run()
+                t2 = time.perf_counter()
+                res, buf, coff = h.results_raw()
+                t3 = time.perf_counter()
+                with lock:
+                    t["upload_dev"] += up_dev; t["run_dev"] += h.timing()["ms_total"] * 1e-3
+                    t["upload"] += t1 - t0; t["run"] += t2 - t1; t["fetch"] += t3 - t2
+                to_write.put((hb, sid, res, buf, coff))
+            h.close()
+        except Exception as e:                      # noqa: BLE001
+            errors.append(e)
+            while parsed.get() is not None:
+                pass
+        to_write.put(None)
+
+    def writer_thread():                            # c3_write_group releases the GIL: overlaps parsing and the GPUs
+        live = n_work
+        while live:
+            item = to_write.get()
+            if item is None:
+                live -= 1
+                continue
+            hb, sid, res, buf, coff = item
+            t0 = time.perf_counter()
+            try:
+                if not errors:
+                    _lib.write_group(hb, res, buf, coff, sid, cons_paths, sub_paths, getattr(args, "zero", True))
+            except Exception as e:                  # noqa: BLE001
+                errors.append(e)
+            t["write"] += time.perf_counter() - t0
+            del hb, item
+            tokens.release()
+
+    threads = [threading.Thread(target=reader_thread, daemon=True), threading.Thread(target=writer_thread, daemon=True)]
+    threads += [threading.Thread(target=device_thread, args=(w % n_dev,), daemon=True) for w in range(n_work)]
+    for th in threads:
+        th.start()
+    for th in threads[1:]:
+        th.join()
+    if errors:
+        raise errors[0]
+    threads[0].join()
+    rd.close()
+    if compress:                                                        # -co (C3POa.py:88-90)
+        for p in cons_paths + sub_paths:
+            if os.path.exists(p):
+                with open(p, "rb") as src, gzip.open(p + ".gz", "wb", compresslevel=6) as dst:
+                    shutil.copyfileobj(src, dst, 1 << 24)
+                os.remove(p)
+    if stats is not None:
+        stats.update(t)
+    if os.environ.get("C3_STREAM_STATS"):
+        print("stream: " + " ".join("%s=%.3f" % (k, v) if isinstance(v, float) else "%s=%d" % (k, v) for k, v in t.items()), file=sys.stderr)
+    return t["reads"]

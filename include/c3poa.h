@@ -83,6 +83,8 @@ typedef struct c3_handle c3_handle;
 
 void c3_default_config(c3_config* cfg);
 const char* c3_version(void);
+/* GPUs visible to the process (0 without a GPU); -n of the CLI is clamped to it (C3POa.py:236 sized a process pool) */
+int c3_device_count(void);
 
 /* lifecycle.  Replaces the per-task worker process of C3POa.py:236 (mp.Pool, maxtasksperchild=1). */
 int c3_create(const c3_config* cfg, c3_handle** out);
@@ -160,6 +162,39 @@ int c3_scan_splints(c3_handle* h, int32_t* out, int16_t* assign_splint, char* as
  * stitched sequence is shorter than min_len (args.mdistcutoff, determine_consensus.py:17). */
 int c3_zero_repeats(c3_handle* h, const char* d0, const char* q0, int n0, const char* d1, const char* q1, int n1,
                     int min_len, char* out, int cap, int* out_len);
+
+/* ---- host I/O either side of the path; host code only, works without a GPU ---- */
+
+/* one group of reads in structure-of-arrays form; the buffers belong to the reader (page-locked when a GPU is
+ * present, so c3_batch_upload(h, b.n, b.seqs, b.quals, b.off, ...) copies them by DMA) */
+typedef struct {
+  int32_t n;                 /* reads in the group */
+  int64_t n_short;           /* records skipped because they were shorter than min_len */
+  const char* names;         /* concatenated names, name_off[n+1] (name = header up to the first blank) */
+  const int64_t* name_off;
+  const char* seqs;          /* concatenated bases / qualities, off[n+1] */
+  const char* quals;         /* FASTA records get '!' */
+  const int64_t* off;
+} c3_host_batch;
+
+typedef struct c3_reader c3_reader;
+/* mm.fastx_read(path, read_comment=False) (C3POa.py:201,239): FASTA or FASTQ, multi-line, plain or .gz.
+ * n_sets = how many groups stay valid at once (the buffers of a group are reused n_sets calls later). */
+int c3_reader_open(const char* path, int n_sets, c3_reader** out);
+void c3_reader_close(c3_reader* r);
+const char* c3_reader_error(const c3_reader* r);
+/* names_only != 0: parse but do not store sequences/qualities (first pass of C3POa.py:200-207: names + counts) */
+void c3_reader_names_only(c3_reader* r, int names_only);
+/* next group: at most max_reads reads of length >= min_len (C3POa.py:202-204,240-241), stops early once max_bases
+ * bases are held (0 = no limit).  out->n == 0 at end of file. */
+int c3_reader_next(c3_reader* r, int max_reads, int64_t max_bases, int min_len, c3_host_batch* out);
+
+/* file side effects of analyze_reads + determine_consensus for one group (C3POa.py:141-173,
+ * bin/determine_consensus.py:57-77,108-114): appends the consensus FASTA records to cons_paths[splint_id[i]] and the
+ * subread FASTQ records to sub_paths[splint_id[i]].  cons/cons_off as returned by c3_batch_results; zero = args.zero. */
+int c3_write_group(const c3_host_batch* b, const c3_read_result* res, const char* cons, const int64_t* cons_off,
+                   const int16_t* splint_id, int n_splints, const char* const* cons_paths,
+                   const char* const* sub_paths, int zero);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,204 @@
+"""CPU tests of the native host I/O either side of the path (c3_reader_*, c3_write_group).
+The reader is checked against the Python mirror of mm.fastx_read, the writer against the Python record formatter
+whose formats are pinned by the golden `header` / `dispatch` cases captured from the reference."""
+import gzip
+import os
+import types
+
+import numpy as np
+import pytest
+
+from c3poa_amd import _lib, analyze, synth
+from c3poa_amd.seqio import fastx_read
+
+
+def _write_fastq(path, recs, opener=open, mode="w"):
+    with opener(path, mode) as fh:
+        for r in recs:
+            fh.write("@%s extra words\n%s\n+\n%s\n" % (r[0], r[1], r[2]))
+
+
+def _all(path, group, min_len=0, max_bases=0, sets=2):
+    rd = _lib.Reader(path, n_sets=sets)
+    out, short, sizes = [], 0, []
+    while True:
+        hb = rd.next(group, min_len, max_bases)
+        short += hb.n_short
+        if hb.n == 0:
+            break
+        sizes.append(hb.n)
+        out += [hb.read(i) for i in range(hb.n)]
+    rd.close()
+    return out, short, sizes
+
+
+def test_reader_matches_python_fastx(tmp_path):
+    recs = [(r[0], r[1], r[2]) for r in synth.generate("cfg1", n_reads=23)]
+    p = str(tmp_path / "a.fastq")
+    _write_fastq(p, recs)
+    got, short, sizes = _all(p, 10)
+    assert got == list(fastx_read(p)) == recs and short == 0 and sizes == [10, 10, 3]
+    pz = str(tmp_path / "a.fastq.gz")
+    _write_fastq(pz, recs, gzip.open, "wt")
+    assert _all(pz, 7)[0] == recs
+    # length cut-off: skipped reads are counted, groups still hold `group` kept reads (C3POa.py:202-204,240-241)
+    lens = sorted(len(r[1]) for r in recs)
+    cut = lens[5]
+    got, short, sizes = _all(p, 6, min_len=cut)
+    assert short == 5 and got == [r for r in recs if len(r[1]) >= cut] and sizes == [6, 6, 6]
+    # max_bases closes a group early
+    got, _s, sizes = _all(p, 1000, max_bases=3 * lens[-1])
+    assert got == recs and len(sizes) > 3
+
+
+def test_reader_formats_and_edge_cases(tmp_path):
+    p = tmp_path / "m.fa"
+    p.write_text(">s1 desc\tmore\nAC\nGT\n\n>s2\nTTT\r\n>s3\n>s4\tx\nGG")            # multi-line, CRLF, empty record, no final newline
+    got, _s, _z = _all(str(p), 10)
+    assert got == [("s1", "ACGT", "!!!!"), ("s2", "TTT", "!!!"), ("s3", "", ""), ("s4", "GG", "!!")]
+    assert [(n, s) for n, s, _q in got] == [(n, s) for n, s, _q in fastx_read(str(p))]
+    q = tmp_path / "m.fq"
+    q.write_text("@a\nACGT\nAC\n+a\n@III\nI@\n@b c\nGG\n+\n@@\n")                      # multi-line FASTQ, '@' inside qualities
+    assert _all(str(q), 10)[0] == [("a", "ACGTAC", "@IIII@"), ("b", "GG", "@@")]
+    e = tmp_path / "empty.fq"
+    e.write_text("")
+    assert _all(str(e), 10) == ([], 0, [])
+    bad = tmp_path / "bad.fq"
+    bad.write_text("@a\nACGT\n+\nII\n")
+    with pytest.raises(ValueError):
+        _all(str(bad), 10)
+    bad.write_text("ACGT\n")
+    with pytest.raises(ValueError):
+        _all(str(bad), 10)
+    with pytest.raises(OSError):
+        _lib.Reader(str(tmp_path / "missing.fq"))
+
+
+def test_reader_long_lines_cross_buffer_refills(tmp_path):
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(5):
+        L = int(rng.integers(5_000_000, 9_000_000))                                   # > 16 MiB of lines in total, one > buffer/2
+        s = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, L)].tobytes().decode()
+        recs.append(("long%d" % i, s, "5" * L))
+    p = str(tmp_path / "long.fastq")
+    _write_fastq(p, recs)
+    got, _s, _z = _all(p, 2, sets=1)
+    assert [(n, len(s), len(q)) for n, s, q in got] == [(n, len(s), len(q)) for n, s, q in recs]
+    assert all(g[1] == r[1] for g, r in zip(got, recs))
+
+
+def _fake_results(rng, hb):
+    """result records covering every branch of the writer"""
+    res = np.zeros(hb.n, dtype=_lib.RESULT_DTYPE)
+    cons = []
+    for i in range(hb.n):
+        L = int(hb.off[i + 1] - hb.off[i])
+        kind = i % 9
+        r = res[i]
+        r["status"] = [_lib.ST_OK, _lib.ST_OK, _lib.ST_NO_PEAKS, _lib.ST_NOT_ASSIGNED, _lib.ST_NO_CONSENSUS,
+                       _lib.ST_LIMIT, _lib.ST_OK, _lib.ST_NO_CONSENSUS, _lib.ST_TOO_SHORT][kind]
+        ns = [3, 1, 0, 0, 2, 2, 0, 0, 0][kind]
+        cuts = np.sort(rng.choice(np.arange(10, L - 10), size=ns + 1, replace=False))
+        r["n_sub"] = ns
+        for k in range(ns):
+            r["sub_beg"][k], r["sub_end"][k] = cuts[k], cuts[k + 1]
+        front, tail = [(1, 1), (0, 1), (0, 0), (1, 1), (1, 0), (1, 1), (1, 1), (1, 1), (0, 0)][kind]
+        r["has_front"], r["has_tail"] = front, tail
+        r["front_end"], r["tail_beg"] = cuts[0], cuts[-1]
+        if kind in (6, 7) and ns == 0:
+            r["front_end"], r["tail_beg"] = L // 3, 2 * L // 3
+        c = "".join("ACGT"[j] for j in rng.integers(0, 4, int(rng.integers(50, 400)))) if r["status"] == _lib.ST_OK else ""
+        cons.append(c)
+    return res, cons
+
+
+@pytest.mark.parametrize("zero", [True, False])
+def test_writer_matches_python_records(tmp_path, zero):
+    rng = np.random.default_rng(11)
+    recs = [(r[0], r[1], r[2]) for r in synth.generate("cfg1", n_reads=45)]
+    recs[7] = (recs[7][0], recs[7][1], "I" * len(recs[7][1]))                       # avg qual 40.0
+    recs[8] = (recs[8][0], recs[8][1], "!" * len(recs[8][1]))                       # avg qual 0.0
+    p = str(tmp_path / "a.fastq")
+    _write_fastq(p, recs)
+    hb = _lib.Reader(p).next(100)
+    res, cons = _fake_results(rng, hb)
+    splints = ["SplA", "SplB"]
+    sid = np.array([i % 2 if i % 11 else -1 for i in range(hb.n)], dtype=np.int16)    # -1: not in adapter_dict
+    res["status"][sid < 0] = _lib.ST_NOT_ASSIGNED
+    # native writer
+    raw = "".join(cons).encode()
+    coff = np.zeros(hb.n + 1, dtype=np.int64)
+    np.cumsum([len(c) for c in cons], out=coff[1:])
+    cp = [str(tmp_path / ("c_%s.fa" % s)) for s in splints]
+    sp = [str(tmp_path / ("s_%s.fq" % s)) for s in splints]
+    _lib.write_group(hb, res, np.frombuffer(raw, dtype=np.uint8), coff, sid, cp, sp, zero)
+    _lib.write_group(hb, res, np.frombuffer(raw, dtype=np.uint8), coff, sid, cp, sp, zero)      # appends
+    # Python formatter (analyze.write_group -> records.py, pinned by the golden header/dispatch cases)
+    out = str(tmp_path / "py") + "/"
+    args = types.SimpleNamespace(out_path=out, zero=zero)
+    ad = {recs[i][0]: [splints[sid[i]], "+"] for i in range(hb.n) if sid[i] >= 0}
+    analyze.write_group(args, recs, res, cons, ad, 1)
+    analyze.write_group(args, recs, res, cons, ad, 1)
+    import os
+    for s, c, q in zip(splints, cp, sp):
+        exp_c = open(out + s + "/tmp1/R2C2_Consensus.fasta").read()
+        exp_s = open(out + s + "/tmp1/subreads.fastq").read() if os.path.exists(out + s + "/tmp1/subreads.fastq") else ""
+        assert open(c).read() == exp_c and len(exp_c) > 0
+        assert open(q).read() == exp_s and len(exp_s) > 0
+
+
+def test_avg_qual_text_matches_python_round(tmp_path):
+    """header field avg_qual = str(round(sum/len, 2)) (C3POa.py:168): trailing zeros, .5 cases, long reads"""
+    from c3poa_amd import records
+    rng = np.random.default_rng(2)
+    recs = []
+    for i, L in enumerate([1, 3, 7, 8, 200, 201, 999, 1000, 4096, 12345]):
+        for rep in range(4):
+            q = "".join(chr(33 + int(v)) for v in rng.integers(0, 60, L))
+            recs.append(("q%d_%d" % (i, rep), "A" * L, q))
+    recs.append(("half", "AAAAAAAA", "".join(chr(33 + v) for v in (1, 0, 0, 0, 0, 0, 0, 0))))      # 0.125 -> 0.12
+    recs.append(("half2", "AAAAAAAA", "".join(chr(33 + v) for v in (3, 0, 0, 0, 0, 0, 0, 0))))     # 0.375 -> 0.38
+    p = str(tmp_path / "q.fastq")
+    _write_fastq(p, recs)
+    hb = _lib.Reader(p).next(1000)
+    res = np.zeros(hb.n, dtype=_lib.RESULT_DTYPE)
+    res["n_sub"] = 1
+    res["sub_end"][:, 0] = 1
+    coff = np.arange(hb.n + 1, dtype=np.int64)
+    cp, sp = [str(tmp_path / "c.fa")], [str(tmp_path / "s.fq")]
+    _lib.write_group(hb, res, np.frombuffer(b"A" * hb.n, dtype=np.uint8), coff, np.zeros(hb.n, dtype=np.int16), cp, sp)
+    got = [l.strip() for l in open(cp[0]) if l.startswith(">")]
+    assert got == [records.consensus_header(n, q, len(s), 1, 1) for n, s, q in recs]
+
+
+def test_writer_threads_give_identical_files(tmp_path, monkeypatch):
+    """groups of >= 4096 reads are formatted / written by several threads: same bytes, same record order"""
+    rng = np.random.default_rng(4)
+    recs = []
+    for i in range(5000):
+        L = int(rng.integers(60, 200))
+        recs.append(("w%05d" % i, "".join("ACGT"[j] for j in rng.integers(0, 4, L)), "".join(chr(33 + int(v)) for v in rng.integers(2, 40, L))))
+    p = str(tmp_path / "w.fastq")
+    _write_fastq(p, recs)
+    hb = _lib.Reader(p).next(10000)
+    res, cons = _fake_results(rng, hb)
+    raw = np.frombuffer("".join(cons).encode(), dtype=np.uint8)
+    coff = np.zeros(hb.n + 1, dtype=np.int64)
+    np.cumsum([len(c) for c in cons], out=coff[1:])
+    sid = (np.arange(hb.n) % 3).astype(np.int16)
+    outs = {}
+    for T in ("1", "5"):
+        monkeypatch.setenv("C3_WRITER_THREADS", T)
+        cp = [str(tmp_path / ("c%s_%d.fa" % (T, s))) for s in range(3)]
+        sp = [str(tmp_path / ("s%s_%d.fq" % (T, s))) for s in range(3)]
+        for _rep in range(2):                                             # second call appends after the first
+            _lib.write_group(hb, res, raw, coff, sid, cp, sp, True)
+        outs[T] = [open(x).read() if os.path.exists(x) else "" for x in cp + sp]
+    assert outs["1"] == outs["5"] and sum(1 for x in outs["1"] if x) >= 4
+    args = types.SimpleNamespace(out_path=str(tmp_path / "py") + "/", zero=True)
+    ad = {recs[i][0]: ["S%d" % sid[i], "+"] for i in range(hb.n)}
+    analyze.write_group(args, recs, res, cons, ad, 1)
+    analyze.write_group(args, recs, res, cons, ad, 1)
+    assert outs["5"][3] == open(args.out_path + "S0/tmp1/subreads.fastq").read()
+    assert outs["5"][1] == open(args.out_path + "S1/tmp1/R2C2_Consensus.fasta").read()

@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 output that a gpurun call merged into gpurun_out/ into the summaries kept under profiles/.
+
+  python tools/collect_profiles.py TAG STATS_DIR FETCH_DIR WRITE_DIR [BENCH_JSON]
+
+STATS_DIR : `rocprofv3 --kernel-trace --stats -d STATS_DIR -o s -- python3 bench.py --steps 1 --warmup 0 --no-cpu`
+FETCH_DIR : `rocprofv3 --kernel-trace --pmc FETCH_SIZE -d FETCH_DIR -o b -- python3 bench.py ...` (own pass)
+WRITE_DIR : same with WRITE_SIZE (own pass; counters are never combined with other trace domains)
+HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: on this device FETCH_SIZE counts half of the bytes of dword loads
+(tools/pmc_calibrate.py, 1 GiB each way), WRITE_SIZE is exact.
+"""
+import csv, glob, json, os, shutil, sys
+from collections import defaultdict
+
+
+def counter_sum(d, name):
+    acc, calls = defaultdict(float), defaultdict(int)
+    for f in glob.glob(os.path.join(d, "*results.db")):          # rocprofv3 default output (rocpd sqlite)
+        import sqlite3
+        for kn, v in sqlite3.connect(f).execute("select kernel_name, value from counters_collection where counter_name = ?", (name,)):
+            k = kn.split("(")[0].replace("void ", "")
+            acc[k] += float(v); calls[k] += 1
+    for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] == name:
+                k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                acc[k] += float(row["Counter_Value"]); calls[k] += 1
+    return {k: acc[k] / calls[k] for k in acc}
+
+
+def main():
+    tag, stats_dir, fdir, wdir = sys.argv[1:5]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prof = os.path.join(root, "profiles")
+    dst = os.path.join(prof, "%s_kernel_stats_bench_cfg2_100k.csv" % tag)
+    csvs = glob.glob(os.path.join(stats_dir, "*kernel_stats.csv"))
+    if csvs:
+        shutil.copy(csvs[0], dst)
+    else:                                                           # same table from the rocpd database
+        import sqlite3
+        db = sqlite3.connect(glob.glob(os.path.join(stats_dir, "*results.db"))[0])
+        rows = db.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels group by name order by 3 desc").fetchall()
+        tot = sum(r[2] for r in rows)
+        with open(dst, "w") as fh:
+            fh.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"\n')
+            for r in rows:
+                fh.write('"%s",%d,%d,%.1f,%.2f,%d,%d\n' % (r[0], r[1], r[2], r[3], 100.0 * r[2] / tot, r[4], r[5]))
+    st = dst
+    fetch, write = counter_sum(fdir, "FETCH_SIZE"), counter_sum(wdir, "WRITE_SIZE")
+    out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python3 bench.py --steps 1 "
+                   "--warmup 0 --no-cpu` (cfg2, 100000 reads); KB per launch as reported, averaged over launches. "
+                   "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE reports 1/2 of dword loads on this device, "
+                   "calibrated with tools/pmc_calibrate.py; WRITE_SIZE exact).",
+           "workload": "cfg2: 100000 reads/GPU/step", "kernels": {}}
+    for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, 0) + write.get(k, 0))):
+        if not k.startswith("k_"):
+            continue
+        out["kernels"][k] = {"FETCH_SIZE_KB": fetch.get(k, 0.0), "WRITE_SIZE_KB": write.get(k, 0.0),
+                             "hbm_bytes_per_launch": (2 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024}
+    json.dump(out, open(os.path.join(prof, "%s_pmc_traffic_cfg2_100k.json" % tag), "w"), indent=1)
+    if len(sys.argv) > 5:
+        shutil.copy(sys.argv[5], os.path.join(prof, "%s_bench_under_rocprof.json" % tag))
+    print(open(st).read())
+    print(json.dumps(out["kernels"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
