@@ -52,37 +52,34 @@ def psl_row(read_name, read_len, splint_name, splint_len, strand, score, offset,
     return "\t".join(str(c) for c in cols)
 
 
-def gpu_find_splints(args, align_psl, batch_reads=16384, handle=None):
+def gpu_find_splints(args, align_psl, batch_reads=131072, handle=None):
     """GPU splint/strand finder: one PSL row per accepted read (best candidate only, like the reference keeps the
-    best row per read, bin/preprocess.py:39).  Reads are streamed in batches; the handle is reused."""
+    best row per read, bin/preprocess.py:39).  Reads are streamed by the native reader in page-locked batches."""
+    import numpy as np
     from . import _lib
     from .seqio import fastx_read
     splints = [(s[0], s[1]) for s in fastx_read(args.splint_file)]
     h = handle or _lib.Handle()
     h.set_splints([s[1] for s in splints])
+    rd = _lib.Reader(args.reads, n_sets=1)
     n_rows = 0
     with open(align_psl + ".part", "w") as out:
-        def flush(names, seqs):
-            nonlocal n_rows
-            if not names:
-                return
-            h.upload(seqs, ["!" * len(s) for s in seqs], "?" * len(seqs))
+        while True:
+            hb = rd.next(batch_reads, args.lencutoff, 1 << 30)
+            if hb.n == 0:
+                break
+            h.upload_host(hb, b"?" * hb.n, np.zeros(hb.n, dtype=np.int16))
             tab, sid, st = h.scan_splints()
-            for i, name in enumerate(names):
-                if sid[i] < 0:
-                    continue
-                e = tab[i, sid[i], 1 if st[i:i + 1] == b"-" else 0]
-                out.write(psl_row(name, len(seqs[i]), splints[sid[i]][0], len(splints[sid[i]][1]),
-                                  st[i:i + 1].decode(), e[0], e[1], h.cfg.conk_match) + "\n")
-                n_rows += 1
-        names, seqs = [], []
-        for rd in fastx_read(args.reads):
-            if len(rd[1]) < args.lencutoff:
-                continue
-            names.append(rd[0]); seqs.append(rd[1])
-            if len(names) >= batch_reads:
-                flush(names, seqs); names, seqs = [], []
-        flush(names, seqs)
+            names, lens = hb.names(), np.diff(hb.off)
+            rows = []
+            for i in np.nonzero(sid >= 0)[0]:
+                k = int(sid[i])
+                e = tab[i, k, 1 if st[i] == 45 else 0]
+                rows.append(psl_row(names[i], int(lens[i]), splints[k][0], len(splints[k][1]), chr(st[i]), e[0], e[1], h.cfg.conk_match))
+            if rows:
+                out.write("\n".join(rows) + "\n")
+            n_rows += len(rows)
+    rd.close()
     os.replace(align_psl + ".part", align_psl)
     if handle is None:
         h.close()
