@@ -350,47 +350,52 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   // In state H the wave speculates 64 steps down the diagonal at once (lane k fetches the cell k steps
   // back and checks "match move from the previous row"); the cell that breaks the run is resolved by
   // the scalar state machine below.
+  // Every round fetches, in two dependent load levels, the cells (i-k, j-k) for all 64 lanes (row metadata and both
+  // descriptors first, then the direction word); lane 0 is always the current cell.  The breaking cell is then
+  // resolved from lane m's registers by the scalar state machine below, which only goes back to memory when the
+  // cell changes -- one round per break instead of a chain of dependent scalar loads per state transition.
   int* vq = c.mpl;
   int rc = 0;
   {
     int i = bi, j = Q, st = 0;   // st: 0 H, 1 Ht, 2 E1, 3 E2, 4 F1, 5 F2
     while (!(i == 0 && j == 0)) {
+      const int ik = i - lane, jk = j - lane;
+      const int ic = max(ik, 0);
+      const int b = c.rbeg[ic], e = c.rend[ic], ro = c.roff[ic];
+      const uint4 A = c.descA[ic], B = c.descB[ic];
+      const bool inb = ik >= 0 && jk >= b && jk <= e;
+      const unsigned d = inb ? c.D[ro + (jk - b)] : 0u;
+      int m = 0;
       if (st == 0 && i > 0 && j > 0) {
-        const int ik = i - lane, jk = j - lane;
-        bool ok = ik >= 1 && jk >= 1;
-        int node = 0;
-        if (ok) {
-          const int b = c.rbeg[ik], e = c.rend[ik];
-          const uint4 A = c.descA[ik];
-          node = (int)A.x;
-          ok = jk >= b && jk <= e;
-          if (ok) {
-            const unsigned d = c.D[c.roff[ik] + (jk - b)];
-            const int mp = d & 0xff;
-            ok = ((d >> 26) & 15) == 0 && mp < 4 && !((A.z >> 17) & 1);
-            if (ok) { const uint4 B = c.descB[ik]; const int pi = mp == 0 ? B.x : mp == 1 ? B.y : mp == 2 ? B.z : B.w; ok = pi == ik - 1; }
-          }
-        }
+        const int mp = d & 0xff;
+        bool ok = ik >= 1 && jk >= 1 && inb && ((d >> 26) & 15) == 0 && mp < 4 && !((A.z >> 17) & 1);
+        const int pi = mp == 0 ? (int)B.x : mp == 1 ? (int)B.y : mp == 2 ? (int)B.z : (int)B.w;
+        ok = ok && pi == ik - 1;
         const unsigned long long bal = __ballot(ok);
-        const int m = (~bal) ? __builtin_ctzll(~bal) : 64;
-        if (lane < m) vq[jk - 1] = node;
+        m = (~bal) ? __builtin_ctzll(~bal) : 64;
+        if (lane < m) vq[jk - 1] = (int)A.x;
         i -= m; j -= m;
         if (m == 64 || (i == 0 && j == 0)) continue;
       }
-      // scalar step at (i, j)
-      if (j < c.rbeg[i] || j > c.rend[i]) { rc = -2; break; }
-      const uint32_t d = c.D[c.roff[i] + (j - c.rbeg[i])];
-      const int v = c.order[i];
-      if (st == 0) { const int hs = (d >> 28) & 3; st = hs == 0 ? 1 : (hs == 1 ? 4 : 5); }
-      else if (st == 1) {
-        const int hts = (d >> 26) & 3;
-        if (hts == 0) { if (lane == 0) vq[j - 1] = v; i = c.index[c.in_from[v * K + (d & 0xff)]]; --j; st = 0; }
-        else st = hts == 1 ? 2 : 3;
+      // the current cell (i, j) sits in lane m
+      if (!wave_bcast((int)inb, m)) { rc = -2; break; }
+      const unsigned d0 = (unsigned)wave_bcast((int)d, m);
+      const int v = wave_bcast((int)A.x, m);
+      const int p0 = wave_bcast((int)B.x, m), p1 = wave_bcast((int)B.y, m), p2 = wave_bcast((int)B.z, m), p3 = wave_bcast((int)B.w, m);
+#define TB_PRED(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index[c.in_from[v * K + (k)]])
+      for (bool same = true; same;) {
+        if (st == 0) { const int hs = (d0 >> 28) & 3; st = hs == 0 ? 1 : (hs == 1 ? 4 : 5); }
+        else if (st == 1) {
+          const int hts = (d0 >> 26) & 3;
+          if (hts == 0) { if (lane == 0) vq[j - 1] = v; const int k = d0 & 0xff; i = TB_PRED(k); --j; st = 0; same = false; }
+          else st = hts == 1 ? 2 : 3;
+        }
+        else if (st == 2) { const int ec = (d0 >> 8) & 0x1ff; const int k = ec >> 1; i = TB_PRED(k); st = (ec & 1) ? 2 : 0; same = false; }
+        else if (st == 3) { const int ec = (d0 >> 17) & 0x1ff; const int k = ec >> 1; i = TB_PRED(k); st = (ec & 1) ? 3 : 0; same = false; }
+        else if (st == 4) { if (lane == 0) vq[j - 1] = -1; st = ((d0 >> 30) & 1) ? 4 : 1; --j; same = false; }
+        else { if (lane == 0) vq[j - 1] = -1; st = ((d0 >> 31) & 1) ? 5 : 1; --j; same = false; }
       }
-      else if (st == 2) { const int ec = (d >> 8) & 0x1ff; i = c.index[c.in_from[v * K + (ec >> 1)]]; st = (ec & 1) ? 2 : 0; }
-      else if (st == 3) { const int ec = (d >> 17) & 0x1ff; i = c.index[c.in_from[v * K + (ec >> 1)]]; st = (ec & 1) ? 3 : 0; }
-      else if (st == 4) { if (lane == 0) vq[j - 1] = -1; st = ((d >> 30) & 1) ? 4 : 1; --j; }
-      else { if (lane == 0) vq[j - 1] = -1; st = ((d >> 31) & 1) ? 5 : 1; --j; }
+#undef TB_PRED
     }
   }
   WSYNC();

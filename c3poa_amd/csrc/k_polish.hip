@@ -640,8 +640,10 @@ __global__ __launch_bounds__(64, 3) void k_window(WinArgs a) {
             const bool val = rk >= 1 && jk >= 0;
             int d = 0, prow = -1;
             if (val) {
+              // both loads are issued together (one dependent level per round, not two)
+              const uint4 de = c.rdesc[rk];
               d = c.D[(size_t)rk * RS + win_idx(jk, cpl)];
-              if (win_d_type(d) != 2) { const uint4 de = c.rdesc[rk]; prow = ((de.x >> 16) & 1) ? -2 : win_pred_row(c, de, rk, win_d_pred(d)); }
+              if (win_d_type(d) != 2) prow = ((de.x >> 16) & 1) ? -2 : win_pred_row(c, de, rk, win_d_pred(d));
             }
             const bool diag1 = val && jk >= 1 && win_d_type(d) == 0 && prow == rk - 1;
             const unsigned long long bal = __ballot(diag1);
