@@ -14,8 +14,12 @@ recs = (recs * (n // len(recs) + 1))[:n]
 h = _lib.Handle(mdistcutoff=synth.CONFIGS[cfg]["mdist"])
 h.set_splints([synth.SPLINT1])
 h.upload([r[1] for r in recs], [r[2] for r in recs], [r[3] for r in recs])
-h.run(); h.run()
-print({k: round(v, 2) if isinstance(v, float) else v for k, v in h.timing().items()})
+best = None
+for _rep in range(int(os.environ.get("C3_REPS", "4"))):                 # min over repetitions: clocks / power state add +-5 %
+    h.run(); h.results(with_consensus=False)
+    t = h.timing()
+    best = t if best is None else {k: (min(v, best[k]) if isinstance(v, float) else v) for k, v in t.items()}
+print({k: round(v, 2) if isinstance(v, float) else v for k, v in best.items()})
 names = [["remain/init", "DP rows", "traceback", "fuse", "reorder", "columns", "consensus/pairwise", "tpos", "-", "between"],
          ["backbone", "sort+mask", "compaction", "DP rows", "end select", "traceback", "fuse", "reorder", "consensus", "queue/other"]]
 h.lib.c3_debug_phases.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
