@@ -478,7 +478,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   HIPCHK(hipEventRecord(h->ev[7], h->stream));
   if (n_win > 0) {
     HIPCHK(h->d_wout.ensure((size_t)n_win * wout_cap));
-    const int Ncap = 3 * WL + 48 * NLcap, K = NLcap + 2;
+    const int Ncap = 3 * WL + 40 * NLcap, K = NLcap + 2;   // cfg2: 1700 nodes -> 10.2 KB of LDS per wave, 16 waves per CU
     const long long hcap = (long long)(Ncap + 1) * 64 * 12;
     const size_t N = (size_t)Ncap;
     const int NI = 18;

@@ -288,7 +288,7 @@ __device__ void w_reorder(WCtx& c, int n_old, int lane) {
 // dependent graph loads:
 //   x = base | np<<8 | overflow<<16 | needH<<17 | isend<<18,  y = p0 | p1<<16,  z = p2 | p3<<16
 // p = DP row of a masked predecessor in in-edge order (row 0 = the virtual start row);
-// needH: some masked successor is not the next row, so the H row must be kept in memory;
+// needH: some masked successor is neither of the next two rows, so the H row must be kept in memory;
 // isend: no masked successor, the row is a candidate end of the global alignment.
 __device__ void win_build_desc(WCtx& c, int R, int lane) {
   const int K = c.K;
@@ -306,7 +306,7 @@ __device__ void win_build_desc(WCtx& c, int R, int lane) {
     unsigned needh = 0, has = 0;
     for (int k = 0; k < c.n_out()[v]; ++k) {
       const int sr = c.rowof()[c.out_to()[v * K + k]];
-      if (sr >= 0) { has = 1; if (sr != r + 1) needh = 1; }
+      if (sr >= 0) { has = 1; if (sr != r + 1 && sr != r + 2) needh = 1; }     // rows r-1 and r-2 stay in registers
     }
     unsigned ovf = np > 4;
     if (np == 0) np = 1;                      // no masked predecessor: virtual row 0
@@ -348,10 +348,11 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
   constexpr int DS = (CPL + 3) & ~3, RSD = 64 * DS;                        // D row: natural column order, DS bytes per lane
   if ((long long)(R + 1) * RSD > c.hcap || R >= 65535) return -1;
   const int NEG8 = -(1 << 30);
-  int qc[CPL], hcur[CPL], gj8[CPL];
+  int qc[CPL], hcur[CPL], hp2[CPL], gj8[CPL];                               // hcur = row r-1, hp2 = row r-2
 #pragma unroll
   for (int cc = 0; cc < CPL; ++cc) {
     const int j = lane * CPL + cc;
+    hp2[cc] = 0;
     qc[cc] = (j >= 1 && j <= Q) ? c3_code_at(pk, qbeg + j - 1) : 7;
     hcur[cc] = j * g8;                                                      // virtual row 0
     gj8[cc] = (j <= Q) ? g8 * j : (1 << 28);                                // columns past Q drop out of the scan
@@ -396,6 +397,9 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
       if (prow == r - 1) {
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc) hp[cc] = hcur[cc];
+      } else if (prow == r - 2) {                                            // the usual "skip one sibling" edge
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) hp[cc] = hp2[cc];
       } else {
         const int32_t* hp_ = c.H + (size_t)prow * RS;
 #pragma unroll
@@ -423,6 +427,7 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
     for (int cc = 0; cc < CPL; ++cc) {
       const int k2 = max(key[cc], ex + gj8[cc] + W_TAG_H);                   // for j == 0 ex is NEG8: never wins
       ex = max(ex, y[cc]);
+      hp2[cc] = hcur[cc];
       hcur[cc] = k2 & ~0xff;
       dpk[cc / 4] |= (unsigned)(k2 & 0xff) << (8 * (cc & 3));
     }
