@@ -286,34 +286,45 @@ __device__ void w_reorder(WCtx& c, int n_old, int lane) {
 
 // Row descriptors of one alignment, built in parallel before the DP so that the row loop has no
 // dependent graph loads:
-//   x = base | np<<8 | overflow<<16 | needH<<17 | isend<<18,  y = p0 | p1<<16,  z = p2 | p3<<16
+//   x = base | np<<8 | overflow<<16 | needH<<17 | isend<<18 | twobit<<19,  y = p0 | p1<<16,  z = p2 | p3<<16
 // p = DP row of a masked predecessor in in-edge order (row 0 = the virtual start row);
 // needH: some masked successor is neither of the next two rows, so the H row must be kept in memory;
 // isend: no masked successor, the row is a candidate end of the global alignment.
-__device__ void win_build_desc(WCtx& c, int R, int lane) {
+// m2[i] bit b: DP row 1+64i+b has exactly one masked predecessor (its direction cells are stored with 2 bits);
+// ma[i] bit b: ... and that predecessor is the previous row.  Both live in LDS so the traceback can classify the 64 rows
+// of a round without a dependent global load (allow2 = false: every row uses byte cells, e.g. the linear fallback).
+__device__ void win_build_desc(WCtx& c, int R, int lane, unsigned long long* m2, unsigned long long* ma, bool allow2) {
   const int K = c.K;
-  for (int r = 1 + lane; r <= R; r += 64) {
-    const int v = c.rows()[r];
-    const int nin = c.n_in()[v];
-    unsigned p[4] = {0, 0, 0, 0};
-    int np = 0;
-    for (int k = 0; k < nin; ++k) {
-      const int pr = c.rowof()[c.in_from()[v * K + k]];
-      if (pr < 0) continue;
-      if (np < 4) p[np] = (unsigned)pr;
-      ++np;
+  for (int r0 = 1; r0 <= R; r0 += 64) {
+    const int r = r0 + lane;
+    bool two = false, adj = false;
+    if (r <= R) {
+      const int v = c.rows()[r];
+      const int nin = c.n_in()[v];
+      unsigned p[4] = {0, 0, 0, 0};
+      int np = 0;
+      for (int k = 0; k < nin; ++k) {
+        const int pr = c.rowof()[c.in_from()[v * K + k]];
+        if (pr < 0) continue;
+        if (np < 4) p[np] = (unsigned)pr;
+        ++np;
+      }
+      unsigned needh = 0, has = 0;
+      for (int k = 0; k < c.n_out()[v]; ++k) {
+        const int sr = c.rowof()[c.out_to()[v * K + k]];
+        if (sr >= 0) { has = 1; if (sr != r + 1 && sr != r + 2) needh = 1; }     // rows r-1 and r-2 stay in registers
+      }
+      unsigned ovf = np > 4;
+      if (np == 0) np = 1;                      // no masked predecessor: virtual row 0
+      two = allow2 && np == 1;
+      adj = two && (int)p[0] == r - 1;
+      uint4 d; d.x = (unsigned)c.base()[v] | ((unsigned)min(np, 255) << 8) | (ovf << 16) | (needh << 17) | ((has ^ 1u) << 18) | ((unsigned)two << 19);
+      d.y = p[0] | (p[1] << 16); d.z = p[2] | (p[3] << 16); d.w = 0;
+      c.rdesc[r] = d;
+      c.hend()[r] = INT32_MIN;
     }
-    unsigned needh = 0, has = 0;
-    for (int k = 0; k < c.n_out()[v]; ++k) {
-      const int sr = c.rowof()[c.out_to()[v * K + k]];
-      if (sr >= 0) { has = 1; if (sr != r + 1 && sr != r + 2) needh = 1; }     // rows r-1 and r-2 stay in registers
-    }
-    unsigned ovf = np > 4;
-    if (np == 0) np = 1;                      // no masked predecessor: virtual row 0
-    uint4 d; d.x = (unsigned)c.base()[v] | ((unsigned)min(np, 255) << 8) | (ovf << 16) | (needh << 17) | ((has ^ 1u) << 18);
-    d.y = p[0] | (p[1] << 16); d.z = p[2] | (p[3] << 16); d.w = 0;
-    c.rdesc[r] = d;
-    c.hend()[r] = INT32_MIN;
+    const unsigned long long b2 = __ballot(two), ba = __ballot(adj);
+    if (lane == 0) { m2[r0 >> 6] = b2; ma[r0 >> 6] = ba; }
   }
   WSYNC();
 }
@@ -373,7 +384,7 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
     de.x = __builtin_amdgcn_readlane(dblk.x, li); de.y = __builtin_amdgcn_readlane(dblk.y, li);
     de.z = __builtin_amdgcn_readlane(dblk.z, li); de.w = 0;
     const int vb = de.x & 0xff, np = (de.x >> 8) & 0xff;
-    const bool ovf = (de.x >> 16) & 1, needh = (de.x >> 17) & 1, isend = (de.x >> 18) & 1;
+    const bool ovf = (de.x >> 16) & 1, needh = (de.x >> 17) & 1, isend = (de.x >> 18) & 1, two = (de.x >> 19) & 1;
     if (np > 64) return -1;
     int sel[CPL], key[CPL];
 #pragma unroll
@@ -419,17 +430,37 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
     for (int cc = 0; cc < CPL; ++cc) { y[cc] = (key[cc] & ~0xff) - gj8[cc]; run = max(run, y[cc]); }
     const int s = wave_scan_max(run);
     int ex = wave_shr1(s, NEG8);                                             // max over all previous lanes
-    unsigned dpk[DS / 4];
-#pragma unroll
-    for (int w = 0; w < DS / 4; ++w) dpk[w] = 0;
     int32_t* hrow = c.H + (size_t)r * RS;
+    if (two) {
+      // single-predecessor row: the tag is 255 (diag), 191 (vert) or 127 (horiz) -> 2 bits per cell, one dword per
+      // lane, 256 contiguous bytes per row instead of 64*DS
+      unsigned w2 = 0;
 #pragma unroll
-    for (int cc = 0; cc < CPL; ++cc) {
-      const int k2 = max(key[cc], ex + gj8[cc] + W_TAG_H);                   // for j == 0 ex is NEG8: never wins
-      ex = max(ex, y[cc]);
-      hp2[cc] = hcur[cc];
-      hcur[cc] = k2 & ~0xff;
-      dpk[cc / 4] |= (unsigned)(k2 & 0xff) << (8 * (cc & 3));
+      for (int cc = 0; cc < CPL; ++cc) {
+        const int k2 = max(key[cc], ex + gj8[cc] + W_TAG_H);                 // for j == 0 ex is NEG8: never wins
+        ex = max(ex, y[cc]);
+        hp2[cc] = hcur[cc];
+        hcur[cc] = k2 & ~0xff;
+        w2 |= (((unsigned)k2 >> 6) & 3u) << (2 * cc);
+      }
+      if (lane * CPL <= Q) ((unsigned*)(c.D + (size_t)r * RSD))[lane] = w2;
+    } else {
+      unsigned dpk[DS / 4];
+#pragma unroll
+      for (int w = 0; w < DS / 4; ++w) dpk[w] = 0;
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) {
+        const int k2 = max(key[cc], ex + gj8[cc] + W_TAG_H);
+        ex = max(ex, y[cc]);
+        hp2[cc] = hcur[cc];
+        hcur[cc] = k2 & ~0xff;
+        dpk[cc / 4] |= (unsigned)(k2 & 0xff) << (8 * (cc & 3));
+      }
+      unsigned* drow = (unsigned*)(c.D + (size_t)r * RSD) + lane * (DS / 4);
+      if (lane * CPL <= Q) {
+#pragma unroll
+        for (int w = 0; w < DS / 4; ++w) drow[w] = dpk[w];
+      }
     }
     if (needh) {
 #pragma unroll
@@ -438,11 +469,6 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
     if (isend) {
 #pragma unroll
       for (int cc = 0; cc < CPL; ++cc) if (lane * CPL + cc == Q) c.hend()[r] = hcur[cc] >> 8;
-    }
-    unsigned* drow = (unsigned*)(c.D + (size_t)r * RSD) + lane * (DS / 4);
-    if (lane * CPL <= Q) {
-#pragma unroll
-      for (int w = 0; w < DS / 4; ++w) drow[w] = dpk[w];
     }
   }
   }
@@ -501,13 +527,14 @@ __device__ int win_rows_lin(WCtx& c, const C3Params& P, const uint32_t* pk, int 
 // byte index of column j inside a D row for the layout chosen by win_rows_dispatch
 __device__ __forceinline__ int win_idx(int j, int cpl) { return cpl ? (j / cpl) * ((cpl + 3) & ~3) + j % cpl : j; }
 
-__device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane, int* cpl_out, int* rs_out, unsigned long long* dbg) {
+__device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane, int* cpl_out, int* rs_out, unsigned long long* dbg,
+                                 unsigned long long* m2, unsigned long long* ma) {
   const int need = (Q + 1 + 63) / 64;
   int cpl;
   if (need <= 2) cpl = 2; else if (need <= 4) cpl = 4; else if (need <= 6) cpl = 6; else if (need <= 8) cpl = 8;
   else if (need <= 10) cpl = 10; else cpl = 0;
   *cpl_out = cpl; *rs_out = cpl ? 64 * ((cpl + 3) & ~3) : need * 64;    // D row stride in bytes
-  win_build_desc(c, R, lane);
+  win_build_desc(c, R, lane, m2, ma, cpl != 0);
   switch (cpl) {
     case 2: return win_rows<2>(c, P, pk, qbeg, Q, R, lane, dbg);
     case 4: return win_rows<4>(c, P, pk, qbeg, Q, R, lane, dbg);
@@ -532,6 +559,8 @@ __global__ __launch_bounds__(64, 4) void k_window(WinArgs a) {
   const C3Params& P = a.p;
   extern __shared__ int lds_dyn[];                      // [Ncap] scores + [Ncap] u16 predecessors
   int* s_score = lds_dyn; unsigned short* s_pred = (unsigned short*)(lds_dyn + a.Ncap);
+  // the same LDS holds the row-type bitmasks of the layer being aligned (DP rows + traceback; the consensus sweep comes later)
+  unsigned long long* m2bits = (unsigned long long*)lds_dyn; unsigned long long* mabits = m2bits + ((a.Ncap + 64) >> 6) + 1;
   PH_DECL
 
   for (;;) {
@@ -622,7 +651,7 @@ __global__ __launch_bounds__(64, 4) void k_window(WinArgs a) {
         PH_MARK(2)
         int cpl = 0, RS = 0;
         unsigned long long dbg_[3] = {0, 0, 0};
-        if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_) < 0) { fail = 1; break; }
+        if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits) < 0) { fail = 1; break; }
 #ifdef C3_PHASE_PROF
         ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1]; ph_acc_[9] += dbg_[2];
 #endif
@@ -647,10 +676,19 @@ __global__ __launch_bounds__(64, 4) void k_window(WinArgs a) {
             const bool val = rk >= 1 && jk >= 0;
             int d = 0, prow = -1;
             if (val) {
-              // both loads are issued together (one dependent level per round, not two)
-              const uint4 de = c.rdesc[rk];
-              d = c.D[(size_t)rk * RS + win_idx(jk, cpl)];
-              if (win_d_type(d) != 2) prow = ((de.x >> 16) & 1) ? -2 : win_pred_row(c, de, rk, win_d_pred(d));
+              const int rb = rk - 1;
+              const bool two = (m2bits[rb >> 6] >> (rb & 63)) & 1;
+              if (two) {
+                // 2-bit row: no descriptor needed on the common path (LDS says whether the predecessor is row rk-1)
+                const unsigned w = ((const unsigned*)(c.D + (size_t)rk * RS))[jk / cpl];
+                d = 63 + 64 * (int)((w >> (2 * (jk % cpl))) & 3u);
+                prow = ((mabits[rb >> 6] >> (rb & 63)) & 1) ? rk - 1 : -3;
+              } else {
+                // both loads are issued together (one dependent level per round, not two)
+                const uint4 de = c.rdesc[rk];
+                d = c.D[(size_t)rk * RS + win_idx(jk, cpl)];
+                if (win_d_type(d) != 2) prow = ((de.x >> 16) & 1) ? -2 : win_pred_row(c, de, rk, win_d_pred(d));
+              }
             }
             const bool diag1 = val && jk >= 1 && win_d_type(d) == 0 && prow == rk - 1;
             const unsigned long long bal = __ballot(diag1);
@@ -664,7 +702,7 @@ __global__ __launch_bounds__(64, 4) void k_window(WinArgs a) {
               const int ty = win_d_type(db);
               if (ty == 2) { if (lane == 0) rq[j - 1] = 0; --j; }
               else {
-                if (pb == -2) pb = win_pred_row(c, c.rdesc[r], r, win_d_pred(db));   // >4 predecessors (uniform slow path)
+                if (pb <= -2) pb = win_pred_row(c, c.rdesc[r], r, win_d_pred(db));   // >4 predecessors, or a 2-bit row whose predecessor is not r-1 (uniform slow path)
                 if (ty == 0) { if (lane == 0) rq[j - 1] = r; --j; }
                 r = pb;
               }
