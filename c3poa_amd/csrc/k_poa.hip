@@ -593,39 +593,71 @@ __global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
           WSYNC();
           C = c.rem[0];
         } else {
-          // ---- abPOA heaviest bundling.  Reverse sweep, 64 nodes at a time: their out-edges are fetched in
-          // parallel and consumed in order through lane broadcasts; scores of the last 512 nodes sit in
-          // an LDS ring (ties need them), older ones come from memory.  The path itself is then read
-          // off binary-lifting jump tables instead of a 1500-step pointer chase.
+          // ---- abPOA heaviest bundling: nxt[v] = out-edge of maximum weight, ties (equal weight) go to the LATER edge
+          // whose target has a score >= the current one, score[v] = weight + score[nxt[v]] (reverse topological sweep in
+          // the oracle).  Only nodes with a tie for the maximum ever look at a score, so: (a) every node picks its
+          // maximum-weight edge in parallel and flags ties; (b) pointer jumping, with tie nodes and SNK as terminators,
+          // gives every node the weight sum of its chain up to the next terminator; (c) the few tie nodes are resolved
+          // serially in reverse topological order from those sums.  The path itself is then read off binary-lifting jump
+          // tables instead of a 1500-step pointer chase.
           {
             const int K = c.K, n = c.n;
-            int* sring = &L.H[0][0];                       // PR*PW >= 512 ints, free after the alignments
-            int* sc32 = c.rem;                             // scores of all nodes (global copy)
-            for (int i1 = n; i1 > 0; i1 -= 64) {
-              const int i = i1 - 1 - lane;                 // lane 0 = last node of the chunk
-              int v = 0, no = 0, t0 = 0, w0 = 0, x0 = 0, t1 = 0, w1 = 0, x1 = 0;
-              if (i >= 0) {
-                v = c.order[i]; no = c.n_out[v];
-                if (no > 0) { t0 = c.out_to[v * K]; w0 = c.out_w[v * K]; x0 = c.index[t0]; }
-                if (no > 1) { t1 = c.out_to[v * K + 1]; w1 = c.out_w[v * K + 1]; x1 = c.index[t1]; }
+            int* nxA = c.jump; int* nxB = c.jump + (size_t)c.Ncap; int* ssA = c.jump + 2 * (size_t)c.Ncap; int* ssB = c.jump + 3 * (size_t)c.Ncap;
+            int* score = c.jump + 4 * (size_t)c.Ncap; int* tief = c.jump + 5 * (size_t)c.Ncap;     // all rebuilt below
+            for (int v = lane; v < n; v += 64) {
+              const int no = c.n_out[v];
+              int bw = INT32_MIN, bt = SNK, cm = 0;
+              for (int k = 0; k < no; ++k) {
+                const int ww = c.out_w[v * K + k];
+                if (ww > bw) { bw = ww; bt = c.out_to[v * K + k]; cm = 1; } else if (ww == bw) ++cm;
               }
-              const int cnt = min(64, i1);
-              for (int t = 0; t < cnt; ++t) {
-                const int vv = wave_bcast(v, t), nn = wave_bcast(no, t), ii = i1 - 1 - t;
-                int bw = INT32_MIN, bt = SNK, sbt = 0;
-                if (vv != SNK) {
-                  for (int k = 0; k < nn; ++k) {
-                    int tt, ww, xx;
-                    if (k == 0) { tt = wave_bcast(t0, t); ww = wave_bcast(w0, t); xx = wave_bcast(x0, t); }
-                    else if (k == 1) { tt = wave_bcast(t1, t); ww = wave_bcast(w1, t); xx = wave_bcast(x1, t); }
-                    else { tt = c.out_to[vv * K + k]; ww = c.out_w[vv * K + k]; xx = c.index[tt]; }
-                    const int st = (xx - ii < 512) ? sring[xx & 511] : sc32[tt];
-                    if (ww > bw) { bw = ww; bt = tt; sbt = st; }
-                    else if (ww == bw && sbt <= st) { bt = tt; sbt = st; }
-                  }
+              const bool term = (v == SNK) || cm >= 2 || no == 0;
+              c.nxt[v] = bt; tief[v] = (v != SNK && cm >= 2) ? 1 : 0;
+              nxA[v] = term ? v : bt; ssA[v] = term ? 0 : bw;
+              score[v] = (v == SNK) ? 0 : (no == 0 ? INT32_MIN : 0);
+            }
+            WSYNC();
+            for (int span = 1; span < n; span <<= 1) {
+              int pending = 0;
+              for (int v = lane; v < n; v += 64) {
+                const int u = nxA[v], uu = nxA[u];
+                ssB[v] = ssA[v] + ssA[u]; nxB[v] = uu;
+                pending |= nxA[uu] != uu;
+              }
+              WSYNC();
+              int* t1 = nxA; nxA = nxB; nxB = t1; t1 = ssA; ssA = ssB; ssB = t1;
+              if (!__ballot(pending)) break;
+            }
+            // (c) tie nodes, last in topological order first
+            for (int i1 = n; i1 > 0; i1 -= 64) {
+              const int i = i1 - 1 - lane;
+              const int vl = i >= 0 ? c.order[i] : 0;
+              unsigned long long todo = __ballot(i >= 0 && tief[vl]);
+              while (todo) {
+                const int t = __builtin_ctzll(todo); todo &= todo - 1;
+                const int vv = wave_bcast(vl, t);
+                const int no = c.n_out[vv];
+                // lane k evaluates out-edge k: weight, target, score of the target
+                int ww = INT32_MIN, tt = SNK, st = 0;
+                if (lane < min(no, 64)) {
+                  ww = c.out_w[vv * K + lane]; tt = c.out_to[vv * K + lane];
+                  const int tm = nxA[tt];
+                  st = (tm == tt) ? score[tt] : ssA[tt] + score[tm];
                 }
-                const int scv = (vv == SNK) ? 0 : bw + sbt;
-                if (lane == 0) { sring[ii & 511] = scv; sc32[vv] = scv; c.nxt[vv] = bt; }
+                int bw = INT32_MIN, bt = SNK, sbt = 0;
+                for (int k = 0; k < no; ++k) {
+                  int wk, tk, sk;
+                  if (k < 64) { wk = wave_bcast(ww, k); tk = wave_bcast(tt, k); sk = wave_bcast(st, k); }
+                  else {                                     // more than 64 out-edges: uniform loads
+                    wk = c.out_w[vv * K + k]; tk = c.out_to[vv * K + k];
+                    const int tm = nxA[tk];
+                    sk = (tm == tk) ? score[tk] : ssA[tk] + score[tm];
+                  }
+                  if (wk > bw) { bw = wk; bt = tk; sbt = sk; }
+                  else if (wk == bw && sbt <= sk) { bt = tk; sbt = sk; }
+                }
+                if (lane == 0) { score[vv] = bw + sbt; c.nxt[vv] = bt; }
+                WSYNC();
               }
             }
             WSYNC();
