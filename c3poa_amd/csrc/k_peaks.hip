@@ -16,6 +16,8 @@
 #include "c3_args.h"
 
 #define PK_T 256
+#define SG_T 2048        /* outputs per LDS tile */
+#define SG_H 64          /* largest halo (iters * half) the tiled path supports; 3 * 20 = 60 for the reference's settings */
 
 
 __device__ __forceinline__ double sg_pad(const double* y, int n, int half, int x) {
@@ -80,6 +82,7 @@ __global__ __launch_bounds__(PK_T) void k_peaks(PeaksArgs a) {
   __shared__ int sh_idx[PK_T];
   __shared__ int sh_cnt[PK_T + 1];
   __shared__ int kept[C3_MAX_PEAKS + 1];
+  __shared__ double tb0[SG_T + 2 * SG_H], tb1[SG_T + 2 * SG_H];
   const int tid = threadIdx.x;
   double* A = a.bufA + (size_t)blockIdx.x * a.maxL;
   double* B = a.bufB + (size_t)blockIdx.x * a.maxL;
@@ -95,10 +98,54 @@ __global__ __launch_bounds__(PK_T) void k_peaks(PeaksArgs a) {
     const int n = (int)(a.b.off[rid + 1] - off);
     if (n < half + 1 || n < 2) { if (tid == 0) { info->status = C3_ST_TOO_SHORT; a.n_raw[rid] = 0; } continue; }
     const int32_t* tr = a.track + off;
+    // ---- smoothing passes.  Tiled through LDS: a tile of SG_T outputs plus a halo of iters*half points on each side is
+    // loaded once, all passes run LDS -> LDS (each pass needs half fewer halo points than the one before), and only the
+    // last pass writes the smoothed track to memory.  Per point the arithmetic (and its order) is the one of the
+    // untiled loop below, so the result is bit-identical.  Read ends: the mirrored-difference padding
+    // (bin/savitzky_golay.py:33-35) is evaluated on the fly from that pass's own input, which the first / last tile holds.
+    double* src = A; double* dst = B;
+    const int H = a.iters * half;
+    if (a.iters >= 1 && H <= SG_H) {
+      double* xout = (a.iters & 1) ? B : A;
+      for (int t0 = 0; t0 < n; t0 += SG_T) {
+        const int base = t0 - H;                                   // global index of LDS slot 0
+        const int T = min(SG_T, n - t0);
+        for (int x = tid; x < T + 2 * H; x += PK_T) { const int g = base + x; if (g >= 0 && g < n) tb0[x] = (double)tr[g]; }
+        __syncthreads();
+        double* sb = tb0; double* db = tb1;
+        for (int it = 0; it < a.iters; ++it) {
+          const int ext = (a.iters - 1 - it) * half;               // outputs still needed beyond the core
+          const int glo = max(0, t0 - ext), ghi = min(n, t0 + T + ext);
+          const bool last = it == a.iters - 1;
+          const double* yv = sb - base;                            // yv[g] = input of this pass at global index g
+          for (int g = glo + tid; g < ghi; g += PK_T) {
+            double acc = 0.0;
+            if (g >= half && g + half < n) {
+              const double* y = yv + (g - half);
+              if (half == 20) {
+#pragma unroll
+                for (int k = 0; k < 20; ++k) acc = __builtin_fma(a.coef[k], y[k] + y[40 - k], acc);
+                acc = __builtin_fma(a.coef[20], y[20], acc);
+              } else {
+                for (int k = 0; k < half; ++k) acc = __builtin_fma(a.coef[k], y[k] + y[2 * half - k], acc);
+                acc = __builtin_fma(a.coef[half], y[half], acc);
+              }
+            } else {
+              for (int k = 0; k < half; ++k)
+                acc = __builtin_fma(a.coef[k], sg_pad(yv, n, half, g + k) + sg_pad(yv, n, half, g + 2 * half - k), acc);
+              acc = __builtin_fma(a.coef[half], sg_pad(yv, n, half, g + half), acc);
+            }
+            if (last) xout[g] = acc; else db[g - base] = acc;
+          }
+          __syncthreads();
+          double* t = sb; sb = db; db = t;
+        }
+      }
+      src = xout;
+      __syncthreads();
+    } else {
     for (int i = tid; i < n; i += PK_T) A[i] = (double)tr[i];
     __syncthreads();
-    // ---- smoothing passes: A -> B -> A -> ...
-    double* src = A; double* dst = B;
     for (int it = 0; it < a.iters; ++it) {
       for (int i = tid; i < n; i += PK_T) {
         double acc = 0.0;
@@ -115,6 +162,7 @@ __global__ __launch_bounds__(PK_T) void k_peaks(PeaksArgs a) {
       }
       __syncthreads();
       double* t = src; src = dst; dst = t;
+    }
     }
     const double* x = src;    // smoothed track
     // ---- np.median
