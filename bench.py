@@ -90,11 +90,16 @@ def main():
     quals = [r[1] for r in recs] * reps
     strands = [r[2] for r in recs] * reps
     seqs, quals, strands = seqs[:a.reads], quals[:a.reads], strands[:a.reads]
-    t_up = time.perf_counter()
-    h.upload(seqs, quals, strands)              # H2D + 2-bit pack: outside the timed region
-    t_up = time.perf_counter() - t_up
     lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    off = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    seq_cat, qual_cat = "".join(seqs).encode(), "".join(quals).encode()   # the boundary hands over flat host buffers
     del seqs, quals
+    h.upload_flat(seq_cat, qual_cat, off, "".join(strands))               # first call also allocates the device buffers
+    t_up = time.perf_counter()
+    h.upload_flat(seq_cat, qual_cat, off, "".join(strands))               # H2D + 2-bit pack: outside the timed region
+    t_up = time.perf_counter() - t_up
+    del seq_cat, qual_cat
 
     def barrier():
         if dist is not None:
