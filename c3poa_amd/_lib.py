@@ -19,7 +19,8 @@ EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_create", "c
            "c3_batch_upload", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_timing",
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
            "c3_call_peaks", "c3_poa_msa", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
-           "c3_reader_open", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_write_group"]
+           "c3_reader_open", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_write_group",
+           "c3_scan_adapters", "c3_match_index"]
 
 
 class Config(C.Structure):
@@ -91,6 +92,8 @@ def load():
     lib.c3_poa_msa.argtypes = [vp, C.c_int, C.POINTER(cp), ip, vp, C.c_int, ip, vp, C.c_int64, ip]
     lib.c3_zero_repeats.argtypes = [vp, cp, cp, C.c_int, cp, cp, C.c_int, C.c_int, vp, C.c_int, ip]
     lib.c3_scan_splints.argtypes = [vp, vp, vp, vp]
+    lib.c3_scan_adapters.argtypes = [vp, vp]
+    lib.c3_match_index.argtypes = [cp, C.c_int, C.c_int, cp, vp]
     lib.c3_reader_open.argtypes = [cp, C.c_int, C.POINTER(vp)]
     lib.c3_reader_close.argtypes = [vp]
     lib.c3_reader_close.restype = None
@@ -292,6 +295,14 @@ class Handle:
         self._chk(self.lib.c3_scan_splints(self.h, tab.ctypes.data, sid.ctypes.data, st.ctypes.data))
         return tab, sid, st.tobytes()
 
+    def scan_adapters(self):
+        """adapter finder over the resident batch (replaces blat in C3POa_postprocessing.py:229-236): table
+        [n][n_adapters][2 strands][12] = score, qStart, qEnd, tStart, tEnd, matches, misMatches, qBaseInsert,
+        tBaseInsert, qNumInsert, tNumInsert, read length"""
+        tab = np.zeros((self.n, self.n_splints, 2, 12), dtype=np.int32)
+        self._chk(self.lib.c3_scan_adapters(self.h, tab.ctypes.data))
+        return tab
+
     def zero_repeats(self, d0, q0, d1, q1, min_len=0):
         b0, b1 = _b(d0), _b(d1)
         cap = len(b0) + len(b1) + 16
@@ -315,6 +326,15 @@ class Handle:
         if return_draft:
             return out.raw[:ol.value].decode(), draft.raw[:dl.value].decode()
         return out.raw[:ol.value].decode()
+
+
+def match_index(seq, index_seqs):
+    """c3_match_index: number of the winning index (file order) or -1 (match_index, C3POa_postprocessing.py:266-285)"""
+    bs = [_b(x) for x in index_seqs]
+    off = np.zeros(len(bs) + 1, dtype=np.int64)
+    np.cumsum([len(b) for b in bs], out=off[1:])
+    sq = _b(seq)
+    return int(load().c3_match_index(sq, len(sq), len(bs), b"".join(bs), off.ctypes.data))
 
 
 def device_count():

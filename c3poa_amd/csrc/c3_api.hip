@@ -10,6 +10,7 @@
 
 // ---- kernel launchers (one translation unit per kernel family) --------------------------
 extern "C" void c3k_launch_conk(const ConkArgs*, int, int, int, hipStream_t);
+extern "C" void c3k_launch_adapter(const AdapterArgs*, int, hipStream_t);
 extern "C" void c3k_launch_peaks(const PeaksArgs*, int, hipStream_t);
 extern "C" void c3k_launch_poa(const PoaArgs*, int, hipStream_t);
 extern "C" void c3k_launch_prep(const PrepArgs*, int, hipStream_t);
@@ -752,6 +753,32 @@ extern "C" int c3_scan_splints(c3_handle* h, int32_t* out /* [n][n_spl][2][4] */
     if (assign_splint) assign_splint[i] = ok ? (int16_t)(best >> 1) : (int16_t)-1;
     if (assign_strand) assign_strand[i] = ok ? ((best & 1) ? '-' : '+') : '?';
   }
+  return C3_E_OK;
+}
+
+// adapter finder of the post-processing step (replaces the blat call of C3POa_postprocessing.py:229-236): best local
+// affine alignment of every read of the resident batch against every entry of the splint table (= the adapters,
+// c3_set_splints) on both strands, traced back.  out[(i*n_ad + a)*2 + rc][12] = score, qStart, qEnd, tStart, tEnd
+// (PSL conventions: query = read, forward coordinates; target = adapter, forward coordinates), matches, mismatches,
+// qBaseInsert, tBaseInsert, qNumInsert, tNumInsert, read length.  score 0 = no alignment.
+extern "C" int c3_scan_adapters(c3_handle* h, int32_t* out) {
+  if (!h || h->n <= 0 || h->n_spl <= 0 || !out) return C3_E_STATE;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const size_t items = (size_t)h->n * h->n_spl * 2;
+  const long long dcap = (long long)(h->maxL + 1) * (h->max_spl + 1) + 64;
+  const int grid = (int)std::min<size_t>(items, (size_t)h->n_cus * 16);
+  DBuf res, dd;
+  HIPCHK(res.ensure(sizeof(int32_t) * 12 * items)); HIPCHK(dd.ensure((size_t)dcap * grid));
+  HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 64, h->stream));
+  AdapterArgs a; memset(&a, 0, sizeof(a));
+  a.b = dev_batch(h); a.p = dev_params(h->cfg); a.counter = h->d_counter.as<int>();
+  a.ad_codes = h->d_sp_codes.as<uint8_t>(); a.ad_len = h->d_sp_len.as<int>(); a.n_ad = h->n_spl;
+  a.D = dd.as<uint8_t>(); a.dcap = dcap; a.out = res.as<int32_t>();
+  c3k_launch_adapter(&a, grid, h->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, res.p, sizeof(int32_t) * 12 * items, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  res.release(); dd.release();
   return C3_E_OK;
 }
 

@@ -37,6 +37,14 @@ struct StitchArgs {
   C3Batch b; C3Info* info; const int* work; int n_work; const WinRec* wrec; const int* win_base; const uint8_t* wout; int wout_cap; char* cons;
   const uint8_t* zflag;
 };
+// adapter finder (k_adapter): every read x every entry of the splint table x both strands
+struct AdapterArgs {
+  C3Batch b; C3Params p; int* counter;
+  const uint8_t* ad_codes; const int* ad_len; int n_ad;
+  uint8_t* D; long long dcap;           // [grid][dcap] direction bytes
+  int32_t* out;                         // [n * n_ad * 2][12]
+};
+
 struct ZeroArgs {
   C3Batch b; C3Info* info; C3Params p; int* counter; const int* work; int n_work;
   uint8_t* D; long long dcap;           // [grid][dcap] direction bytes

@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <cerrno>
+#include <climits>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -337,4 +338,49 @@ extern "C" int c3_write_group(const c3_host_batch* b, const c3_read_result* res,
   }
   for (int fd : fds) if (close(fd) != 0) ok = false;
   return ok ? C3_E_OK : C3_E_ARG;
+}
+
+// ---- oligo-dT index matcher of the post-processing step (C3POa_postprocessing.py:266-285, match_index) ----------
+// seq is slid over every index (file order); the Levenshtein distance of seq[p : p+len(idx)] to idx is taken for every
+// position where the slice has the full length (at a position where it is too short for index k the reference breaks
+// out of the loop over indexes, so k+1.. are skipped there as well); per index the minimum counts.  Stable sort by
+// distance; the best index wins when its distance is < 2 and the runner-up is more than 1 further away.  Returns the
+// winning index number, -1 for '-'.  (The reference raises on an index that never fits and on fewer than two indexes;
+// both cases return -1 here.)
+namespace {
+int edit_distance(const char* a, const char* b, int n) {
+  int prev[256], cur[256];
+  if (n > 255) return n;
+  for (int j = 0; j <= n; ++j) prev[j] = j;
+  for (int i = 1; i <= n; ++i) {
+    cur[0] = i;
+    for (int j = 1; j <= n; ++j) {
+      int v = prev[j - 1] + (a[i - 1] != b[j - 1]);
+      v = std::min(v, prev[j] + 1); v = std::min(v, cur[j - 1] + 1);
+      cur[j] = v;
+    }
+    memcpy(prev, cur, sizeof(int) * (size_t)(n + 1));
+  }
+  return prev[n];
+}
+}  // namespace
+
+extern "C" int c3_match_index(const char* seq, int n, int n_idx, const char* idx_cat, const int64_t* idx_off) {
+  if (!seq || n_idx < 2 || !idx_cat || !idx_off) return -1;
+  std::vector<int> best((size_t)n_idx, INT32_MAX);
+  for (int p = 0; p < n; ++p) {
+    for (int k = 0; k < n_idx; ++k) {
+      const int len = (int)(idx_off[k + 1] - idx_off[k]);
+      if (p + len > n) break;                                   // the reference's `break` (not `continue`)
+      best[(size_t)k] = std::min(best[(size_t)k], edit_distance(seq + p, idx_cat + idx_off[k], len));
+    }
+  }
+  int i0 = -1, i1 = -1;                                         // first and second entry of the stable sort
+  for (int k = 0; k < n_idx; ++k) {
+    if (best[(size_t)k] == INT32_MAX) return -1;
+    if (i0 < 0 || best[(size_t)k] < best[(size_t)i0]) { i1 = i0; i0 = k; }
+    else if (i1 < 0 || best[(size_t)k] < best[(size_t)i1]) i1 = k;
+  }
+  if (best[(size_t)i0] < 2 && best[(size_t)i1] - best[(size_t)i0] > 1) return i0;
+  return -1;
 }

@@ -157,6 +157,13 @@ int c3_determine_consensus(c3_handle* h, int n, const char* const* subs, const c
  * (the diagonal sum of a perfect 51-base match: `matches > 50`, bin/preprocess.py:32). */
 int c3_scan_splints(c3_handle* h, int32_t* out, int16_t* assign_splint, char* assign_strand);
 
+/* adapter finder of the post-processing step (replaces the blat call of C3POa_postprocessing.py:229-236; fields as
+ * read by parse_blat, :238-264): best local affine alignment of every read of the resident batch against every entry
+ * of the splint table (load the adapters with c3_set_splints) on both strands.
+ * out[(i*n_adapters + a)*2 + rc][12] = score, qStart, qEnd, tStart, tEnd (PSL conventions, forward coordinates),
+ * matches, misMatches, qBaseInsert, tBaseInsert, qNumInsert, tNumInsert, read length; score 0 = no alignment. */
+int c3_scan_adapters(c3_handle* h, int32_t* out);
+
 /* zero_repeats(name, seq, qual, dangling, qual_dangling, subread_file) (determine_consensus.py:106-136):
  * d0 = first dangling piece, d1 = second; *out_len = 0 when there is no acceptable overlap or the
  * stitched sequence is shorter than min_len (args.mdistcutoff, determine_consensus.py:17). */
@@ -195,6 +202,11 @@ int c3_reader_next(c3_reader* r, int max_reads, int64_t max_bases, int min_len, 
 int c3_write_group(const c3_host_batch* b, const c3_read_result* res, const char* cons, const int64_t* cons_off,
                    const int16_t* splint_id, int n_splints, const char* const* cons_paths,
                    const char* const* sub_paths, int zero);
+
+/* match_index(seq, seq_to_idx) of C3POa_postprocessing.py:266-285 (oligo-dT demultiplexing): sliding Levenshtein
+ * distance of seq against every index (file order, idx_off[n_idx+1] into idx_cat); returns the winning index number or
+ * -1 for '-'.  Host code. */
+int c3_match_index(const char* seq, int n, int n_idx, const char* idx_cat, const int64_t* idx_off);
 
 #ifdef __cplusplus
 }

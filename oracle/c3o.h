@@ -25,6 +25,7 @@
  *   c3o_pairwise_consensus bin/consensus.py:4-81
  *   c3o_polish             bin/determine_consensus.py:56-99 (mappy overlaps + racon -q 5 -t 1)
  *   c3o_process_read       C3POa.py:110-173 + bin/determine_consensus.py:10-104
+ *   c3o_adapter_align      C3POa_postprocessing.py:229-264 (blat adapters vs consensus reads; parity unpinned)
  */
 #ifndef C3O_H
 #define C3O_H
@@ -130,6 +131,10 @@ int c3o_determine_consensus(const char* const* subs, const char* const* quals,
  * returns the stitched length (0 = no rescue). */
 int c3o_zero_repeats(const char* d0, const char* q0, int n0, const char* d1, const char* q1, int n1,
                      const c3o_params* P, char* out, int cap, int64_t* cells);
+
+/* adapter finder of the post-processing step (C3POa_postprocessing.py:229-264): out[12] = score, qStart, qEnd, tStart,
+ * tEnd, matches, misMatches, qBaseInsert, tBaseInsert, qNumInsert, tNumInsert, read length.  rc = 1: strand '-'. */
+int c3o_adapter_align(const char* read, int n, const char* adapter, int m, int rc, const c3o_params* P, int32_t* out);
 
 /* whole per-read path.  returns status; on C3O_OK cons/cons_len are set. */
 typedef struct {

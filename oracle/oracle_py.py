@@ -93,6 +93,16 @@ def scan_splints(seqs, splints, penalty=20, match=5, mismatch=-4):
     return tab, sid, bytes(strand)
 
 
+def adapter_align(read, adapter, rc=False, params=None):
+    """ORACLE of c3_scan_adapters for one (read, adapter, strand): 12 ints (score, qStart, qEnd, tStart, tEnd, matches,
+    misMatches, qBaseInsert, tBaseInsert, qNumInsert, tNumInsert, read length)"""
+    P = params or default_params()
+    out = np.zeros(12, dtype=np.int32)
+    rd, ad = _b(read), _b(adapter)
+    lib().c3o_adapter_align(rd, len(rd), ad, len(ad), 1 if rc else 0, C.byref(P), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def savgol(y, window=41, order=2):
     y = np.ascontiguousarray(y, dtype=np.float64)
     out = np.empty_like(y)
