@@ -223,7 +223,9 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         }
         const int hb = act ? h9 : INT32_MIN;
         const int rb = wave_max(hb);
-        const int left = wave_min(hb == rb ? j : INT32_MAX / 2), right = wave_max(hb == rb ? j : -1);
+        // first / last column holding the row maximum: columns are beg + lane, so one ballot replaces two reductions
+        const unsigned long long mxm = __ballot(hb == rb);
+        const int left = beg + __builtin_ctzll(mxm), right = beg + 63 - __builtin_clzll(mxm);
         if (lane == 0) {
           L.beg[slot] = beg; L.end[slot] = end; L.rl[slot] = left; L.rr[slot] = right; L.inl[slot] = 1;
           c.rbeg[idx] = beg; c.rend[idx] = end; c.roff[idx] = ro;
