@@ -71,11 +71,18 @@ def gpu_find_splints(args, align_psl, batch_reads=131072, handle=None):
             h.upload_host(hb, b"?" * hb.n, np.zeros(hb.n, dtype=np.int16))
             tab, sid, st = h.scan_splints()
             names, lens = hb.names(), np.diff(hb.off)
-            rows = []
-            for i in np.nonzero(sid >= 0)[0]:
-                k = int(sid[i])
-                e = tab[i, k, 1 if st[i] == 45 else 0]
-                rows.append(psl_row(names[i], int(lens[i]), splints[k][0], len(splints[k][1]), chr(st[i]), e[0], e[1], h.cfg.conk_match))
+            # vectorised PSL fields (psl_row is the scalar statement of the same row)
+            acc = np.nonzero(sid >= 0)[0]
+            k = sid[acc].astype(np.int64)
+            rc = (np.frombuffer(st, dtype=np.uint8)[acc] == 45).astype(np.int64)
+            e = tab[acc, k, rc]
+            slen = np.array([len(s[1]) for s in splints], dtype=np.int64)[k]
+            m = np.minimum(((np.sqrt(1.0 + 8.0 * np.maximum(e[:, 0], 0) / h.cfg.conk_match) - 1.0) / 2.0).astype(np.int64), slen)
+            q0 = np.clip(e[:, 1].astype(np.int64), 0, lens[acc])
+            q1 = np.minimum(lens[acc], q0 + slen)
+            rows = ["%d\t%d\t0\t0\t0\t0\t0\t0\t%s\t%s\t%d\t%d\t%d\t%s\t%d\t0\t%d\t1\t%d,\t%d,\t0," %
+                    (m[x], slen[x] - m[x], "-" if rc[x] else "+", names[i], lens[i], q0[x], q1[x], splints[k[x]][0], slen[x], slen[x], slen[x], q0[x])
+                    for x, i in enumerate(acc.tolist())]
             if rows:
                 out.write("\n".join(rows) + "\n")
             n_rows += len(rows)
