@@ -179,10 +179,24 @@ __device__ __forceinline__ void prep_one(const PrepArgs& a, int wi, int lane, ui
       else if (i == ns && hf) { lb = 0; le = info->front_end; }
       else { lb = info->tail_beg; le = L; }
       // first / last aligned base of the layer, and per window
+      // Only the first / last base of every run of equal window numbers inside a 64-base chunk touches memory: 64
+      // lanes hammering one address with atomicMin/atomicMax (two L2 atomics per base) was the bulk of this kernel.
       int qf = INT32_MAX, ql = -1;
-      for (int k = lb + lane; k < le; k += 64) {
-        int t = tpos[k];
-        if (t >= 0) { qf = min(qf, k); ql = max(ql, k); int w = t / WL; atomicMin(&lwf[i * nwin + w], k); atomicMax(&lwl[i * nwin + w], k); }
+      for (int k0 = lb; k0 < le; k0 += 64) {
+        const int k = k0 + lane;
+        const int t = k < le ? tpos[k] : -1;
+        const bool valid = t >= 0;
+        const int w = valid ? t / WL : -1;
+        const unsigned long long vm = __ballot(valid);
+        const unsigned long long below = vm & ((1ull << lane) - 1ull);
+        const unsigned long long above = lane == 63 ? 0ull : (vm & ~((2ull << lane) - 1ull));
+        const int pl = below ? 63 - __builtin_clzll(below) : lane, nx = above ? __builtin_ctzll(above) : lane;
+        const int wp = __shfl(w, pl), wn = __shfl(w, nx);
+        if (valid) {
+          qf = min(qf, k); ql = max(ql, k);
+          if (!below || wp != w) atomicMin(&lwf[i * nwin + w], k);
+          if (!above || wn != w) atomicMax(&lwl[i * nwin + w], k);
+        }
       }
       qf = wave_min(qf); ql = wave_max(ql);
       WSYNC();
