@@ -81,8 +81,8 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 // carries no vector loads on its common path (descriptors arrive 64 rows at a time and are broadcast
 // with v_readlane).  Rows with a successor more than PR-1 rows ahead, or wider than a ring slot,
 // also go to the global arena; the direction words always do (4 B per cell).
-#define PW 96       // ring slot width (cells)
-#define PR 8        // ring rows
+#define PW 128      // ring slot width (cells)
+#define PR 4        // ring rows
 #define PQW 112     // packed query words kept in LDS (1792 bases); longer subreads read the packed read
 struct PoaLds { int H[PR][PW], E1[PR][PW], E2[PR][PW]; int beg[PR], end[PR], rl[PR], rr[PR], inl[PR]; unsigned qpk[PQW]; };
 __shared__ PoaLds L;     // file scope: accesses stay in the LDS address space (ds_*, lgkmcnt only)
@@ -473,7 +473,10 @@ __device__ void normalize_len(const uint8_t* row, int msa_len, const uint8_t* qu
   if (n != msa_len) { int gap = 0; while (gap < msa_len && row[msa_len - 1 - gap] == 4) { out[n] = out[n - 1]; ++n; ++gap; } }
 }
 
-__global__ __launch_bounds__(64) void k_poa(PoaArgs a) {
+// 6 waves/SIMD (80 VGPRs, 26 spilled outside the row loop) with a 4-row LDS ring (6.7 KB per wave, 24 waves per CU):
+// 59.4 ms per 32768 cfg2 reads against 67.8 ms at 4 waves/SIMD with the 8-row ring -- the row loop is a dependent
+// chain (scan -> next row), so resident waves are what hides its latency.
+__global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
   const int lane = wave_lane();
   const int slot = blockIdx.x;
   Ctx c;
