@@ -484,7 +484,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     const size_t N = (size_t)Ncap;
     const int NI = 18;
     const size_t per_slot = N * (NI * 4 + 8 + 2) + N * K * 16 + (size_t)hcap * 6;
-    const int slots = auto_slots(h, h->cfg.slots_win, per_slot, n_win, 16);
+    const int slots = auto_slots(h, h->cfg.slots_win, per_slot, n_win, 20);
     HIPCHK(h->s_win_i.ensure(sizeof(int) * N * NI * slots + 64)); HIPCHK(h->s_win_nk.ensure(sizeof(int) * N * K * 4 * slots));
     HIPCHK(h->s_win_h.ensure(sizeof(int32_t) * (size_t)hcap * slots)); HIPCHK(h->s_win_d.ensure(sizeof(uint16_t) * (size_t)hcap * slots));
     HIPCHK(h->s_win_b.ensure(N * 2 * slots)); HIPCHK(h->s_win_sc.ensure(sizeof(long long) * N * slots));
@@ -495,7 +495,8 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     a.draft = h->d_draft.as<uint8_t>();
     a.ibase = h->s_win_i.as<int>(); a.ebase = h->s_win_nk.as<int>();
     a.base = h->s_win_b.as<uint8_t>(); a.score = h->s_win_sc.as<long long>();
-    a.H = h->s_win_h.as<int32_t>(); a.D = h->s_win_d.as<uint16_t>(); a.rdesc = h->s_win_desc.as<uint4>(); a.Ncap = Ncap; a.K = K; a.hcap = hcap;
+    a.H = h->s_win_h.as<int32_t>(); a.D = h->s_win_d.as<uint16_t>(); a.rdesc = h->s_win_desc.as<uint4>(); a.Ncap = Ncap; a.K = K; a.hcap = hcap; a.Lcap = std::min(Ncap, 2 * WL + 30 * NLcap);
+    if (const char* e = getenv("C3_DEBUG_WIN_LCAP")) a.Lcap = std::max(64, std::min(Ncap, atoi(e)));   // test hook: forces the global-scratch consensus path
     a.wout = h->d_wout.as<uint8_t>(); a.wout_cap = wout_cap;
     HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 256, h->stream));
     a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);

@@ -31,6 +31,7 @@ struct WinArgs {
   const uint8_t* draft;
   uint8_t* base; int* ibase; int* ebase; long long* score;
   int32_t* H; uint16_t* D; uint4* rdesc; int Ncap, K; long long hcap; uint8_t* wout; int wout_cap;
+  int Lcap;                               // nodes the LDS consensus sweep can hold (<= Ncap)
   unsigned long long* phases;
 };
 struct StitchArgs {

@@ -559,9 +559,97 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
   }
 }
 
-// 4 waves/SIMD (128 VGPRs, 38 spilled to scratch outside the row loops) measured 12 % faster than 3 waves/SIMD
-// (168 VGPRs, no spills): 86.9 vs 98.3 ms for 32768 cfg2 reads.  The 10.4 KB of LDS per wave caps a CU at 15 waves.
-__global__ __launch_bounds__(64, 4) void k_window(WinArgs a) {
+// spoa heaviest bundle of one window graph -> consensus bases in out[]; returns their number (-1: does not fit).
+// Scores / predecessors live in s_score / s_pred: the LDS arrays when the graph fits them (the usual case), a slice of
+// the slot's DP scratch in global memory otherwise -- the function is inlined at both call sites so each copy keeps its
+// own address space.  The forward sweep takes the nodes 64 at a time: their in-edges are fetched in parallel, then
+// consumed in order with lane broadcasts (no dependent global loads on the serial path).
+__device__ __forceinline__ int win_consensus(WCtx& c, int* s_score, unsigned short* s_pred, int tgs, int nl, uint8_t* out, int wout_cap, int lane) {
+  int olen = 0;
+  const int K = c.K, n = c.n;
+  for (int v = lane; v < n; v += 64) { s_score[v] = -1; s_pred[v] = 0xffff; }
+  WSYNC();
+  int max_id = 0;
+  for (int i0 = 0; i0 < n; i0 += 64) {
+    const int i = i0 + lane;
+    int v = 0, nin = 0, u0 = 0, w0 = 0, u1 = 0, w1 = 0;
+    if (i < n) {
+      v = c.order()[i]; nin = c.n_in()[v];
+      if (nin > 0) { u0 = c.in_from()[v * K]; w0 = c.in_w()[v * K]; }
+      if (nin > 1) { u1 = c.in_from()[v * K + 1]; w1 = c.in_w()[v * K + 1]; }
+    }
+    const int cnt = min(64, n - i0);
+    for (int t = 0; t < cnt; ++t) {
+      const int vv = wave_bcast(v, t), nn = wave_bcast(nin, t);
+      int sc = -1, pr = -1;
+      for (int k = 0; k < nn; ++k) {
+        int u, w;
+        if (k == 0) { u = wave_bcast(u0, t); w = wave_bcast(w0, t); }
+        else if (k == 1) { u = wave_bcast(u1, t); w = wave_bcast(w1, t); }
+        else { u = c.in_from()[vv * K + k]; w = c.in_w()[vv * K + k]; }
+        if (sc < w || (sc == w && s_score[pr] <= s_score[u])) { sc = w; pr = u; }
+      }
+      if (pr != -1) sc += s_score[pr];
+      if (lane == 0) { s_score[vv] = sc; s_pred[vv] = (unsigned short)pr; }
+      __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the LDS write has landed
+      if (s_score[max_id] < sc) max_id = vv;
+    }
+  }
+  WSYNC();
+  if (c.n_out()[max_id] > 0) {
+    // branch completion (rare): spill to the global arrays and run spoa's re-scoring there
+    for (int v = lane; v < n; v += 64) { c.score[v] = s_score[v]; c.pred()[v] = s_pred[v] == 0xffff ? -1 : (int)s_pred[v]; }
+    WSYNC();
+    if (lane == 0) {
+      while (c.n_out()[max_id] > 0) {
+        const int v = max_id;
+        for (int k = 0; k < c.n_out()[v]; ++k) {
+          const int t2 = c.out_to()[v * K + k];
+          for (int e = 0; e < c.n_in()[t2]; ++e) { int u = c.in_from()[t2 * K + e]; if (u != v) c.score[u] = -1; }
+        }
+        long long ms = 0; int mid = -1;
+        for (int i = c.index()[v] + 1; i < n; ++i) {
+          const int x = c.order()[i];
+          c.score[x] = -1; c.pred()[x] = -1;
+          for (int k = 0; k < c.n_in()[x]; ++k) {
+            const int u = c.in_from()[x * K + k]; const long long w = c.in_w()[x * K + k];
+            if (c.score[u] == -1) continue;
+            if (c.score[x] < w || (c.score[x] == w && c.score[c.pred()[x]] <= c.score[u])) { c.score[x] = w; c.pred()[x] = u; }
+          }
+          if (c.pred()[x] != -1) c.score[x] += c.score[c.pred()[x]];
+          if (ms < c.score[x]) { ms = c.score[x]; mid = x; }
+        }
+        if (mid < 0) break;
+        max_id = mid;
+      }
+      c.anchor()[0] = max_id;
+    }
+    WSYNC();
+    max_id = c.anchor()[0];
+    for (int v = lane; v < n; v += 64) s_pred[v] = c.pred()[v] < 0 ? 0xffff : (unsigned short)c.pred()[v];
+    WSYNC();
+  }
+  // consensus path (LDS pointer chase), coverage trim, emit
+  int nc = 0;
+  for (int v = max_id; v != 0xffff; v = s_pred[v]) { if (lane == 0) c.opn()[nc] = v; ++nc; }
+  WSYNC();
+  int b = 0, e = nc - 1;      // positions in forward order: forward[i] = opn[nc-1-i]
+  if (tgs) {
+    const int avg = nl / 2;
+    for (; b < nc; ++b) if (c.ncov()[c.opn()[nc - 1 - b]] >= avg) break;
+    for (; e >= 0; --e) if (c.ncov()[c.opn()[nc - 1 - e]] >= avg) break;
+    if (b >= e) { b = 0; e = nc - 1; }
+  }
+  if (e - b + 1 > wout_cap) olen = -1;
+  else { for (int i = b + lane; i <= e; i += 64) out[i - b] = c.base()[c.opn()[nc - 1 - i]]; olen = e - b + 1; }
+  return olen;
+}
+
+// Occupancy is what hides the latency of the dependent row chain: 3 waves/SIMD (168 VGPRs) 98.3 ms, 4 waves (128 VGPRs,
+// 38 spilled outside the row loops) 86.9 ms per 32768 cfg2 reads; with the LDS sweep sized for 2*WL+30*NL nodes (6.9 KB
+// per wave, larger graphs fall back to global scratch) 5 waves/SIMD run 65.5 ms against 72.2 ms; 6 waves spill into the
+// row loops (76 ms).
+__global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
   const int lane = wave_lane();
   const int slot = blockIdx.x;
   WCtx c;
@@ -572,7 +660,7 @@ __global__ __launch_bounds__(64, 4) void k_window(WinArgs a) {
   c.K = a.K; c.Ncap = a.Ncap; c.hcap = a.hcap;
   const C3Params& P = a.p;
   extern __shared__ int lds_dyn[];                      // [Ncap] scores + [Ncap] u16 predecessors
-  int* s_score = lds_dyn; unsigned short* s_pred = (unsigned short*)(lds_dyn + a.Ncap);
+  int* s_score = lds_dyn; unsigned short* s_pred = (unsigned short*)(lds_dyn + a.Lcap);
   // the same LDS holds the row-type bitmasks of the layer being aligned (DP rows + traceback; the consensus sweep comes later)
   unsigned long long* m2bits = (unsigned long long*)lds_dyn; unsigned long long* mabits = m2bits + ((a.Ncap + 64) >> 6) + 1;
   PH_DECL
@@ -787,87 +875,9 @@ __global__ __launch_bounds__(64, 4) void k_window(WinArgs a) {
         PH_MARK(7)
       }
       if (!fail) {
-        // ---- spoa heaviest bundle.  Scores / predecessors live in LDS; the forward sweep takes the
-        // nodes 64 at a time: their in-edges are fetched in parallel, then consumed in order with
-        // lane broadcasts (no dependent global loads on the serial path).
-        {
-          const int K = c.K, n = c.n;
-          for (int v = lane; v < n; v += 64) { s_score[v] = -1; s_pred[v] = 0xffff; }
-          WSYNC();
-          int max_id = 0;
-          for (int i0 = 0; i0 < n; i0 += 64) {
-            const int i = i0 + lane;
-            int v = 0, nin = 0, u0 = 0, w0 = 0, u1 = 0, w1 = 0;
-            if (i < n) {
-              v = c.order()[i]; nin = c.n_in()[v];
-              if (nin > 0) { u0 = c.in_from()[v * K]; w0 = c.in_w()[v * K]; }
-              if (nin > 1) { u1 = c.in_from()[v * K + 1]; w1 = c.in_w()[v * K + 1]; }
-            }
-            const int cnt = min(64, n - i0);
-            for (int t = 0; t < cnt; ++t) {
-              const int vv = wave_bcast(v, t), nn = wave_bcast(nin, t);
-              int sc = -1, pr = -1;
-              for (int k = 0; k < nn; ++k) {
-                int u, w;
-                if (k == 0) { u = wave_bcast(u0, t); w = wave_bcast(w0, t); }
-                else if (k == 1) { u = wave_bcast(u1, t); w = wave_bcast(w1, t); }
-                else { u = c.in_from()[vv * K + k]; w = c.in_w()[vv * K + k]; }
-                if (sc < w || (sc == w && s_score[pr] <= s_score[u])) { sc = w; pr = u; }
-              }
-              if (pr != -1) sc += s_score[pr];
-              if (lane == 0) { s_score[vv] = sc; s_pred[vv] = (unsigned short)pr; }
-              __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the LDS write has landed
-              if (s_score[max_id] < sc) max_id = vv;
-            }
-          }
-          WSYNC();
-          if (c.n_out()[max_id] > 0) {
-            // branch completion (rare): spill to the global arrays and run spoa's re-scoring there
-            for (int v = lane; v < n; v += 64) { c.score[v] = s_score[v]; c.pred()[v] = s_pred[v] == 0xffff ? -1 : (int)s_pred[v]; }
-            WSYNC();
-            if (lane == 0) {
-              while (c.n_out()[max_id] > 0) {
-                const int v = max_id;
-                for (int k = 0; k < c.n_out()[v]; ++k) {
-                  const int t2 = c.out_to()[v * K + k];
-                  for (int e = 0; e < c.n_in()[t2]; ++e) { int u = c.in_from()[t2 * K + e]; if (u != v) c.score[u] = -1; }
-                }
-                long long ms = 0; int mid = -1;
-                for (int i = c.index()[v] + 1; i < n; ++i) {
-                  const int x = c.order()[i];
-                  c.score[x] = -1; c.pred()[x] = -1;
-                  for (int k = 0; k < c.n_in()[x]; ++k) {
-                    const int u = c.in_from()[x * K + k]; const long long w = c.in_w()[x * K + k];
-                    if (c.score[u] == -1) continue;
-                    if (c.score[x] < w || (c.score[x] == w && c.score[c.pred()[x]] <= c.score[u])) { c.score[x] = w; c.pred()[x] = u; }
-                  }
-                  if (c.pred()[x] != -1) c.score[x] += c.score[c.pred()[x]];
-                  if (ms < c.score[x]) { ms = c.score[x]; mid = x; }
-                }
-                if (mid < 0) break;
-                max_id = mid;
-              }
-              c.anchor()[0] = max_id;
-            }
-            WSYNC();
-            max_id = c.anchor()[0];
-            for (int v = lane; v < n; v += 64) s_pred[v] = c.pred()[v] < 0 ? 0xffff : (unsigned short)c.pred()[v];
-            WSYNC();
-          }
-          // consensus path (LDS pointer chase), coverage trim, emit
-          int nc = 0;
-          for (int v = max_id; v != 0xffff; v = s_pred[v]) { if (lane == 0) c.opn()[nc] = v; ++nc; }
-          WSYNC();
-          int b = 0, e = nc - 1;      // positions in forward order: forward[i] = opn[nc-1-i]
-          if (rec.tgs) {
-            const int avg = nl / 2;
-            for (; b < nc; ++b) if (c.ncov()[c.opn()[nc - 1 - b]] >= avg) break;
-            for (; e >= 0; --e) if (c.ncov()[c.opn()[nc - 1 - e]] >= avg) break;
-            if (b >= e) { b = 0; e = nc - 1; }
-          }
-          if (e - b + 1 > a.wout_cap) olen = -1;
-          else { for (int i = b + lane; i <= e; i += 64) out[i - b] = c.base()[c.opn()[nc - 1 - i]]; olen = e - b + 1; }
-        }
+        // ---- consensus: LDS-resident sweep; graphs larger than the LDS arrays use the slot's DP scratch instead
+        if (c.n <= a.Lcap) olen = win_consensus(c, s_score, s_pred, rec.tgs, nl, out, a.wout_cap, lane);
+        else olen = win_consensus(c, (int*)c.H, (unsigned short*)(c.H + c.Ncap), rec.tgs, nl, out, a.wout_cap, lane);
         PH_MARK(8)
         if (olen < 0) { fail = 1; olen = 0; } else polished = 1;
       }
@@ -914,7 +924,7 @@ __global__ __launch_bounds__(64) void k_stitch(StitchArgs a) {
 
 extern "C" void c3k_launch_prep(const PrepArgs* a, int slots, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(slots), dim3(64), 0, s, *a); }
 extern "C" void c3k_launch_window(const WinArgs* a, int slots, hipStream_t s) {
-  const size_t lds = (size_t)a->Ncap * 6 + 16;
+  const size_t lds = (size_t)a->Lcap * 6 + 16;
   hipLaunchKernelGGL(k_window, dim3(slots), dim3(64), lds, s, *a);
 }
 extern "C" void c3k_launch_stitch(const StitchArgs* a, int grid, hipStream_t s) { hipLaunchKernelGGL(k_stitch, dim3(grid), dim3(64), 0, s, *a); }

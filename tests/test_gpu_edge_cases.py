@@ -285,3 +285,10 @@ def test_cli_gpu_splint_finder(tmp_path):
     C3POa.main(C3POa.parse_args(["-r", fq, "-s", fa, "-o", out]))                 # resume: PSL reused
     assert os.stat(out + "/tmp/splint_to_read_alignments.psl").st_mtime_ns == mtime
     assert sorted(fastx_read(out + "/Splint1/R2C2_Consensus.fasta")) == first
+
+
+def test_window_consensus_global_scratch_path(O, monkeypatch):
+    """graphs larger than the LDS sweep arrays take the global-scratch copy of the consensus sweep: same results"""
+    monkeypatch.setenv("C3_DEBUG_WIN_LCAP", "64")                 # every window graph is "too large" for LDS
+    recs = list(synth.generate("cfg1", n_reads=24))
+    _compare(O, [synth.SPLINT1], [(r[1], r[2]) for r in recs], [r[3] for r in recs], [0] * len(recs))
