@@ -16,7 +16,7 @@
 #include "c3_args.h"
 
 #define PK_T 256
-#define SG_T 2048        /* outputs per LDS tile */
+#define SG_T 1024        /* outputs per LDS tile */
 #define SG_H 64          /* largest halo (iters * half) the tiled path supports; 3 * 20 = 60 for the reference's settings */
 
 
