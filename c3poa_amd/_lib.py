@@ -20,7 +20,7 @@ EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_create", "c
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
            "c3_call_peaks", "c3_poa_msa", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
            "c3_reader_open", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_write_group",
-           "c3_scan_adapters", "c3_match_index"]
+           "c3_scan_adapters", "c3_match_index", "c3_match_index_batch"]
 
 
 class Config(C.Structure):
@@ -94,6 +94,7 @@ def load():
     lib.c3_scan_splints.argtypes = [vp, vp, vp, vp]
     lib.c3_scan_adapters.argtypes = [vp, vp]
     lib.c3_match_index.argtypes = [cp, C.c_int, C.c_int, cp, vp]
+    lib.c3_match_index_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, cp, vp, vp]
     lib.c3_reader_open.argtypes = [cp, C.c_int, C.POINTER(vp)]
     lib.c3_reader_close.argtypes = [vp]
     lib.c3_reader_close.restype = None
@@ -302,6 +303,24 @@ class Handle:
         tab = np.zeros((self.n, self.n_splints, 2, 12), dtype=np.int32)
         self._chk(self.lib.c3_scan_adapters(self.h, tab.ctypes.data))
         return tab
+
+    def match_index_batch(self, pieces, index_seqs):
+        """c3_match_index_batch: winning index number (or -1) for every piece (str, <= 64 bases)"""
+        n = len(pieces)
+        if n == 0:
+            return np.zeros(0, dtype=np.int32)
+        buf = np.zeros((n, 64), dtype=np.uint8)
+        lens = np.zeros(n, dtype=np.int32)
+        for i, pc in enumerate(pieces):
+            b = _b(pc)
+            lens[i] = len(b)
+            buf[i, :len(b)] = np.frombuffer(b, dtype=np.uint8)
+        bs = [_b(x) for x in index_seqs]
+        off = np.zeros(len(bs) + 1, dtype=np.int64)
+        np.cumsum([len(b) for b in bs], out=off[1:])
+        out = np.zeros(n, dtype=np.int32)
+        self._chk(self.lib.c3_match_index_batch(self.h, n, buf.ctypes.data, lens.ctypes.data, len(bs), b"".join(bs), off.ctypes.data, out.ctypes.data))
+        return out
 
     def zero_repeats(self, d0, q0, d1, q1, min_len=0):
         b0, b1 = _b(d0), _b(d1)

@@ -11,6 +11,7 @@
 // ---- kernel launchers (one translation unit per kernel family) --------------------------
 extern "C" void c3k_launch_conk(const ConkArgs*, int, int, int, hipStream_t);
 extern "C" void c3k_launch_adapter(const AdapterArgs*, int, hipStream_t);
+extern "C" void c3k_launch_match_index(const char*, const int*, int, int, const char*, const long long*, int*, hipStream_t);
 extern "C" void c3k_launch_peaks(const PeaksArgs*, int, hipStream_t);
 extern "C" void c3k_launch_poa(const PoaArgs*, int, hipStream_t);
 extern "C" void c3k_launch_prep(const PrepArgs*, int, hipStream_t);
@@ -780,6 +781,32 @@ extern "C" int c3_scan_adapters(c3_handle* h, int32_t* out) {
   HIPCHK(hipMemcpyAsync(out, res.p, sizeof(int32_t) * 12 * items, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   res.release(); dd.release();
+  return C3_E_OK;
+}
+
+// match_index for a batch of pieces (C3POa_postprocessing.py:266-285): pieces = n slots of 64 bytes, lens[n] (<= 64);
+// at most 16 indexes of at most 32 bases (idx_off[n_idx+1] into idx_cat); out[i] = winning index number or -1.
+extern "C" int c3_match_index_batch(c3_handle* h, int n, const char* pieces, const int32_t* lens, int n_idx,
+                                    const char* idx_cat, const int64_t* idx_off, int32_t* out) {
+  if (!h || n <= 0 || !pieces || !lens || !idx_cat || !idx_off || !out) return C3_E_ARG;
+  if (n_idx < 2) { for (int i = 0; i < n; ++i) out[i] = -1; return C3_E_OK; }      // the reference needs a runner-up
+  if (n_idx > 16) return c3_fail(h, C3_E_LIMIT, "more than 16 indexes");
+  for (int k = 0; k < n_idx; ++k) if (idx_off[k + 1] - idx_off[k] > 32 || idx_off[k + 1] < idx_off[k]) return c3_fail(h, C3_E_LIMIT, "index longer than 32 bases");
+  for (int i = 0; i < n; ++i) if (lens[i] < 0 || lens[i] > 64) return c3_fail(h, C3_E_ARG, "piece longer than 64 bases");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  DBuf dp, dl, di, doff, dout;
+  const size_t ib = (size_t)idx_off[n_idx];
+  HIPCHK(dp.ensure((size_t)n * 64)); HIPCHK(dl.ensure(sizeof(int) * (size_t)n)); HIPCHK(di.ensure(ib + 16));
+  HIPCHK(doff.ensure(sizeof(int64_t) * (size_t)(n_idx + 1))); HIPCHK(dout.ensure(sizeof(int) * (size_t)n));
+  HIPCHK(hipMemcpyAsync(dp.p, pieces, (size_t)n * 64, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(dl.p, lens, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(di.p, idx_cat, ib, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(doff.p, idx_off, sizeof(int64_t) * (size_t)(n_idx + 1), hipMemcpyHostToDevice, h->stream));
+  c3k_launch_match_index(dp.as<char>(), dl.as<int>(), n, n_idx, di.as<char>(), doff.as<long long>(), dout.as<int>(), h->stream);
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemcpyAsync(out, dout.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  dp.release(); dl.release(); di.release(); doff.release(); dout.release();
   return C3_E_OK;
 }
 

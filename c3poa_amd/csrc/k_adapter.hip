@@ -109,3 +109,53 @@ __global__ __launch_bounds__(64) void k_adapter(AdapterArgs a) {
 }
 
 extern "C" void c3k_launch_adapter(const AdapterArgs* a, int grid, hipStream_t s) { hipLaunchKernelGGL(k_adapter, dim3(grid), dim3(64), 0, s, *a); }
+
+// ---- oligo-dT index matcher (C3POa_postprocessing.py:266-285, match_index) for a whole batch of pieces -------------
+// One lane per piece (the 20-mer cut next to an adapter): sliding Levenshtein distance against every index, the
+// reference's quirks included (a slice that is too short for index k ends the loop over indexes at that position;
+// stable order; winner needs distance < 2 and a runner-up more than 1 further away).  Same function as the host
+// statement c3_match_index (c3_io.cpp), which the golden cases of the reference pin.
+#define IDX_MAX 32      // longest index handled on the device
+#define PIECE_W 64      // bytes per piece slot
+__global__ __launch_bounds__(64) void k_match_index(const char* pieces, const int* lens, int n, int n_idx,
+                                                     const char* idx_cat, const long long* idx_off, int* out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const char* seq = pieces + (size_t)t * PIECE_W;
+  const int L = lens[t];
+  int best[16];
+  for (int k = 0; k < 16; ++k) best[k] = INT32_MAX;
+  for (int p = 0; p < L; ++p) {
+    for (int k = 0; k < n_idx; ++k) {
+      const int len = (int)(idx_off[k + 1] - idx_off[k]);
+      if (p + len > L) break;
+      const char* b = idx_cat + idx_off[k];
+      int prev[IDX_MAX + 1], cur[IDX_MAX + 1];
+      for (int j = 0; j <= len; ++j) prev[j] = j;
+      for (int i = 1; i <= len; ++i) {
+        cur[0] = i;
+        const char ca = seq[p + i - 1];
+        for (int j = 1; j <= len; ++j) {
+          int v = prev[j - 1] + (ca != b[j - 1]);
+          v = min(v, prev[j] + 1); v = min(v, cur[j - 1] + 1);
+          cur[j] = v;
+        }
+        for (int j = 0; j <= len; ++j) prev[j] = cur[j];
+      }
+      best[k] = min(best[k], prev[len]);
+    }
+  }
+  int i0 = -1, i1 = -1, res = -1; bool bad = false;
+  for (int k = 0; k < n_idx; ++k) {
+    if (best[k] == INT32_MAX) { bad = true; break; }
+    if (i0 < 0 || best[k] < best[i0]) { i1 = i0; i0 = k; }
+    else if (i1 < 0 || best[k] < best[i1]) i1 = k;
+  }
+  if (!bad && i0 >= 0 && i1 >= 0 && best[i0] < 2 && best[i1] - best[i0] > 1) res = i0;
+  out[t] = res;
+}
+
+extern "C" void c3k_launch_match_index(const char* pieces, const int* lens, int n, int n_idx, const char* idx_cat,
+                                       const long long* idx_off, int* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_match_index, dim3((n + 63) / 64), dim3(64), 0, s, pieces, lens, n, n_idx, idx_cat, idx_off, out);
+}

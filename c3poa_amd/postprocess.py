@@ -116,22 +116,27 @@ class _Outputs:
         self.fh = {}
 
 
-def write_fasta_file(args, path, adapter_dict, reads, seq_to_idx, idx_to_seq):
-    """:287-398 -- classification, trimming, orientation, demultiplexing; returns the number of reads written"""
+def match_batch_host(pieces, index_seqs):
+    """one native c3_match_index call per piece (host; what the CPU tests use)"""
+    return np.array([_lib.match_index(p, index_seqs) for p in pieces], dtype=np.int32)
+
+
+def match_batch_gpu(pieces, index_seqs, handle=None):
+    """c3_match_index_batch: one lane per piece on the GPU"""
+    h = handle or _lib.Handle()
+    out = h.match_index_batch(pieces, index_seqs)
+    if handle is None:
+        h.close()
+    return out
+
+
+def write_fasta_file(args, path, adapter_dict, reads, seq_to_idx, idx_to_seq, match_batch=match_batch_gpu):
+    """:287-398 -- classification, trimming, orientation, demultiplexing; returns the number of reads written.
+    Two passes instead of the reference's one: the reads that pass the adapter rules are collected first so that all
+    oligo-dT pieces are matched in one batch (match_index, :266-285), then the records are written in read order."""
     undirectional, barcoded, trim = args.undirectional, args.barcoded, args.trim
     odt = bool(seq_to_idx)
-    outs = _Outputs()
-    if odt:
-        for idx in idx_to_seq:
-            if os.path.exists(path + idx):
-                shutil.rmtree(path + idx)
-        mux = open(path + MUX_TSV, "w")
-    else:
-        for name in (FLC, FLC_LEFT, FLC_RIGHT):
-            open(path + name, "w").close()
-    if barcoded:
-        open(path + FLC_10X, "w").close()
-    written = 0
+    keep = []                                              # (name, p_pos, m_pos, direction)
     for name, sequence in reads.items():
         plus = sorted((x for x in adapter_dict[name]["+"] if x[0] != "-"), key=lambda x: x[2])
         minus = sorted((x for x in adapter_dict[name]["-"] if x[0] != "-"), key=lambda x: x[2])
@@ -146,13 +151,35 @@ def write_fasta_file(args, path, adapter_dict, reads, seq_to_idx, idx_to_seq):
             direction = "+" if plus[0][0] == "5Prime_adapter" else "-"
         else:
             continue
+        keep.append((name, p_pos, m_pos, direction))
+    fwd_pieces, rev_pieces, fwd_idx, rev_idx = [], [], [], []
+    if odt:
+        index_seqs = list(seq_to_idx)
+        for name, p_pos, m_pos, _d in keep:
+            sequence = reads[name]
+            fwd_pieces.append(sequence[p_pos - 4:p_pos + 16])
+            rev_pieces.append(revcomp(sequence[m_pos - 16:m_pos + 4]))
+        hits = match_batch(fwd_pieces + rev_pieces, index_seqs) if keep else np.zeros(0, dtype=np.int32)
+        names = [seq_to_idx[x] for x in index_seqs]
+        fwd_idx = [names[k] if k >= 0 else "-" for k in hits[:len(keep)]]
+        rev_idx = [names[k] if k >= 0 else "-" for k in hits[len(keep):]]
+    outs = _Outputs()
+    if odt:
+        for idx in idx_to_seq:
+            if os.path.exists(path + idx):
+                shutil.rmtree(path + idx)
+        mux = open(path + MUX_TSV, "w")
+    else:
+        for nm in (FLC, FLC_LEFT, FLC_RIGHT):
+            open(path + nm, "w").close()
+    if barcoded:
+        open(path + FLC_10X, "w").close()
+    for k, (name, p_pos, m_pos, direction) in enumerate(keep):
+        sequence = reads[name]
         dest = path
         if odt:
-            fwd_piece = sequence[p_pos - 4:p_pos + 16]
-            rev_piece = revcomp(sequence[m_pos - 16:m_pos + 4])
-            mux.write("%s\t%s\t%s\n" % (name, rev_piece, fwd_piece))
-            forward_index = match_index(fwd_piece, seq_to_idx)
-            reverse_index = match_index(rev_piece, seq_to_idx)
+            mux.write("%s\t%s\t%s\n" % (name, rev_pieces[k], fwd_pieces[k]))
+            forward_index, reverse_index = fwd_idx[k], rev_idx[k]
             idx_name = "no_index_found"
             if forward_index in idx_to_seq and reverse_index not in idx_to_seq:
                 direction, idx_name = "-", forward_index
@@ -175,11 +202,10 @@ def write_fasta_file(args, path, adapter_dict, reads, seq_to_idx, idx_to_seq):
             out5.write(">%s\n%s\n" % (out_name, sequence[m_pos:]))
             if barcoded:
                 outs.get(path, FLC_10X).write(">%s\n%sminus\n" % (out_name, sequence[p_pos:p_pos + 40]))
-        written += 1
     outs.close()
     if odt:
         mux.close()
-    return written
+    return len(keep)
 
 
 def _gzip_in_place(path):

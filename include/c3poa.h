@@ -203,6 +203,11 @@ int c3_write_group(const c3_host_batch* b, const c3_read_result* res, const char
                    const int16_t* splint_id, int n_splints, const char* const* cons_paths,
                    const char* const* sub_paths, int zero);
 
+/* match_index for a whole batch on the GPU (one lane per piece): pieces = n slots of 64 bytes, lens[n] <= 64, at most
+ * 16 indexes of at most 32 bases; out[i] = winning index number or -1.  Same function as c3_match_index below. */
+int c3_match_index_batch(c3_handle* h, int n, const char* pieces, const int32_t* lens, int n_idx,
+                         const char* idx_cat, const int64_t* idx_off, int32_t* out);
+
 /* match_index(seq, seq_to_idx) of C3POa_postprocessing.py:266-285 (oligo-dT demultiplexing): sliding Levenshtein
  * distance of seq against every index (file order, idx_off[n_idx+1] into idx_cat); returns the winning index number or
  * -1 for '-'.  Host code. */

@@ -118,3 +118,28 @@ def test_post_cli_oligo_dt_demux(tmp_path):
     assert seen == where
     tsv = open(out + "/R2C2_oligodT_multiplexing.tsv").read().splitlines()
     assert len(tsv) == 30 and all(len(l.split("\t")) == 3 for l in tsv)
+
+
+def test_match_index_batch_matches_reference_golden():
+    """GPU batch matcher == the reference's match_index on its golden cases, == the host statement on random pieces"""
+    import json
+    from c3poa_amd import _lib, postprocess
+    g = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "post_cases.json")))
+    names = [n for n, _s in g["indexes"]]
+    seqs = [s for _n, s in g["indexes"]]
+    h = _lib.Handle()
+    got = h.match_index_batch([c["seq"] for c in g["match_index"]], seqs)
+    assert [names[k] if k >= 0 else "-" for k in got] == [c["result"] for c in g["match_index"]]
+    rng = np.random.default_rng(12)
+    idx = [_rand(rng, 16), _rand(rng, 16), _rand(rng, 12), _rand(rng, 20), _rand(rng, 16)]       # mixed lengths: the `break` quirk
+    pieces = []
+    for i in range(3000):
+        base = list(idx[i % 5])
+        for _ in range(int(rng.integers(0, 4))):
+            base[int(rng.integers(0, len(base)))] = "ACGT"[int(rng.integers(0, 4))]
+        p = _rand(rng, int(rng.integers(0, 6))) + "".join(base) + _rand(rng, int(rng.integers(0, 6)))
+        pieces.append(p[:int(rng.integers(0, 30))])
+    pieces += ["", "A", "ACGT" * 16]
+    assert np.array_equal(h.match_index_batch(pieces, idx), postprocess.match_batch_host(pieces, idx))
+    assert np.array_equal(h.match_index_batch(pieces[:7], idx[:1]), np.full(7, -1))                # fewer than two indexes
+    h.close()

@@ -47,7 +47,7 @@ def test_parse_and_write_match_reference(post_golden, tmp_path):
         f = c["flags"]
         args = types.SimpleNamespace(undirectional=f.get("u", False), barcoded=f.get("b", False), trim=f.get("t", False), threads=1)
         ad = postprocess.parse_blat(path + postprocess.PSL_NAME, c["reads"])
-        postprocess.write_fasta_file(args, path, ad, c["reads"], seq_to_idx, idx_to_seq)
+        postprocess.write_fasta_file(args, path, ad, c["reads"], seq_to_idx, idx_to_seq, match_batch=postprocess.match_batch_host)
         got = _tree(path)
         assert got == c["files"], "case %d (%s)" % (k, f)
         assert sum(len(v) for v in got.values()) > 1000
