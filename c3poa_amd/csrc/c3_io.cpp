@@ -292,7 +292,7 @@ extern "C" int c3_write_group(const c3_host_batch* b, const c3_read_result* res,
                               const char* const* sub_paths, int zero) {
   if (!b || !res || !cons_off || !splint_id || n_splints <= 0 || !cons_paths || !sub_paths) return C3_E_ARG;
   int T = 1;
-  if (b->n >= 4096) { T = 6; if (const char* e = getenv("C3_WRITER_THREADS")) T = std::max(1, std::min(32, atoi(e))); }
+  if (b->n >= 4096) { T = 8; if (const char* e = getenv("C3_WRITER_THREADS")) T = std::max(1, std::min(32, atoi(e))); }
   typedef std::vector<std::string> Strs;
   std::vector<Strs> oc((size_t)T, Strs((size_t)n_splints)), os((size_t)T, Strs((size_t)n_splints));
   // phase 1: format (parallel)
