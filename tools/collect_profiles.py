@@ -51,6 +51,8 @@ def main():
                    "--warmup 0 --no-cpu` (cfg2, 100000 reads); KB per launch as reported, averaged over launches. "
                    "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE reports 1/2 of dword loads on this device, "
                    "calibrated with tools/pmc_calibrate.py; WRITE_SIZE exact).",
+           "calibration": {"source": "tools/pmc_calibrate.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this pool (round 1)",
+                           "bytes_read": 1073741824, "bytes_written": 1073741824, "FETCH_SIZE_KB": 524307.25, "WRITE_SIZE_KB": 1048576.0},
            "workload": "cfg2: 100000 reads/GPU/step", "kernels": {}}
     for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, 0) + write.get(k, 0))):
         if not k.startswith("k_"):
