@@ -123,7 +123,7 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    res, _ = h.results(with_consensus=False)
+    res, cons = h.results(with_consensus=(rank == 0))
     tm = h.timing()
     ok = res["status"] == 0
 
@@ -137,6 +137,9 @@ def main():
         alg_bytes = float(np.sum((lens + 3) // 4 + lens) + np.sum(res["cons_len"][ok]) + 4 * np.sum(res["n_peaks"]))
         achieved = alg_bytes / (avg[dom] * 1e-3) / 1e9
         cells = tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish"]
+        # consensus % identity vs the synthetic truth (second half of BASELINE.json's metric), on a sample
+        n_id = min(200, n_unique)
+        idents = np.array([synth.identity(cons[i], recs[i][3]) if cons[i] else 0.0 for i in range(n_id)])
         # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process;
         # the number comes from the committed rocprofv3 pass of THIS command when the workload matches
         traffic = None
@@ -156,6 +159,7 @@ def main():
                        if a.cfg == "cfg2" else "%s: %d reads/GPU/step" % (a.cfg, a.reads),
                        "stages": "conk+peaks/split+POA+polish", "reads_per_gpu_step": a.reads,
                        "consensus_ok": int(ok.sum()), "mean_read_len": float(lens.mean()),
+                       "identity_vs_truth": {"mean": round(float(idents.mean()), 5), "median": round(float(np.median(idents)), 5), "reads": int(n_id)},
                        "upload_ms": round(t_up * 1e3, 1),
                        "pcie_inclusive_reads_per_s": round(a.reads * world / (dt / a.steps + t_up), 1)},
             "roofline": {"bound": "hbm", "kernel": dom.replace("ms_", "k_"), "achieved": round(achieved, 3),
