@@ -18,7 +18,7 @@ ST_OK, ST_NOT_ASSIGNED, ST_NO_PEAKS, ST_NO_CONSENSUS, ST_TOO_SHORT, ST_LIMIT = r
 EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_create", "c3_destroy", "c3_last_error", "c3_set_splints",
            "c3_batch_upload", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_timing",
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
-           "c3_call_peaks", "c3_poa_msa", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
+           "c3_call_peaks", "c3_poa_msa", "c3_pairwise_consensus", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
            "c3_reader_open", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_write_group",
            "c3_scan_adapters", "c3_match_index", "c3_match_index_batch"]
 
@@ -92,6 +92,7 @@ def load():
     lib.c3_poa_msa.argtypes = [vp, C.c_int, C.POINTER(cp), ip, vp, C.c_int, ip, vp, C.c_int64, ip]
     lib.c3_zero_repeats.argtypes = [vp, cp, cp, C.c_int, cp, cp, C.c_int, C.c_int, vp, C.c_int, ip]
     lib.c3_scan_splints.argtypes = [vp, vp, vp, vp]
+    lib.c3_pairwise_consensus.argtypes = [vp, cp, cp, C.c_int, cp, C.c_int, cp, cp, C.c_int, cp, vp, C.c_int, ip]
     lib.c3_scan_adapters.argtypes = [vp, vp]
     lib.c3_match_index.argtypes = [cp, C.c_int, C.c_int, cp, vp]
     lib.c3_match_index_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, cp, vp, vp]
@@ -321,6 +322,15 @@ class Handle:
         out = np.zeros(n, dtype=np.int32)
         self._chk(self.lib.c3_match_index_batch(self.h, n, buf.ctypes.data, lens.ctypes.data, len(bs), b"".join(bs), off.ctypes.data, out.ctypes.data))
         return out
+
+    def pairwise_consensus(self, msa_rows, subreads, quals):
+        """pairwise_consensus(msa_rows, subreads, quals) of bin/consensus.py:76"""
+        ra, rb = _b(msa_rows[0]), _b(msa_rows[1])
+        sa, sb, qa, qb = _b(subreads[0]), _b(subreads[1]), _b(quals[0]), _b(quals[1])
+        out = C.create_string_buffer(len(ra) + 1)
+        ol = C.c_int(0)
+        self._chk(self.lib.c3_pairwise_consensus(self.h, ra, rb, len(ra), sa, len(sa), qa, sb, len(sb), qb, out, len(ra) + 1, C.byref(ol)))
+        return out.raw[:ol.value].decode()
 
     def zero_repeats(self, d0, q0, d1, q1, min_len=0):
         b0, b1 = _b(d0), _b(d1)

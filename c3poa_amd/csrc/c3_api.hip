@@ -11,6 +11,7 @@
 // ---- kernel launchers (one translation unit per kernel family) --------------------------
 extern "C" void c3k_launch_conk(const ConkArgs*, int, int, int, hipStream_t);
 extern "C" void c3k_launch_adapter(const AdapterArgs*, int, hipStream_t);
+extern "C" void c3k_launch_pairwise(const uint8_t*, int, const uint8_t*, int, const uint8_t*, int, uint8_t*, uint8_t*, int*, hipStream_t);
 extern "C" void c3k_launch_match_index(const char*, const int*, int, int, const char*, const long long*, int*, hipStream_t);
 extern "C" void c3k_launch_peaks(const PeaksArgs*, int, hipStream_t);
 extern "C" void c3k_launch_poa(const PoaArgs*, int, hipStream_t);
@@ -807,6 +808,43 @@ extern "C" int c3_match_index_batch(c3_handle* h, int n, const char* pieces, con
   HIPCHK(hipMemcpyAsync(out, dout.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   dp.release(); dl.release(); di.release(); doff.release(); dout.release();
+  return C3_E_OK;
+}
+
+// pairwise_consensus(msa_rows, subreads, quals) (bin/consensus.py:76-81; call site determine_consensus.py:36-40): rows are
+// the two MSA rows ('-' = gap, msa_len columns), subA/subB the ungapped subreads with their qualities.  Identical
+// subreads share the later quality (the seqDict collision of consensus.py:77-79).
+extern "C" int c3_pairwise_consensus(c3_handle* h, const char* rowA, const char* rowB, int msa_len,
+                                     const char* subA, int lenA, const char* qualA, const char* subB, int lenB, const char* qualB,
+                                     char* out, int cap, int* out_len) {
+  if (!h || !rowA || !rowB || msa_len < 0 || !subA || !subB || !qualA || !qualB || !out || !out_len) return C3_E_ARG;
+  *out_len = 0;
+  if (msa_len == 0) return C3_E_OK;
+  if (cap < msa_len) return C3_E_LIMIT;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  auto code = [](char ch) -> uint8_t { switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2;
+                                                       case 'T': case 't': case 'U': case 'u': return 3; case '-': return 4; default: return 0; } };
+  std::vector<uint8_t> rows((size_t)2 * msa_len);
+  int na = 0, nb = 0;
+  for (int i = 0; i < msa_len; ++i) { rows[i] = code(rowA[i]); rows[(size_t)msa_len + i] = code(rowB[i]); na += rows[i] != 4; nb += rows[(size_t)msa_len + i] != 4; }
+  if (na != lenA || nb != lenB) return c3_fail(h, C3_E_ARG, "MSA rows do not spell the subreads");
+  const bool same = lenA == lenB && memcmp(subA, subB, (size_t)lenA) == 0;
+  DBuf d_rows, d_qa, d_qb, d_scr, d_out, d_len;
+  HIPCHK(d_rows.ensure((size_t)2 * msa_len)); HIPCHK(d_qa.ensure((size_t)lenA + 16)); HIPCHK(d_qb.ensure((size_t)lenB + 16));
+  HIPCHK(d_scr.ensure((size_t)2 * msa_len + 16)); HIPCHK(d_out.ensure((size_t)msa_len + 16)); HIPCHK(d_len.ensure(16));
+  HIPCHK(hipMemcpyAsync(d_rows.p, rows.data(), rows.size(), hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d_qa.p, same ? qualB : qualA, (size_t)lenA, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(d_qb.p, qualB, (size_t)lenB, hipMemcpyHostToDevice, h->stream));
+  c3k_launch_pairwise(d_rows.as<uint8_t>(), msa_len, d_qa.as<uint8_t>(), lenA, d_qb.as<uint8_t>(), lenB, d_scr.as<uint8_t>(), d_out.as<uint8_t>(), d_len.as<int>(), h->stream);
+  HIPCHK(hipGetLastError());
+  std::vector<uint8_t> codes((size_t)msa_len);
+  int n = 0;
+  HIPCHK(hipMemcpyAsync(&n, d_len.p, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(codes.data(), d_out.p, (size_t)msa_len, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; ++i) out[i] = "ACGT"[codes[(size_t)i] & 3];
+  *out_len = n;
+  d_rows.release(); d_qa.release(); d_qb.release(); d_scr.release(); d_out.release(); d_len.release();
   return C3_E_OK;
 }
 

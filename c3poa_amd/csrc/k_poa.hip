@@ -473,6 +473,44 @@ __device__ void normalize_len(const uint8_t* row, int msa_len, const uint8_t* qu
   if (n != msa_len) { int gap = 0; while (gap < msa_len && row[msa_len - 1 - gap] == 4) { out[n] = out[n - 1]; ++n; ++gap; } }
 }
 
+// bin/consensus.py:4-48 (pairwise_consensus core) on code rows (4 = gap) with the normalised qualities qa/qb of
+// normalize_len: equal columns are copied, mismatches take the base of higher quality, gap runs go to the row whose
+// quality sum over the run is larger.  col2t (optional) receives the draft position of every emitted column.
+__device__ int pairwise_merge(const uint8_t* rowA, const uint8_t* rowB, int ncol, const uint8_t* qa, const uint8_t* qb_,
+                              uint8_t* draft, int* col2t) {
+  int o = 0, i = 0;
+  while (i != ncol) {
+    const int A = rowA[i], B = rowB[i];
+    if (A == B) { if (A != 4) { if (col2t) col2t[i] = o; draft[o++] = (uint8_t)A; } }
+    if (A != B && A != 4 && B != 4) { if (col2t) col2t[i] = o; draft[o++] = (uint8_t)((qa[i] > qb_[i]) ? A : B); }
+    if (A == 4 || B == 4) {
+      int gl = 1; const uint8_t* gs = (A == 4) ? rowA : rowB;
+      for (;;) { if (i + gl >= ncol) { gl = 1; break; } if (gs[i + gl] == 4) ++gl; else break; }
+      long sa = 0, sb = 0;
+      for (int k = i; k < i + gl && k < ncol; ++k) { sa += qa[k]; sb += qb_[k]; }
+      const uint8_t* srcr = (sa > sb) ? rowA : rowB;
+      for (int k = i; k < i + gl && k < ncol; ++k) if (srcr[k] != 4) { if (col2t) col2t[k] = o; draft[o++] = srcr[k]; }
+      i += gl; continue;
+    }
+    ++i;
+  }
+  return o;
+}
+
+// stand-alone stage probe: pairwise_consensus(msa_rows, subreads, quals) (bin/consensus.py:76-81) for one pair.
+// rows: 2 x ncol codes; scratch: 2 x ncol bytes; out: ncol bytes of codes, out_len[0] = their number.
+__global__ void k_pairwise(const uint8_t* rows, int ncol, const uint8_t* qualA, int lenA, const uint8_t* qualB, int lenB,
+                           uint8_t* scratch, uint8_t* out, int* out_len) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  normalize_len(rows, ncol, qualA, lenA, scratch);
+  normalize_len(rows + ncol, ncol, qualB, lenB, scratch + ncol);
+  out_len[0] = pairwise_merge(rows, rows + ncol, ncol, scratch, scratch + ncol, out, nullptr);
+}
+extern "C" void c3k_launch_pairwise(const uint8_t* rows, int ncol, const uint8_t* qa, int la, const uint8_t* qb, int lb,
+                                    uint8_t* scratch, uint8_t* out, int* out_len, hipStream_t s) {
+  hipLaunchKernelGGL(k_pairwise, dim3(1), dim3(64), 0, s, rows, ncol, qa, la, qb, lb, scratch, out, out_len);
+}
+
 // 6 waves/SIMD (80 VGPRs, 26 spilled outside the row loop) with a 4-row LDS ring (6.7 KB per wave, 24 waves per CU):
 // 59.4 ms per 32768 cfg2 reads against 67.8 ms at 4 waves/SIMD with the 8-row ring -- the row loop is a dependent
 // chain (scan -> next row), so resident waves are what hides its latency.
@@ -577,22 +615,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
             for (int k = 0; same && k < l0; ++k) same = c3_code_at(c.pk, b0 + k) == c3_code_at(c.pk, b1 + k);
             normalize_len(rowA, ncol, same ? qual + b1 : qual + b0, l0, qa);
             normalize_len(rowB, ncol, qual + b1, l1, qb_);
-            int o = 0, i = 0;
-            while (i != ncol) {
-              const int A = rowA[i], B = rowB[i];
-              if (A == B) { if (A != 4) { c.col2t[i] = o; draft[o++] = (uint8_t)A; } }
-              if (A != B && A != 4 && B != 4) { c.col2t[i] = o; draft[o++] = (uint8_t)((qa[i] > qb_[i]) ? A : B); }
-              if (A == 4 || B == 4) {
-                int gl = 1; const uint8_t* gs = (A == 4) ? rowA : rowB;
-                for (;;) { if (i + gl >= ncol) { gl = 1; break; } if (gs[i + gl] == 4) ++gl; else break; }
-                long sa = 0, sb = 0;
-                for (int k = i; k < i + gl && k < ncol; ++k) { sa += qa[k]; sb += qb_[k]; }
-                const uint8_t* srcr = (sa > sb) ? rowA : rowB;
-                for (int k = i; k < i + gl && k < ncol; ++k) if (srcr[k] != 4) { c.col2t[k] = o; draft[o++] = srcr[k]; }
-                i += gl; continue;
-              }
-              ++i;
-            }
+            const int o = pairwise_merge(rowA, rowB, ncol, qa, qb_, draft, c.col2t);
             c.rem[0] = o;
           }
           WSYNC();

@@ -62,6 +62,11 @@ class msa_aligner:
         return _MsaResult(cons, msa)
 
 
+def pairwise_consensus(msa_rows, subreads, quals):
+    """bin/consensus.py:76 (imported at bin/determine_consensus.py:5, called :36-40)"""
+    return _handle().pairwise_consensus(msa_rows, subreads, quals)
+
+
 def determine_consensus(args, read, subreads, sub_qual, dangling_subreads, qual_dangling_subreads, racon=None,
                         tmp_dir=None, subread_file=None):
     """(final_cons, repeats) as bin/determine_consensus.py:10-104; appends the subread FASTQ records to

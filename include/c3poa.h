@@ -142,6 +142,11 @@ int c3_call_peaks(c3_handle* h, const int32_t* scores, int n, int min_dist, int3
  * msa receives n rows of *msa_len chars (row-major).  quals may be NULL. */
 int c3_poa_msa(c3_handle* h, int n, const char* const* seqs, const int* lens,
                char* cons, int cons_cap, int* cons_len, char* msa, int64_t msa_cap, int* msa_len);
+/* pairwise_consensus(msa_rows, subreads, quals) (bin/consensus.py:76-81; call site determine_consensus.py:36-40): rowA/rowB
+ * are the two MSA rows ('-' = gap), msa_len columns each.  *out_len <= msa_len bases are written to out. */
+int c3_pairwise_consensus(c3_handle* h, const char* rowA, const char* rowB, int msa_len,
+                          const char* subA, int lenA, const char* qualA, const char* subB, int lenB, const char* qualB,
+                          char* out, int cap, int* out_len);
 /* determine_consensus for repeats >= 1 (determine_consensus.py:29-99): draft + polish.
  * front/tail may be NULL.  returns consensus length in *out_len (0 = nothing emitted). */
 int c3_determine_consensus(c3_handle* h, int n, const char* const* subs, const char* const* quals,

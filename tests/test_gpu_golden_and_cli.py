@@ -134,3 +134,17 @@ def test_large_batch_properties():
     assert [cons1[i] for i in idx] == ocons
     assert t["cells_conk"] > 0 and t["n_windows"] >= 3 * (half - 2)      # timing of the last (half) run
     h.close()
+
+
+def test_pairwise_consensus_against_reference_golden(golden):
+    """c3_pairwise_consensus (GPU, through the C ABI) == bin/consensus.py pairwise_consensus on the reference's golden cases"""
+    from c3poa_amd import shims
+    cases, _ = golden
+    assert len(cases["pairwise"]) > 5
+    for c in cases["pairwise"]:
+        rows, quals = c["rows"], c["quals"]
+        subs = [r.replace("-", "") for r in rows]
+        assert shims.pairwise_consensus(rows, subs, quals) == c["cons"], c
+    # identical subreads share the later quality (bin/consensus.py:77-79)
+    assert shims.pairwise_consensus(["AC-GT", "ACG-T"], ["ACGT", "ACGT"], ["IIII", "5555"]) == \
+        __import__("oracle.oracle_py", fromlist=["x"]).pairwise_consensus(["AC-GT", "ACG-T"], ["ACGT", "ACGT"], ["IIII", "5555"])
