@@ -271,16 +271,29 @@ def test_cli_gpu_splint_finder(tmp_path):
         for r in recs:
             fh.write("@%s\n%s\n+\n%s\n" % (r[0], r[1], r[2]))
         fh.write("@junk\n%s\n+\n%s\n" % (_rand(rng, 2000), "I" * 2000))
+    other = _rand(rng, 240)
+    others = []
+    with open(fq, "a") as fh:                                                       # reads of a second splint, both strands
+        for i in range(6):
+            s, q = _concatemer(rng, other, 900, 3, 80, 80)
+            if i % 2:
+                s, q = revcomp(s), q[::-1]
+            others.append(("o%02d" % i, s, q, "+-"[i % 2]))
+            fh.write("@%s\n%s\n+\n%s\n" % (others[-1][0], s, q))
     fa = str(tmp_path / "splint.fasta")
-    open(fa, "w").write(">Splint1\n%s\n>Other\n%s\n" % (synth.SPLINT1, _rand(rng, 240)))
+    open(fa, "w").write(">Splint1\n%s\n>Other\n%s\n" % (synth.SPLINT1, other))
     C3POa.main(C3POa.parse_args(["-r", fq, "-s", fa, "-o", out]))
     psl = open(out + "/tmp/splint_to_read_alignments.psl").read().splitlines()
-    assert len(psl) == 12 and all(len(l.split("\t")) == 21 for l in psl)
-    assert [(l.split("\t")[9], l.split("\t")[8], l.split("\t")[13]) for l in psl] == [(r[0], r[3], "Splint1") for r in recs]
+    assert len(psl) == 18 and all(len(l.split("\t")) == 21 for l in psl)
+    assert [(l.split("\t")[9], l.split("\t")[8], l.split("\t")[13]) for l in psl] == \
+        [(r[0], r[3], "Splint1") for r in recs] + [(r[0], r[3], "Other") for r in others]
     log = open(out + "/c3poa.log").read().splitlines()
     assert log[2].startswith("No splint reads: 1 ")
     first = sorted(fastx_read(out + "/Splint1/R2C2_Consensus.fasta"))
     assert len(first) == 12
+    second = list(fastx_read(out + "/Other/R2C2_Consensus.fasta"))
+    assert len(second) == 6 and {r[0].split("_")[0] for r in second} == {r[0] for r in others}
+    assert all(int(r[0].split("_")[3]) == 3 for r in second)                        # repeats field of the header
     mtime = os.stat(out + "/tmp/splint_to_read_alignments.psl").st_mtime_ns
     C3POa.main(C3POa.parse_args(["-r", fq, "-s", fa, "-o", out]))                 # resume: PSL reused
     assert os.stat(out + "/tmp/splint_to_read_alignments.psl").st_mtime_ns == mtime
