@@ -85,8 +85,6 @@ def cat_files(path, pattern, output, compress):
 
 
 def main(args):
-    from c3poa_amd.analyze import analyze_reads
-    from c3poa_amd.preprocess import preprocess
     if not args.out_path.endswith("/"):
         args.out_path += "/"
     os.makedirs(args.out_path, exist_ok=True)
@@ -99,15 +97,20 @@ def main(args):
     tmp_dir = args.out_path + "tmp/"
     os.makedirs(tmp_dir, exist_ok=True)
 
-    from c3poa_amd import stream
+    from c3poa_amd import stream, _lib
+    from c3poa_amd.preprocess import ensure_psl
     import time
     t_main = [time.perf_counter()]
-    names, short_reads = stream.scan_names(args.reads, args.lencutoff)      # native reader (C3POa.py:200-207)
+    splint_dict = {}
+    for splint in fastx_read(args.splint_file):
+        splint_dict[splint[0]] = [splint[1], revcomp(splint[1])]
+    # splint / strand per read from the PSL (bin/preprocess.py:12-45).  The PSL is reused when it exists, otherwise
+    # written by the GPU finder (or blat); it is then held in a native name -> (splint, strand) table, and the first
+    # pass over the reads (C3POa.py:200-207) only counts: no Python object per read.
+    assigner = _lib.Assigner(ensure_psl(blat, args, tmp_dir), sorted(splint_dict))
     t_main.append(time.perf_counter())
-    tmp_adapter_dict = {name: [[None, 1, None]] for name in names}
-    total_reads = len(names)
-    del names
-    adapter_dict, adapter_set, no_splint = preprocess(blat, args, tmp_dir, tmp_adapter_dict, total_reads)
+    total_reads, short_reads, no_splint = stream.count_reads(args.reads, args.lencutoff, assigner)
+    adapter_set, _rows = assigner.seen()
     for adapter in adapter_set:
         os.makedirs(args.out_path + adapter, exist_ok=True)
     t_main.append(time.perf_counter())
@@ -122,18 +125,14 @@ def main(args):
     print("Reads after preprocessing:", all_reads - (short_reads + no_splint), file=log_file)
     log_file.close()
 
-    splint_dict = {}
-    for splint in fastx_read(args.splint_file):
-        splint_dict[splint[0]] = [splint[1], revcomp(splint[1])]
-
-    from c3poa_amd import _lib
     n_dev = max(1, min(max(1, args.numThreads), _lib.device_count()))        # -n = GPUs that share the groups
     # streaming pipeline: native reader -> GPU batches -> native writer (c3poa_amd/stream.py); the tail group is
     # processed too (deliberate fix of SURVEY.md App. A.12)
-    stream.run(args, splint_dict, adapter_dict, adapter_set, n_dev)
+    stream.run(args, splint_dict, assigner, adapter_set, n_dev)
+    assigner.close()
     if os.environ.get("C3_STREAM_STATS"):
         t_main.append(time.perf_counter())
-        print("main: scan_names=%.3f preprocess=%.3f consensus=%.3f" % tuple(b - a for a, b in zip(t_main, t_main[1:])), file=sys.stderr)
+        print("main: psl=%.3f count=%.3f consensus=%.3f" % tuple(b - a for a, b in zip(t_main, t_main[1:])), file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -20,7 +20,8 @@ EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_create", "c
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
            "c3_call_peaks", "c3_poa_msa", "c3_pairwise_consensus", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
            "c3_reader_open", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_write_group",
-           "c3_scan_adapters", "c3_match_index", "c3_match_index_batch"]
+           "c3_scan_adapters", "c3_match_index", "c3_match_index_batch",
+           "c3_assign_open", "c3_assign_close", "c3_assign_batch", "c3_assign_seen"]
 
 
 class Config(C.Structure):
@@ -96,6 +97,11 @@ def load():
     lib.c3_scan_adapters.argtypes = [vp, vp]
     lib.c3_match_index.argtypes = [cp, C.c_int, C.c_int, cp, vp]
     lib.c3_match_index_batch.argtypes = [vp, C.c_int, vp, vp, C.c_int, cp, vp, vp]
+    lib.c3_assign_open.argtypes = [cp, C.c_int, C.POINTER(cp), C.POINTER(vp)]
+    lib.c3_assign_close.argtypes = [vp]
+    lib.c3_assign_close.restype = None
+    lib.c3_assign_batch.argtypes = [vp, C.POINTER(HostBatchStruct), vp, vp]
+    lib.c3_assign_seen.argtypes = [vp, vp, vp]
     lib.c3_reader_open.argtypes = [cp, C.c_int, C.POINTER(vp)]
     lib.c3_reader_close.argtypes = [vp]
     lib.c3_reader_close.restype = None
@@ -416,6 +422,44 @@ class Reader:
         if self.r:
             self.lib.c3_reader_close(self.r)
             self.r = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Assigner:
+    """native PSL -> per-read splint / strand assignment (c3_assign_*): bin/preprocess.py:22-45 without Python objects"""
+
+    def __init__(self, psl_path, splint_names):
+        self.lib = load()
+        self.names = list(splint_names)
+        arr = (C.c_char_p * len(self.names))(*[_b(n) for n in self.names])
+        self.a = C.c_void_p()
+        if self.lib.c3_assign_open(_b(str(psl_path)), len(self.names), arr, C.byref(self.a)) != 0:
+            raise OSError("cannot read %s" % psl_path)
+
+    def batch(self, hb):
+        """(splint_id int16[n] with -1 = none, strand bytes, number assigned)"""
+        sid = np.zeros(hb.n, dtype=np.int16)
+        st = np.zeros(hb.n, dtype=np.uint8)
+        k = self.lib.c3_assign_batch(self.a, C.byref(hb.c), sid.ctypes.data, st.ctypes.data)
+        if k < 0:
+            raise RuntimeError("c3_assign_batch failed (%d)" % k)
+        return sid, st.tobytes(), int(k)
+
+    def seen(self):
+        flags = np.zeros(len(self.names), dtype=np.uint8)
+        rows = C.c_int64(0)
+        self.lib.c3_assign_seen(self.a, flags.ctypes.data, C.byref(rows))
+        return set(n for n, f in zip(self.names, flags) if f), int(rows.value)
+
+    def close(self):
+        if self.a:
+            self.lib.c3_assign_close(self.a)
+            self.a = C.c_void_p()
 
     def __del__(self):
         try:

@@ -384,3 +384,80 @@ extern "C" int c3_match_index(const char* seq, int n, int n_idx, const char* idx
   if (best[(size_t)i0] < 2 && best[(size_t)i1] - best[(size_t)i0] > 1) return i0;
   return -1;
 }
+
+// ---- splint assignment from the PSL (bin/preprocess.py:22-45) without per-read Python objects ---------------------
+// Rows with qBaseInsert (col 5) < 50 and matches (col 0) > 50 count; per read the row with the most matches wins, the
+// earliest row on ties (Python's stable sort with reverse=True keeps the first of equal keys); every splint named by a
+// counted row is "seen" (adapter_set).  Rows naming a splint that is not in the splint file are ignored.
+#include <unordered_map>
+
+struct c3_assign {
+  struct Entry { double matches; int16_t splint; char strand; };
+  std::unordered_map<std::string, Entry> best;
+  std::unordered_map<std::string, int> splint_of;
+  std::vector<uint8_t> seen;
+  int64_t rows_kept = 0;
+};
+
+extern "C" int c3_assign_open(const char* psl_path, int n_splints, const char* const* splint_names, c3_assign** out) {
+  if (!psl_path || n_splints <= 0 || !splint_names || !out) return C3_E_ARG;
+  FILE* f = fopen(psl_path, "rb");
+  if (!f) return C3_E_ARG;
+  c3_assign* a = new c3_assign();
+  for (int i = 0; i < n_splints; ++i) a->splint_of.emplace(splint_names[i], i);
+  a->seen.assign((size_t)n_splints, 0);
+  char* lp = nullptr; size_t cap = 0; ssize_t got;
+  while ((got = getline(&lp, &cap, f)) >= 0) {
+    while (got > 0 && (lp[got - 1] == '\n' || lp[got - 1] == '\r')) lp[--got] = 0;
+    if (got == 0) continue;
+    const char* col[21]; size_t len[21]; int nc = 0;
+    const char* p = lp;
+    while (nc < 21) {
+      const char* t = strchr(p, '\t');
+      col[nc] = p; len[nc] = t ? (size_t)(t - p) : strlen(p); ++nc;
+      if (!t) break;
+      p = t + 1;
+    }
+    if (nc < 14) continue;
+    const double matches = strtod(col[0], nullptr), gaps = strtod(col[5], nullptr);
+    if (!(gaps < 50 && matches > 50)) continue;
+    auto sp = a->splint_of.find(std::string(col[13], len[13]));
+    if (sp == a->splint_of.end()) continue;
+    a->seen[(size_t)sp->second] = 1;
+    ++a->rows_kept;
+    std::string name(col[9], len[9]);
+    auto it = a->best.find(name);
+    const char strand = len[8] ? col[8][0] : '?';
+    if (it == a->best.end()) a->best.emplace(std::move(name), c3_assign::Entry{matches, (int16_t)sp->second, strand});
+    else if (matches > it->second.matches) it->second = c3_assign::Entry{matches, (int16_t)sp->second, strand};
+  }
+  free(lp);
+  fclose(f);
+  *out = a;
+  return C3_E_OK;
+}
+
+extern "C" void c3_assign_close(c3_assign* a) { delete a; }
+
+// splint row / strand of every read of the group: -1 / '?' when the read has no counted row.  Returns the number of
+// assigned reads (>= 0) or a negative c3_err.
+extern "C" int c3_assign_batch(const c3_assign* a, const c3_host_batch* b, int16_t* splint_id, char* strand) {
+  if (!a || !b || !splint_id || !strand) return C3_E_ARG;
+  int n_ok = 0;
+  std::string key;
+  for (int i = 0; i < b->n; ++i) {
+    key.assign(b->names + b->name_off[i], (size_t)(b->name_off[i + 1] - b->name_off[i]));
+    auto it = a->best.find(key);
+    if (it == a->best.end()) { splint_id[i] = -1; strand[i] = '?'; }
+    else { splint_id[i] = it->second.splint; strand[i] = it->second.strand == '-' ? '-' : '+'; ++n_ok; }
+  }
+  return n_ok;
+}
+
+// adapter_set of bin/preprocess.py:34,43: flags[s] = 1 when a counted row names splint s
+extern "C" int c3_assign_seen(const c3_assign* a, uint8_t* flags, int64_t* rows_kept) {
+  if (!a || !flags) return C3_E_ARG;
+  memcpy(flags, a->seen.data(), a->seen.size());
+  if (rows_kept) *rows_kept = a->rows_kept;
+  return C3_E_OK;
+}

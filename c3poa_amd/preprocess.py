@@ -93,7 +93,9 @@ def gpu_find_splints(args, align_psl, batch_reads=131072, handle=None):
     return n_rows
 
 
-def preprocess(blat, args, tmp_dir, tmp_adapter_dict, num_reads):
+def ensure_psl(blat, args, tmp_dir):
+    """make sure <tmp_dir>/splint_to_read_alignments.psl exists (bin/preprocess.py:13-20): reuse it, or create it with the
+    GPU finder (default) or the blat binary.  Returns its path."""
     align_psl = tmp_dir + "splint_to_read_alignments.psl"
     finder = getattr(args, "splint_finder", "gpu")
     if (not os.path.exists(align_psl) or os.stat(align_psl).st_size == 0) and finder == "gpu":
@@ -115,4 +117,10 @@ def preprocess(blat, args, tmp_dir, tmp_adapter_dict, num_reads):
         os.remove(fa)
     else:
         print("Reading existing psl file", file=sys.stderr)
-    return parse_psl(align_psl, tmp_adapter_dict)
+    return align_psl
+
+
+def preprocess(blat, args, tmp_dir, tmp_adapter_dict, num_reads):
+    """same signature and return value as bin/preprocess.py:12 (the CLI itself uses the native assignment,
+    c3_assign_*, which returns the same splint / strand per read without a Python object per read)"""
+    return parse_psl(ensure_psl(blat, args, tmp_dir), tmp_adapter_dict)

@@ -26,41 +26,51 @@ HANDLES_PER_GPU = 1              # measured: two handles per GPU make the persis
 GPU_BATCH_BASES = 1 << 30        # bound on host/device memory per batch
 
 
-def scan_names(path, lencutoff):
-    """first pass of C3POa.py:200-207: names of the reads that pass the length cut-off, number of short reads"""
+def count_reads(path, lencutoff, assigner):
+    """first pass of C3POa.py:200-207 + the bookkeeping of bin/preprocess.py:36-44: (reads passing the length cut-off,
+    short reads, reads without a splint).  Names-only parse, native lookups."""
     rd = _lib.Reader(path, n_sets=1, names_only=True)
-    names, short = [], 0
+    total = short = assigned = 0
     while True:
         hb = rd.next(GPU_BATCH_READS, lencutoff, GPU_BATCH_BASES)
         short += hb.n_short
         if hb.n == 0:
             break
-        names.extend(hb.names())
+        total += hb.n
+        assigned += assigner.batch(hb)[2]
     rd.close()
-    return names, short
+    return total, short, total - assigned
 
 
-def assign(hb, adapter_dict, sid_of):
-    """per-read splint row / strand of a host batch from the PSL assignment (C3POa.py:115-122)"""
-    n = hb.n
-    sid = np.full(n, -1, dtype=np.int16)
-    st = bytearray(b"?" * n)
-    for i, name in enumerate(hb.names()):
-        ad = adapter_dict.get(name)
-        if ad:
-            sid[i] = sid_of[ad[0]]
-            st[i] = 45 if ad[1] == "-" else 43
-    return sid, bytes(st)
+class DictAssigner:
+    """adapter for callers that hold the reference's adapter_dict {name: [splint, strand]} (tests, stage seams)"""
+
+    def __init__(self, adapter_dict, splint_names):
+        self.d, self.sid_of = adapter_dict, {n: i for i, n in enumerate(splint_names)}
+
+    def batch(self, hb):
+        sid = np.full(hb.n, -1, dtype=np.int16)
+        st = bytearray(b"?" * hb.n)
+        k = 0
+        for i, name in enumerate(hb.names()):
+            ad = self.d.get(name)
+            if ad:
+                sid[i] = self.sid_of[ad[0]]; st[i] = 45 if ad[1] == "-" else 43; k += 1
+        return sid, bytes(st), k
 
 
-def run(args, splint_dict, adapter_dict, adapter_set=None, n_dev=1, stats=None):
-    """the second pass of C3POa.py:236-271.  returns the number of reads sent to the GPUs."""
+def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None):
+    """the second pass of C3POa.py:236-271.  assigner: _lib.Assigner (native PSL table) or an adapter_dict.
+    returns the number of reads sent to the GPUs."""
     splint_names = sorted(splint_dict)
-    sid_of = {n: i for i, n in enumerate(splint_names)}
+    if isinstance(assigner, dict):
+        assigner = DictAssigner(assigner, splint_names)
     compress = bool(getattr(args, "compress_output", False))
     cons_paths = [args.out_path + n + "/R2C2_Consensus.fasta" for n in splint_names]
     sub_paths = [args.out_path + n + "/R2C2_Subreads.fastq" for n in splint_names]
-    used = set(v[0] for v in adapter_dict.values()) | set(adapter_set or ())   # cat_files runs per adapter_set entry (C3POa.py:259)
+    used = set(adapter_set or ())                                             # cat_files runs per adapter_set entry (C3POa.py:259)
+    if isinstance(assigner, DictAssigner):
+        used |= set(v[0] for v in assigner.d.values())
     for n, cp, sp in zip(splint_names, cons_paths, sub_paths):
         if n in used:
             os.makedirs(args.out_path + n, exist_ok=True)
@@ -86,7 +96,7 @@ def run(args, splint_dict, adapter_dict, adapter_set=None, n_dev=1, stats=None):
                 t1 = time.perf_counter()
                 if hb.n == 0:
                     break
-                sid, st = assign(hb, adapter_dict, sid_of)
+                sid, st, _k = assigner.batch(hb)
                 t["parse"] += t1 - t0; t["assign"] += time.perf_counter() - t1
                 t["reads"] += hb.n; t["batches"] += 1
                 parsed.put((hb, sid, st))

@@ -208,6 +208,16 @@ int c3_write_group(const c3_host_batch* b, const c3_read_result* res, const char
                    const int16_t* splint_id, int n_splints, const char* const* cons_paths,
                    const char* const* sub_paths, int zero);
 
+/* splint assignment from the PSL (bin/preprocess.py:22-45) without per-read host objects: rows with qBaseInsert < 50 and
+ * matches > 50 count, per read the row with the most matches wins (the earliest on ties).  Host code. */
+typedef struct c3_assign c3_assign;
+int c3_assign_open(const char* psl_path, int n_splints, const char* const* splint_names, c3_assign** out);
+void c3_assign_close(c3_assign* a);
+/* splint row / strand ('+', '-'; -1 / '?' = no counted row) of every read of the group; returns how many are assigned */
+int c3_assign_batch(const c3_assign* a, const c3_host_batch* b, int16_t* splint_id, char* strand);
+/* adapter_set (bin/preprocess.py:34,43): flags[s] = 1 when a counted row names splint s; *rows_kept = counted rows */
+int c3_assign_seen(const c3_assign* a, uint8_t* flags, int64_t* rows_kept);
+
 /* match_index for a whole batch on the GPU (one lane per piece): pieces = n slots of 64 bytes, lens[n] <= 64, at most
  * 16 indexes of at most 32 bases; out[i] = winning index number or -1.  Same function as c3_match_index below. */
 int c3_match_index_batch(c3_handle* h, int n, const char* pieces, const int32_t* lens, int n_idx,

@@ -202,3 +202,37 @@ def test_writer_threads_give_identical_files(tmp_path, monkeypatch):
     analyze.write_group(args, recs, res, cons, ad, 1)
     assert outs["5"][3] == open(args.out_path + "S0/tmp1/subreads.fastq").read()
     assert outs["5"][1] == open(args.out_path + "S1/tmp1/R2C2_Consensus.fasta").read()
+
+
+def test_native_assignment_matches_python_psl_parse(tmp_path):
+    """c3_assign_* == the Python mirror of bin/preprocess.py:22-45 (filters, best-by-matches, first on ties, adapter_set)"""
+    from c3poa_amd import preprocess
+    rng = np.random.default_rng(6)
+    names = ["rd%04d" % i for i in range(400)]
+    recs = [(n, "ACGTACGTAC", "IIIIIIIIII") for n in names]
+    fq = str(tmp_path / "r.fastq")
+    _write_fastq(fq, recs)
+    splints = ["SplB", "SplA", "SplC"]                               # CLI order = sorted(splint_dict)
+    rows = []
+    for i, n in enumerate(names):
+        for _k in range(int(rng.integers(0, 4))):
+            m = int(rng.choice([30, 50, 51, 120, 120, 200, 283]))
+            g = int(rng.choice([0, 10, 49, 50, 80]))
+            sp = str(rng.choice(["SplA", "SplB", "SplC", "NotInFile"]))
+            st = "+-"[int(rng.integers(0, 2))]
+            rows.append("\t".join([str(m), "0", "0", "0", "0", str(g), "0", "0", st, n, "5000", "0", "284", sp, "284", "0", "284", "1", "284,", "0,", "0,"]))
+    psl = str(tmp_path / "a.psl")
+    open(psl, "w").write("\n".join(rows) + "\n\n")
+    # python mirror (rows naming a splint outside the file are dropped first: the native table ignores them)
+    psl_py = str(tmp_path / "b.psl")
+    open(psl_py, "w").write("\n".join(r for r in rows if "NotInFile" not in r) + "\n")
+    ad, aset, no_splint = preprocess.parse_psl(psl_py, {n: [[None, 1, None]] for n in names})
+    asg = _lib.Assigner(psl, sorted(splints))
+    hb = _lib.Reader(fq).next(1000)
+    sid, st, k = asg.batch(hb)
+    order = sorted(splints)
+    got = {names[i]: [order[sid[i]], chr(st[i])] for i in range(hb.n) if sid[i] >= 0}
+    assert got == ad and k == len(ad) == len(names) - no_splint and 0 < k < len(names)
+    seen, kept = asg.seen()
+    assert seen == aset and kept == sum(1 for r in rows if "NotInFile" not in r and float(r.split("\t")[0]) > 50 and float(r.split("\t")[5]) < 50)
+    asg.close()
