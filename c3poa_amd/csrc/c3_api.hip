@@ -402,15 +402,8 @@ static int run_poa(c3_handle* h) {
   PoaArgs a; memset(&a, 0, sizeof(a));
   a.b = dev_batch(h); a.info = h->d_info.as<C3Info>(); a.p = dev_params(h->cfg);
   a.counter = h->d_counter.as<int>(); a.work = h->d_work.as<int>(); a.n_work = nw;
-  int* ip = h->s_poa_i.as<int>(); const size_t SN = N * slots;
-  int** fields[] = {&a.n_in, &a.n_out, &a.grp, &a.order, &a.order2, &a.index, &a.gfirst, &a.glast, &a.rem, &a.mpl, &a.mpr,
-                    &a.rbeg, &a.rend, &a.roff, &a.anchor, &a.col, &a.col2t, &a.nxt};
-  for (auto f : fields) { *f = ip; ip += SN; }
-  a.opn = ip; ip += 2 * SN; a.opq = ip; ip += 2 * SN; a.path = ip; ip += (size_t)Pcap * slots;   // Pcap == Ncap
-  int* nk = h->s_poa_nk.as<int>(); a.in_from = nk; a.out_to = nk + SN * K; a.out_w = nk + 2 * SN * K;
-  char* cb = h->s_poa_cells.as<char>(); const size_t CS = (size_t)cells * slots;
-  a.H = (int32_t*)cb; a.E1 = (int32_t*)(cb + CS * 4); a.E2 = (int32_t*)(cb + CS * 8); a.D = (uint32_t*)(cb + CS * 12);
-  a.base = h->s_poa_b.as<uint8_t>(); a.rows2 = a.base + SN; a.score = h->s_poa_sc.as<long long>();
+  a.ibase = h->s_poa_i.as<int>(); a.ebase = h->s_poa_nk.as<int>(); a.cellsb = h->s_poa_cells.as<char>();
+  a.bbase = h->s_poa_b.as<uint8_t>(); a.score = h->s_poa_sc.as<long long>();
   a.Ncap = Ncap; a.K = K; a.Pcap = Pcap; a.cells_cap = (int)cells; a.desc = h->s_poa_desc.as<uint4>(); a.jump = h->s_poa_jump.as<int>();
   a.draft = h->d_draft.as<uint8_t>(); a.tpos = h->d_tpos.as<int32_t>();
   a.msa_dbg = nullptr; a.msa_off = nullptr; a.msa_len = nullptr;

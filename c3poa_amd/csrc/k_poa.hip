@@ -19,31 +19,48 @@
 #define SNK 1
 
 
+// Per-slot scratch of k_poa.  Only a few base pointers are kept live; every array is base + constant multiple of Ncap
+// (or Ncap*K, cells_cap), which keeps the uniform state in SGPRs instead of spilling it into VGPR lanes.
 struct Ctx {
-  uint8_t* base; int *n_in, *n_out, *in_from, *out_to, *out_w, *grp, *order, *order2, *index;
-  int *gfirst, *glast, *rem, *mpl, *mpr, *rbeg, *rend, *roff, *opn, *opq, *anchor, *path, *col, *col2t, *nxt;
-  long long* score;
-  int32_t *H, *E1, *E2; uint32_t* D; uint8_t* rows2; uint4 *descA, *descB; int* jump;
+  int* I; int* E; char* C; uint8_t* B8; long long* score_; uint4* desc_; int* jump_;
   int K, n, Ncap, cells_cap;
   const uint32_t* pk;        // packed read
+#define CTX_I(name, k) __device__ __forceinline__ int* name() const { return I + (size_t)(k) * Ncap; }
+  CTX_I(n_in, 0) CTX_I(n_out, 1) CTX_I(grp, 2) CTX_I(order, 3) CTX_I(order2, 4) CTX_I(index, 5) CTX_I(gfirst, 6) CTX_I(glast, 7)
+  CTX_I(rem, 8) CTX_I(mpl, 9) CTX_I(mpr, 10) CTX_I(rbeg, 11) CTX_I(rend, 12) CTX_I(roff, 13) CTX_I(anchor, 14) CTX_I(col, 15)
+  CTX_I(col2t, 16) CTX_I(nxt, 17) CTX_I(opn, 18) CTX_I(opq, 20) CTX_I(path, 22)
+#undef CTX_I
+  __device__ __forceinline__ int* in_from() const { return E; }
+  __device__ __forceinline__ int* out_to() const { return E + (size_t)Ncap * K; }
+  __device__ __forceinline__ int* out_w() const { return E + 2 * (size_t)Ncap * K; }
+  __device__ __forceinline__ int32_t* H() const { return (int32_t*)C; }
+  __device__ __forceinline__ int32_t* E1() const { return (int32_t*)(C + 4 * (size_t)cells_cap); }
+  __device__ __forceinline__ int32_t* E2() const { return (int32_t*)(C + 8 * (size_t)cells_cap); }
+  __device__ __forceinline__ uint32_t* D() const { return (uint32_t*)(C + 12 * (size_t)cells_cap); }
+  __device__ __forceinline__ uint8_t* base() const { return B8; }
+  __device__ __forceinline__ uint8_t* rows2() const { return B8 + (size_t)Ncap; }
+  __device__ __forceinline__ long long* score() const { return score_; }
+  __device__ __forceinline__ uint4* descA() const { return desc_; }
+  __device__ __forceinline__ uint4* descB() const { return desc_ + (size_t)Ncap; }
+  __device__ __forceinline__ int* jump() const { return jump_; }
 };
 
 __device__ __forceinline__ void g_add_edge(Ctx& c, int u, int v, int w) {
   const int K = c.K;
-  for (int k = 0; k < c.n_out[u]; ++k)
-    if (c.out_to[u * K + k] == v) { c.out_w[u * K + k] += w; return; }
-  int no = c.n_out[u], ni = c.n_in[v];
-  c.out_to[u * K + no] = v; c.out_w[u * K + no] = w; c.n_out[u] = no + 1;
-  c.in_from[v * K + ni] = u; c.n_in[v] = ni + 1;
+  for (int k = 0; k < c.n_out()[u]; ++k)
+    if (c.out_to()[u * K + k] == v) { c.out_w()[u * K + k] += w; return; }
+  int no = c.n_out()[u], ni = c.n_in()[v];
+  c.out_to()[u * K + no] = v; c.out_w()[u * K + no] = w; c.n_out()[u] = no + 1;
+  c.in_from()[v * K + ni] = u; c.n_in()[v] = ni + 1;
 }
 
 // block extents from order/grp (parallel)
 __device__ void g_blocks(Ctx& c, int lane) {
-  for (int i = lane; i < c.n; i += 64) { c.gfirst[i] = 1 << 30; c.glast[i] = -1; }
+  for (int i = lane; i < c.n; i += 64) { c.gfirst()[i] = 1 << 30; c.glast()[i] = -1; }
   WSYNC();
   for (int i = lane; i < c.n; i += 64) {
-    int r = c.grp[c.order[i]];
-    atomicMin(&c.gfirst[r], i); atomicMax(&c.glast[r], i);
+    int r = c.grp()[c.order()[i]];
+    atomicMin(&c.gfirst()[r], i); atomicMax(&c.glast()[r], i);
   }
   WSYNC();
 }
@@ -54,12 +71,12 @@ __device__ void g_reorder(Ctx& c, int n_old, int lane) {
   // old node at old index i moves to i + #(anchor < i); new node k goes to anchor[k] + 1 + k
   for (int i = lane; i < n_old; i += 64) {
     int lo = 0, hi = n_new;                 // first k with anchor[k] >= i
-    while (lo < hi) { int m = (lo + hi) >> 1; if (c.anchor[m] < i) lo = m + 1; else hi = m; }
-    c.order2[i + lo] = c.order[i];
+    while (lo < hi) { int m = (lo + hi) >> 1; if (c.anchor()[m] < i) lo = m + 1; else hi = m; }
+    c.order2()[i + lo] = c.order()[i];
   }
-  for (int k = lane; k < n_new; k += 64) c.order2[c.anchor[k] + 1 + k] = n_old + k;
+  for (int k = lane; k < n_new; k += 64) c.order2()[c.anchor()[k] + 1 + k] = n_old + k;
   WSYNC();
-  for (int i = lane; i < c.n; i += 64) { int v = c.order2[i]; c.order[i] = v; c.index[v] = i; }
+  for (int i = lane; i < c.n; i += 64) { int v = c.order2()[i]; c.order()[i] = v; c.index()[v] = i; }
   WSYNC();
   g_blocks(c, lane);
 }
@@ -99,15 +116,15 @@ __shared__ PoaLds L;     // file scope: accesses stay in the LDS address space (
 __device__ void poa_build_desc(Ctx& c, int lane) {
   const int K = c.K, n = c.n;
   for (int idx = lane; idx < n; idx += 64) {
-    const int v = c.order[idx];
-    const int nin = c.n_in[v];
+    const int v = c.order()[idx];
+    const int nin = c.n_in()[v];
     unsigned p[4] = {0, 0, 0, 0};
-    for (int k = 0; k < nin && k < 4; ++k) p[k] = (unsigned)c.index[c.in_from[v * K + k]];
+    for (int k = 0; k < nin && k < 4; ++k) p[k] = (unsigned)c.index()[c.in_from()[v * K + k]];
     unsigned far = 0;
-    for (int k = 0; k < c.n_out[v]; ++k) { const int t = c.out_to[v * K + k]; if (t == SNK || c.index[t] - idx > PR - 1) far = 1; }
-    uint4 A; A.x = (unsigned)v; A.y = (unsigned)c.rem[v]; A.z = (unsigned)c.base[v] | ((unsigned)min(nin, 255) << 8) | (far << 16) | ((unsigned)(nin > 4) << 17); A.w = 0;
+    for (int k = 0; k < c.n_out()[v]; ++k) { const int t = c.out_to()[v * K + k]; if (t == SNK || c.index()[t] - idx > PR - 1) far = 1; }
+    uint4 A; A.x = (unsigned)v; A.y = (unsigned)c.rem()[v]; A.z = (unsigned)c.base()[v] | ((unsigned)min(nin, 255) << 8) | (far << 16) | ((unsigned)(nin > 4) << 17); A.w = 0;
     uint4 B; B.x = p[0]; B.y = p[1]; B.z = p[2]; B.w = p[3];
-    c.descA[idx] = A; c.descB[idx] = B;
+    c.descA()[idx] = A; c.descB()[idx] = B;
   }
   WSYNC();
 }
@@ -122,10 +139,10 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   // remaining length along the heaviest out-edge (first maximum in out-list order): list ranking by
   // pointer jumping, log2(n) parallel rounds instead of a serial reverse sweep
   {
-    int *dA = c.rem, *nA = c.nxt, *dB = c.col, *nB = c.col2t;
+    int *dA = c.rem(), *nA = c.nxt(), *dB = c.col(), *nB = c.col2t();
     for (int v = lane; v < n; v += 64) {
       int bw = INT32_MIN, bt = SNK;
-      for (int k = 0; k < c.n_out[v]; ++k) { int ww = c.out_w[v * K + k]; if (ww > bw) { bw = ww; bt = c.out_to[v * K + k]; } }
+      for (int k = 0; k < c.n_out()[v]; ++k) { int ww = c.out_w()[v * K + k]; if (ww > bw) { bw = ww; bt = c.out_to()[v * K + k]; } }
       if (v == SNK) bt = SNK;
       nA[v] = bt; dA[v] = (v == SNK) ? 0 : 1;
     }
@@ -143,7 +160,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     }
     for (int v = lane; v < n; v += 64) dB[v] = dA[v] - 1;
     WSYNC();
-    if (dB != c.rem) { for (int v = lane; v < n; v += 64) c.rem[v] = dB[v]; WSYNC(); }
+    if (dB != c.rem()) { for (int v = lane; v < n; v += 64) c.rem()[v] = dB[v]; WSYNC(); }
   }
   poa_build_desc(c, lane);
   // the subread, 2-bit packed and re-aligned to its first base, goes to LDS: the row loop must not
@@ -161,7 +178,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   int ncell = 0;
   int pv_idx = -9, pv_beg = 0, pv_end = -1, pv_left = 0, pv_right = 0, pv_inl = 0;   // previous row, kept in scalars
   for (int ib = 0; ib < n; ib += 64) {
-  uint4 dA = c.descA[min(ib + lane, n - 1)], dB = c.descB[min(ib + lane, n - 1)];
+  uint4 dA = c.descA()[min(ib + lane, n - 1)], dB = c.descB()[min(ib + lane, n - 1)];
   asm volatile("" : "+v"(dA.x), "+v"(dA.y), "+v"(dA.z), "+v"(dB.x), "+v"(dB.y), "+v"(dB.z), "+v"(dB.w));   // wait here, not in the row loop
   const int cnt = min(64, n - ib);
   for (int li = 0; li < cnt; ++li) {
@@ -174,7 +191,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     const bool far = (fl >> 16) & 1, ovf = (fl >> 17) & 1;
     const int p0 = __builtin_amdgcn_readlane(dB.x, li), p1 = __builtin_amdgcn_readlane(dB.y, li);
     const int p2 = __builtin_amdgcn_readlane(dB.z, li), p3 = __builtin_amdgcn_readlane(dB.w, li);
-#define PRED_IDX(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index[c.in_from[v * K + (k)]])
+#define PRED_IDX(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[v * K + (k)]])
     // ---- FAST ROW: one predecessor = the previous row, still in the LDS ring, band fits one 64-lane chunk.
     // Same arithmetic as the general path below, minus the predecessor loop, the tag bookkeeping
     // (ordinal 0 everywhere) and every LDS metadata read (the previous row's band is in scalars).
@@ -217,9 +234,9 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         const int h9 = k3 & ~511;
         d |= ((unsigned)(2 - (k3 & 3)) << 28) | (f1x << 30) | (f2x << 31);
         if (act) {
-          c.D[ro + lane] = d;
+          c.D()[ro + lane] = d;
           L.H[slot][lane] = h9; L.E1[slot][lane] = E1v; L.E2[slot][lane] = E2v;
-          if (far) { c.H[ro + lane] = h9; c.E1[ro + lane] = E1v; c.E2[ro + lane] = E2v; }
+          if (far) { c.H()[ro + lane] = h9; c.E1()[ro + lane] = E1v; c.E2()[ro + lane] = E2v; }
         }
         const int hb = act ? h9 : INT32_MIN;
         const int rb = wave_max(hb);
@@ -228,8 +245,8 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         const int left = beg + __builtin_ctzll(mxm), right = beg + 63 - __builtin_clzll(mxm);
         if (lane == 0) {
           L.beg[slot] = beg; L.end[slot] = end; L.rl[slot] = left; L.rr[slot] = right; L.inl[slot] = 1;
-          c.rbeg[idx] = beg; c.rend[idx] = end; c.roff[idx] = ro;
-          if (far) { c.mpl[idx] = left; c.mpr[idx] = right; }
+          c.rbeg()[idx] = beg; c.rend()[idx] = end; c.roff()[idx] = ro;
+          if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
         }
         pv_idx = idx; pv_beg = beg; pv_end = end; pv_left = left; pv_right = right; pv_inl = 1;
         continue;
@@ -245,7 +262,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         const int pi = PRED_IDX(k);
         int b, e, l, r;
         if (idx - pi < PR) { const int sl = pi & (PR - 1); b = L.beg[sl]; e = L.end[sl]; l = L.rl[sl]; r = L.rr[sl]; }
-        else { b = c.rbeg[pi]; e = c.rend[pi]; l = c.mpl[pi]; r = c.mpr[pi]; }
+        else { b = c.rbeg()[pi]; e = c.rend()[pi]; l = c.mpl()[pi]; r = c.mpr()[pi]; }
         minb = min(minb, b); maxe = max(maxe, e + 1);
         if (e >= b) { mplv = min(mplv, l + 1); mprv = max(mprv, r + 1); }
       }
@@ -280,10 +297,10 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
             if (j >= b && j <= e) { hp = L.H[sl][j - b]; e1p = L.E1[sl][j - b]; e2p = L.E2[sl][j - b]; }
           } else {
             int b, e;
-            if (idx - pi < PR) { b = L.beg[sl]; e = L.end[sl]; } else { b = c.rbeg[pi]; e = c.rend[pi]; }
-            const int po = c.roff[pi];
-            if (j > 0 && j - 1 >= b && j - 1 <= e) hd = c.H[po + (j - 1 - b)];
-            if (j >= b && j <= e) { hp = c.H[po + (j - b)]; e1p = c.E1[po + (j - b)]; e2p = c.E2[po + (j - b)]; }
+            if (idx - pi < PR) { b = L.beg[sl]; e = L.end[sl]; } else { b = c.rbeg()[pi]; e = c.rend()[pi]; }
+            const int po = c.roff()[pi];
+            if (j > 0 && j - 1 >= b && j - 1 <= e) hd = c.H()[po + (j - 1 - b)];
+            if (j >= b && j <= e) { hp = c.H()[po + (j - b)]; e1p = c.E1()[po + (j - b)]; e2p = c.E2()[po + (j - b)]; }
           }
           kM = max(kM, hd + (511 - k));
           kE1 = max(kE1, max(hp - oe1_9 + (511 - 2 * k), e1p - e1_9 + (510 - 2 * k)));
@@ -316,9 +333,9 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       d |= ((unsigned)(2 - (k3 & 3)) << 28) | (f1x << 30) | (f2x << 31);
       if (act) {
         const int ci = c0 + lane;
-        c.D[ro + ci] = d;
+        c.D()[ro + ci] = d;
         if (inl) { L.H[slot][ci] = h9; L.E1[slot][ci] = E1v; L.E2[slot][ci] = E2v; }
-        if (toglobal) { c.H[ro + ci] = h9; c.E1[ro + ci] = E1v; c.E2[ro + ci] = E2v; }
+        if (toglobal) { c.H()[ro + ci] = h9; c.E1()[ro + ci] = E1v; c.E2()[ro + ci] = E2v; }
         if (h9 > best) { best = h9; bl = br = j; } else if (h9 == best) br = j;
       }
     }
@@ -331,8 +348,8 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     }
     if (lane == 0) {
       L.beg[slot] = beg; L.end[slot] = end; L.rl[slot] = left; L.rr[slot] = right; L.inl[slot] = inl;
-      c.rbeg[idx] = beg; c.rend[idx] = end; c.roff[idx] = ro;
-      if (far) { c.mpl[idx] = left; c.mpr[idx] = right; }
+      c.rbeg()[idx] = beg; c.rend()[idx] = end; c.roff()[idx] = ro;
+      if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
     }
     pv_idx = idx; pv_beg = beg; pv_end = end; pv_left = left; pv_right = right; pv_inl = inl;
   }
@@ -342,9 +359,9 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   PH_MARK(1)
   // ---- end cell: best predecessor of the sink at column Q (first maximum in in-edge order)
   int bi = -1, bs = INT32_MIN;
-  for (int k = 0; k < c.n_in[SNK]; ++k) {
-    const int pi = c.index[c.in_from[SNK * K + k]];
-    const int hh = (Q < c.rbeg[pi] || Q > c.rend[pi]) ? NEGS : c.H[c.roff[pi] + (Q - c.rbeg[pi])];
+  for (int k = 0; k < c.n_in()[SNK]; ++k) {
+    const int pi = c.index()[c.in_from()[SNK * K + k]];
+    const int hh = (Q < c.rbeg()[pi] || Q > c.rend()[pi]) ? NEGS : c.H()[c.roff()[pi] + (Q - c.rbeg()[pi])];
     if (hh > bs) { bs = hh; bi = pi; }
   }
   if (bi < 0 || bs <= NEGS / 2) return -1;
@@ -356,17 +373,17 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   // descriptors first, then the direction word); lane 0 is always the current cell.  The breaking cell is then
   // resolved from lane m's registers by the scalar state machine below, which only goes back to memory when the
   // cell changes -- one round per break instead of a chain of dependent scalar loads per state transition.
-  int* vq = c.mpl;
+  int* vq = c.mpl();
   int rc = 0;
   {
     int i = bi, j = Q, st = 0;   // st: 0 H, 1 Ht, 2 E1, 3 E2, 4 F1, 5 F2
     while (!(i == 0 && j == 0)) {
       const int ik = i - lane, jk = j - lane;
       const int ic = max(ik, 0);
-      const int b = c.rbeg[ic], e = c.rend[ic], ro = c.roff[ic];
-      const uint4 A = c.descA[ic], B = c.descB[ic];
+      const int b = c.rbeg()[ic], e = c.rend()[ic], ro = c.roff()[ic];
+      const uint4 A = c.descA()[ic], B = c.descB()[ic];
       const bool inb = ik >= 0 && jk >= b && jk <= e;
-      const unsigned d = inb ? c.D[ro + (jk - b)] : 0u;
+      const unsigned d = inb ? c.D()[ro + (jk - b)] : 0u;
       int m = 0;
       if (st == 0 && i > 0 && j > 0) {
         const int mp = d & 0xff;
@@ -384,7 +401,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       const unsigned d0 = (unsigned)wave_bcast((int)d, m);
       const int v = wave_bcast((int)A.x, m);
       const int p0 = wave_bcast((int)B.x, m), p1 = wave_bcast((int)B.y, m), p2 = wave_bcast((int)B.z, m), p3 = wave_bcast((int)B.w, m);
-#define TB_PRED(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index[c.in_from[v * K + (k)]])
+#define TB_PRED(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[v * K + (k)]])
       for (bool same = true; same;) {
         if (st == 0) { const int hs = (d0 >> 28) & 3; st = hs == 0 ? 1 : (hs == 1 ? 4 : 5); }
         else if (st == 1) {
@@ -410,7 +427,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
 // ids (prefix sum), anchors (prefix max) and the Q+1 edges are all independent.
 __device__ int poa_fuse(Ctx& c, bool first, int qb, int Q, int* path, int lane PHA) {
   const int n_old = c.n, K = c.K;
-  int* vq = c.mpl;                                  // filled by poa_align's traceback
+  int* vq = c.mpl();                                  // filled by poa_align's traceback
   if (first) { for (int q = lane; q < Q; q += 64) vq[q] = -1; WSYNC(); }
   int carry_anchor = 0 /* order index of SRC */, carry_new = 0;
   for (int q0 = 0; q0 < Q; q0 += 64) {
@@ -420,10 +437,10 @@ __device__ int poa_fuse(Ctx& c, bool first, int qb, int Q, int* path, int lane P
     const int cb = act ? c3_code_at(c.pk, qb + q) : 0;
     int tgt = -1, gnew = -1, anc = -1;
     if (v >= 0) {
-      const int rr = c.grp[v];
-      anc = c.glast[rr];
-      if (c.base[v] == cb) tgt = v;
-      else for (int i = c.gfirst[rr]; i <= anc; ++i) { int x = c.order[i]; if (c.base[x] == cb) { tgt = x; break; } }
+      const int rr = c.grp()[v];
+      anc = c.glast()[rr];
+      if (c.base()[v] == cb) tgt = v;
+      else for (int i = c.gfirst()[rr]; i <= anc; ++i) { int x = c.order()[i]; if (c.base()[x] == cb) { tgt = x; break; } }
       if (tgt < 0) gnew = rr;
     }
     const int isnew = act && tgt < 0;
@@ -434,7 +451,7 @@ __device__ int poa_fuse(Ctx& c, bool first, int qb, int Q, int* path, int lane P
     carry_new += wave_bcast(ps, 63);
     if (isnew) {
       const int id = n_old + k;
-      if (id < c.Ncap) { c.base[id] = (uint8_t)cb; c.n_in[id] = 0; c.n_out[id] = 0; c.grp[id] = gnew >= 0 ? gnew : id; c.anchor[k] = as; }
+      if (id < c.Ncap) { c.base()[id] = (uint8_t)cb; c.n_in()[id] = 0; c.n_out()[id] = 0; c.grp()[id] = gnew >= 0 ? gnew : id; c.anchor()[k] = as; }
       tgt = id;
     }
     if (act) path[q] = tgt;
@@ -444,14 +461,14 @@ __device__ int poa_fuse(Ctx& c, bool first, int qb, int Q, int* path, int lane P
   WSYNC();
   for (int q = lane; q <= Q; q += 64) {
     const int u = q == 0 ? SRC : path[q - 1], v = q == Q ? SNK : path[q];
-    const int no = c.n_out[u];
+    const int no = c.n_out()[u];
     int hit = -1;
-    for (int k = 0; k < no; ++k) if (c.out_to[u * K + k] == v) { hit = k; break; }
-    if (hit >= 0) c.out_w[u * K + hit] += 1;
+    for (int k = 0; k < no; ++k) if (c.out_to()[u * K + k] == v) { hit = k; break; }
+    if (hit >= 0) c.out_w()[u * K + hit] += 1;
     else {
-      const int ni = c.n_in[v];
-      c.out_to[u * K + no] = v; c.out_w[u * K + no] = 1; c.n_out[u] = no + 1;
-      c.in_from[v * K + ni] = u; c.n_in[v] = ni + 1;
+      const int ni = c.n_in()[v];
+      c.out_to()[u * K + no] = v; c.out_w()[u * K + no] = 1; c.n_out()[u] = no + 1;
+      c.in_from()[v * K + ni] = u; c.n_in()[v] = ni + 1;
     }
   }
   WSYNC();
@@ -518,18 +535,10 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
   const int lane = wave_lane();
   const int slot = blockIdx.x;
   Ctx c;
-  const size_t N = (size_t)a.Ncap, NK = (size_t)a.Ncap * a.K;
-  c.base = a.base + slot * N; c.n_in = a.n_in + slot * N; c.n_out = a.n_out + slot * N;
-  c.in_from = a.in_from + slot * NK; c.out_to = a.out_to + slot * NK; c.out_w = a.out_w + slot * NK;
-  c.grp = a.grp + slot * N; c.order = a.order + slot * N; c.order2 = a.order2 + slot * N; c.index = a.index + slot * N;
-  c.gfirst = a.gfirst + slot * N; c.glast = a.glast + slot * N; c.rem = a.rem + slot * N;
-  c.mpl = a.mpl + slot * N; c.mpr = a.mpr + slot * N; c.rbeg = a.rbeg + slot * N; c.rend = a.rend + slot * N; c.roff = a.roff + slot * N;
-  c.opn = a.opn + slot * 2 * N; c.opq = a.opq + slot * 2 * N; c.anchor = a.anchor + slot * N;
-  c.path = a.path + (size_t)slot * a.Pcap; c.col = a.col + slot * N; c.col2t = a.col2t + slot * N; c.nxt = a.nxt + slot * N;
-  c.score = a.score + slot * N;
-  c.H = a.H + (size_t)slot * a.cells_cap; c.E1 = a.E1 + (size_t)slot * a.cells_cap; c.E2 = a.E2 + (size_t)slot * a.cells_cap;
-  c.D = a.D + (size_t)slot * a.cells_cap; c.rows2 = a.rows2 + slot * 4 * N;
-  c.descA = a.desc + (size_t)slot * 2 * N; c.descB = c.descA + N; c.jump = a.jump + (size_t)slot * C3_JUMP_LEVELS * N;
+  const size_t N = (size_t)a.Ncap;
+  c.I = a.ibase + (size_t)slot * 23 * N; c.E = a.ebase + (size_t)slot * 3 * N * a.K;
+  c.C = a.cellsb + (size_t)slot * 16 * (size_t)a.cells_cap; c.B8 = a.bbase + (size_t)slot * 5 * N;
+  c.score_ = a.score + (size_t)slot * N; c.desc_ = a.desc + (size_t)slot * 2 * N; c.jump_ = a.jump + (size_t)slot * C3_JUMP_LEVELS * N;
   c.K = a.K; c.Ncap = a.Ncap; c.cells_cap = a.cells_cap;
   PH_DECL
 
@@ -554,8 +563,8 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
     } else {
       // ---- build the graph, one subread at a time
       if (lane == 0) {
-        c.base[SRC] = 0; c.base[SNK] = 0; c.n_in[SRC] = c.n_out[SRC] = c.n_in[SNK] = c.n_out[SNK] = 0;
-        c.grp[SRC] = SRC; c.grp[SNK] = SNK; c.order[0] = SRC; c.order[1] = SNK; c.index[SRC] = 0; c.index[SNK] = 1;
+        c.base()[SRC] = 0; c.base()[SNK] = 0; c.n_in()[SRC] = c.n_out()[SRC] = c.n_in()[SNK] = c.n_out()[SNK] = 0;
+        c.grp()[SRC] = SRC; c.grp()[SNK] = SNK; c.order()[0] = SRC; c.order()[1] = SNK; c.index()[SRC] = 0; c.index()[SNK] = 1;
       }
       c.n = 2;
       WSYNC();
@@ -564,7 +573,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
       for (int s = 0; s < ns && !fail; ++s) {
         const int qb = info->sub_beg[s], Q = info->sub_end[s] - qb;
         if (s > 0) { if (poa_align(c, a.p, qb, Q, lane, &cells PHP) < 0) { fail = 1; break; } }
-        if (poa_fuse(c, s == 0, qb, Q, c.path + poff, lane PHP) < 0) { fail = 1; break; }
+        if (poa_fuse(c, s == 0, qb, Q, c.path() + poff, lane PHP) < 0) { fail = 1; break; }
         poff += Q;
       }
       PH_MARK(9)
@@ -575,17 +584,17 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
           const int i = i0 + lane;
           int v = -1, start = 0;
           if (i < c.n) {
-            v = c.order[i];
-            if (v != SRC && v != SNK) start = (i == 0) || (c.grp[v] != c.grp[c.order[i - 1]]) || c.order[i - 1] == SRC;
+            v = c.order()[i];
+            if (v != SRC && v != SNK) start = (i == 0) || (c.grp()[v] != c.grp()[c.order()[i - 1]]) || c.order()[i - 1] == SRC;
           }
           const int ps = wave_scan_add(start);
-          if (i < c.n) c.col[v] = (v == SRC || v == SNK) ? -1 : ncol_acc + ps - 1;
+          if (i < c.n) c.col()[v] = (v == SRC || v == SNK) ? -1 : ncol_acc + ps - 1;
           ncol_acc += wave_bcast(ps, 63);
         }
         WSYNC();
         PH_MARK(5)
         const int ncol = ncol_acc;
-        for (int i = lane; i < ncol; i += 64) c.col2t[i] = -1;
+        for (int i = lane; i < ncol; i += 64) c.col2t()[i] = -1;
         if (a.msa_dbg) {                       // res.msa_seq rows (codes, 4 = gap), row-major
           uint8_t* dbg = a.msa_dbg + a.msa_off[rid];
           for (int i = lane; i < ns * ncol; i += 64) dbg[i] = 4;
@@ -593,7 +602,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
           int po = 0;
           for (int s = 0; s < ns; ++s) {
             const int Q = info->sub_end[s] - info->sub_beg[s];
-            for (int k = lane; k < Q; k += 64) { int v = c.path[po + k]; dbg[(size_t)s * ncol + c.col[v]] = c.base[v]; }
+            for (int k = lane; k < Q; k += 64) { int v = c.path()[po + k]; dbg[(size_t)s * ncol + c.col()[v]] = c.base()[v]; }
             po += Q;
           }
           if (lane == 0) a.msa_len[rid] = ncol;
@@ -601,13 +610,13 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
         WSYNC();
         if (ns == 2) {
           // rows (codes, 4 = gap) -> bin/consensus.py pairwise_consensus
-          uint8_t* rowA = c.rows2; uint8_t* rowB = c.rows2 + ncol;
-          uint8_t* qa = c.rows2 + 2 * (size_t)ncol; uint8_t* qb_ = c.rows2 + 3 * (size_t)ncol;
-          for (int i = lane; i < 2 * ncol; i += 64) c.rows2[i] = 4;
+          uint8_t* rowA = c.rows2(); uint8_t* rowB = c.rows2() + ncol;
+          uint8_t* qa = c.rows2() + 2 * (size_t)ncol; uint8_t* qb_ = c.rows2() + 3 * (size_t)ncol;
+          for (int i = lane; i < 2 * ncol; i += 64) c.rows2()[i] = 4;
           WSYNC();
           const int b0 = info->sub_beg[0], l0 = info->sub_end[0] - b0, b1 = info->sub_beg[1], l1 = info->sub_end[1] - b1;
-          for (int k = lane; k < l0; k += 64) { int v = c.path[k]; rowA[c.col[v]] = c.base[v]; }
-          for (int k = lane; k < l1; k += 64) { int v = c.path[l0 + k]; rowB[c.col[v]] = c.base[v]; }
+          for (int k = lane; k < l0; k += 64) { int v = c.path()[k]; rowA[c.col()[v]] = c.base()[v]; }
+          for (int k = lane; k < l1; k += 64) { int v = c.path()[l0 + k]; rowB[c.col()[v]] = c.base()[v]; }
           WSYNC();
           if (lane == 0) {
             // seqDict collision: identical subreads share the later quality (consensus.py:77-79)
@@ -615,11 +624,11 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
             for (int k = 0; same && k < l0; ++k) same = c3_code_at(c.pk, b0 + k) == c3_code_at(c.pk, b1 + k);
             normalize_len(rowA, ncol, same ? qual + b1 : qual + b0, l0, qa);
             normalize_len(rowB, ncol, qual + b1, l1, qb_);
-            const int o = pairwise_merge(rowA, rowB, ncol, qa, qb_, draft, c.col2t);
-            c.rem[0] = o;
+            const int o = pairwise_merge(rowA, rowB, ncol, qa, qb_, draft, c.col2t());
+            c.rem()[0] = o;
           }
           WSYNC();
-          C = c.rem[0];
+          C = c.rem()[0];
         } else {
           // ---- abPOA heaviest bundling: nxt[v] = out-edge of maximum weight, ties (equal weight) go to the LATER edge
           // whose target has a score >= the current one, score[v] = weight + score[nxt[v]] (reverse topological sweep in
@@ -630,17 +639,17 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
           // tables instead of a 1500-step pointer chase.
           {
             const int K = c.K, n = c.n;
-            int* nxA = c.jump; int* nxB = c.jump + (size_t)c.Ncap; int* ssA = c.jump + 2 * (size_t)c.Ncap; int* ssB = c.jump + 3 * (size_t)c.Ncap;
-            int* score = c.jump + 4 * (size_t)c.Ncap; int* tief = c.jump + 5 * (size_t)c.Ncap;     // all rebuilt below
+            int* nxA = c.jump(); int* nxB = c.jump() + (size_t)c.Ncap; int* ssA = c.jump() + 2 * (size_t)c.Ncap; int* ssB = c.jump() + 3 * (size_t)c.Ncap;
+            int* score = c.jump() + 4 * (size_t)c.Ncap; int* tief = c.jump() + 5 * (size_t)c.Ncap;     // all rebuilt below
             for (int v = lane; v < n; v += 64) {
-              const int no = c.n_out[v];
+              const int no = c.n_out()[v];
               int bw = INT32_MIN, bt = SNK, cm = 0;
               for (int k = 0; k < no; ++k) {
-                const int ww = c.out_w[v * K + k];
-                if (ww > bw) { bw = ww; bt = c.out_to[v * K + k]; cm = 1; } else if (ww == bw) ++cm;
+                const int ww = c.out_w()[v * K + k];
+                if (ww > bw) { bw = ww; bt = c.out_to()[v * K + k]; cm = 1; } else if (ww == bw) ++cm;
               }
               const bool term = (v == SNK) || cm >= 2 || no == 0;
-              c.nxt[v] = bt; tief[v] = (v != SNK && cm >= 2) ? 1 : 0;
+              c.nxt()[v] = bt; tief[v] = (v != SNK && cm >= 2) ? 1 : 0;
               nxA[v] = term ? v : bt; ssA[v] = term ? 0 : bw;
               score[v] = (v == SNK) ? 0 : (no == 0 ? INT32_MIN : 0);
             }
@@ -659,16 +668,16 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
             // (c) tie nodes, last in topological order first
             for (int i1 = n; i1 > 0; i1 -= 64) {
               const int i = i1 - 1 - lane;
-              const int vl = i >= 0 ? c.order[i] : 0;
+              const int vl = i >= 0 ? c.order()[i] : 0;
               unsigned long long todo = __ballot(i >= 0 && tief[vl]);
               while (todo) {
                 const int t = __builtin_ctzll(todo); todo &= todo - 1;
                 const int vv = wave_bcast(vl, t);
-                const int no = c.n_out[vv];
+                const int no = c.n_out()[vv];
                 // lane k evaluates out-edge k: weight, target, score of the target
                 int ww = INT32_MIN, tt = SNK, st = 0;
                 if (lane < min(no, 64)) {
-                  ww = c.out_w[vv * K + lane]; tt = c.out_to[vv * K + lane];
+                  ww = c.out_w()[vv * K + lane]; tt = c.out_to()[vv * K + lane];
                   const int tm = nxA[tt];
                   st = (tm == tt) ? score[tt] : ssA[tt] + score[tm];
                 }
@@ -677,25 +686,25 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
                   int wk, tk, sk;
                   if (k < 64) { wk = wave_bcast(ww, k); tk = wave_bcast(tt, k); sk = wave_bcast(st, k); }
                   else {                                     // more than 64 out-edges: uniform loads
-                    wk = c.out_w[vv * K + k]; tk = c.out_to[vv * K + k];
+                    wk = c.out_w()[vv * K + k]; tk = c.out_to()[vv * K + k];
                     const int tm = nxA[tk];
                     sk = (tm == tk) ? score[tk] : ssA[tk] + score[tm];
                   }
                   if (wk > bw) { bw = wk; bt = tk; sbt = sk; }
                   else if (wk == bw && sbt <= sk) { bt = tk; sbt = sk; }
                 }
-                if (lane == 0) { score[vv] = bw + sbt; c.nxt[vv] = bt; }
+                if (lane == 0) { score[vv] = bw + sbt; c.nxt()[vv] = bt; }
                 WSYNC();
               }
             }
             WSYNC();
-            // jump tables J_r = nxt^(2^r) and hop counts; level r lives in c.jump + r*Ncap (level 0 = nxt)
-            int* d0 = c.mpl; int* d1 = c.mpr;
-            for (int v = lane; v < n; v += 64) { c.jump[v] = c.nxt[v]; d0[v] = (v == SNK) ? 0 : 1; }
+            // jump tables J_r = nxt^(2^r) and hop counts; level r lives in c.jump() + r*Ncap (level 0 = nxt)
+            int* d0 = c.mpl(); int* d1 = c.mpr();
+            for (int v = lane; v < n; v += 64) { c.jump()[v] = c.nxt()[v]; d0[v] = (v == SNK) ? 0 : 1; }
             WSYNC();
             int levels = 1;
             for (int r = 0; (1 << r) < n && r + 1 < C3_JUMP_LEVELS; ++r) {
-              const int* Jr = c.jump + (size_t)r * c.Ncap; int* Jn = c.jump + (size_t)(r + 1) * c.Ncap;
+              const int* Jr = c.jump() + (size_t)r * c.Ncap; int* Jn = c.jump() + (size_t)(r + 1) * c.Ncap;
               for (int v = lane; v < n; v += 64) { const int u = Jr[v]; Jn[v] = Jr[u]; d1[v] = d0[v] + d0[u]; }
               WSYNC();
               int* tsw = d0; d0 = d1; d1 = tsw;
@@ -708,8 +717,8 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
               const int pp = p0 + lane;
               if (pp < C) {
                 int node = SRC; const int steps = pp + 1;
-                for (int r = 0; r < levels; ++r) if ((steps >> r) & 1) node = c.jump[(size_t)r * c.Ncap + node];
-                draft[pp] = c.base[node]; c.col2t[c.col[node]] = pp;
+                for (int r = 0; r < levels; ++r) if ((steps >> r) & 1) node = c.jump()[(size_t)r * c.Ncap + node];
+                draft[pp] = c.base()[node]; c.col2t()[c.col()[node]] = pp;
               }
             }
             if (C < 0) { fail = 1; C = 0; }
@@ -722,7 +731,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
         int poff2 = 0;
         for (int s = 0; s < ns; ++s) {
           const int qb = info->sub_beg[s], Q = info->sub_end[s] - qb;
-          for (int k = lane; k < Q; k += 64) tpos[qb + k] = c.col2t[c.col[c.path[poff2 + k]]];
+          for (int k = lane; k < Q; k += 64) tpos[qb + k] = c.col2t()[c.col()[c.path()[poff2 + k]]];
           poff2 += Q;
         }
       }
