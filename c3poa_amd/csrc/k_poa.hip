@@ -27,7 +27,7 @@ struct Ctx {
   const uint32_t* pk;        // packed read
 #define CTX_I(name, k) __device__ __forceinline__ int* name() const { return I + (size_t)(k) * Ncap; }
   CTX_I(n_in, 0) CTX_I(n_out, 1) CTX_I(grp, 2) CTX_I(order, 3) CTX_I(order2, 4) CTX_I(index, 5) CTX_I(gfirst, 6) CTX_I(glast, 7)
-  CTX_I(rem, 8) CTX_I(mpl, 9) CTX_I(mpr, 10) CTX_I(rbeg, 11) CTX_I(rend, 12) CTX_I(roff, 13) CTX_I(anchor, 14) CTX_I(col, 15)
+  CTX_I(rem, 8) CTX_I(mpl, 9) CTX_I(mpr, 10) CTX_I(rowm, 11) /* 3 ints per row: band begin, band end, cell offset (blocks 11..13) */ CTX_I(anchor, 14) CTX_I(col, 15)
   CTX_I(col2t, 16) CTX_I(nxt, 17) CTX_I(opn, 18) CTX_I(opq, 20) CTX_I(path, 22)
 #undef CTX_I
   __device__ __forceinline__ int* in_from() const { return E; }
@@ -245,7 +245,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         const int left = beg + __builtin_ctzll(mxm), right = beg + 63 - __builtin_clzll(mxm);
         if (lane == 0) {
           L.beg[slot] = beg; L.end[slot] = end; L.rl[slot] = left; L.rr[slot] = right; L.inl[slot] = 1;
-          c.rbeg()[idx] = beg; c.rend()[idx] = end; c.roff()[idx] = ro;
+          { int* rm = c.rowm() + 3 * idx; rm[0] = beg; rm[1] = end; rm[2] = ro; }
           if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
         }
         pv_idx = idx; pv_beg = beg; pv_end = end; pv_left = left; pv_right = right; pv_inl = 1;
@@ -262,7 +262,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         const int pi = PRED_IDX(k);
         int b, e, l, r;
         if (idx - pi < PR) { const int sl = pi & (PR - 1); b = L.beg[sl]; e = L.end[sl]; l = L.rl[sl]; r = L.rr[sl]; }
-        else { b = c.rbeg()[pi]; e = c.rend()[pi]; l = c.mpl()[pi]; r = c.mpr()[pi]; }
+        else { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1]; l = c.mpl()[pi]; r = c.mpr()[pi]; }
         minb = min(minb, b); maxe = max(maxe, e + 1);
         if (e >= b) { mplv = min(mplv, l + 1); mprv = max(mprv, r + 1); }
       }
@@ -297,8 +297,8 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
             if (j >= b && j <= e) { hp = L.H[sl][j - b]; e1p = L.E1[sl][j - b]; e2p = L.E2[sl][j - b]; }
           } else {
             int b, e;
-            if (idx - pi < PR) { b = L.beg[sl]; e = L.end[sl]; } else { b = c.rbeg()[pi]; e = c.rend()[pi]; }
-            const int po = c.roff()[pi];
+            if (idx - pi < PR) { b = L.beg[sl]; e = L.end[sl]; } else { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1]; }
+            const int po = c.rowm()[3 * pi + 2];
             if (j > 0 && j - 1 >= b && j - 1 <= e) hd = c.H()[po + (j - 1 - b)];
             if (j >= b && j <= e) { hp = c.H()[po + (j - b)]; e1p = c.E1()[po + (j - b)]; e2p = c.E2()[po + (j - b)]; }
           }
@@ -348,7 +348,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     }
     if (lane == 0) {
       L.beg[slot] = beg; L.end[slot] = end; L.rl[slot] = left; L.rr[slot] = right; L.inl[slot] = inl;
-      c.rbeg()[idx] = beg; c.rend()[idx] = end; c.roff()[idx] = ro;
+      { int* rm = c.rowm() + 3 * idx; rm[0] = beg; rm[1] = end; rm[2] = ro; }
       if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
     }
     pv_idx = idx; pv_beg = beg; pv_end = end; pv_left = left; pv_right = right; pv_inl = inl;
@@ -361,7 +361,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   int bi = -1, bs = INT32_MIN;
   for (int k = 0; k < c.n_in()[SNK]; ++k) {
     const int pi = c.index()[c.in_from()[SNK * K + k]];
-    const int hh = (Q < c.rbeg()[pi] || Q > c.rend()[pi]) ? NEGS : c.H()[c.roff()[pi] + (Q - c.rbeg()[pi])];
+    const int hh = (Q < c.rowm()[3 * pi] || Q > c.rowm()[3 * pi + 1]) ? NEGS : c.H()[c.rowm()[3 * pi + 2] + (Q - c.rowm()[3 * pi])];
     if (hh > bs) { bs = hh; bi = pi; }
   }
   if (bi < 0 || bs <= NEGS / 2) return -1;
@@ -380,7 +380,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     while (!(i == 0 && j == 0)) {
       const int ik = i - lane, jk = j - lane;
       const int ic = max(ik, 0);
-      const int b = c.rbeg()[ic], e = c.rend()[ic], ro = c.roff()[ic];
+      const int b = c.rowm()[3 * ic], e = c.rowm()[3 * ic + 1], ro = c.rowm()[3 * ic + 2];
       const uint4 A = c.descA()[ic], B = c.descB()[ic];
       const bool inb = ik >= 0 && jk >= b && jk <= e;
       const unsigned d = inb ? c.D()[ro + (jk - b)] : 0u;
