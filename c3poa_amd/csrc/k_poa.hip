@@ -260,9 +260,13 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       int mplv = INT32_MAX / 2, mprv = 0, minb = INT32_MAX, maxe = INT32_MIN;
       for (int k = 0; k < nin; ++k) {
         const int pi = PRED_IDX(k);
-        int b, e, l, r;
-        if (idx - pi < PR) { const int sl = pi & (PR - 1); b = L.beg[sl]; e = L.end[sl]; l = L.rl[sl]; r = L.rr[sl]; }
-        else { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1]; l = c.mpl()[pi]; r = c.mpr()[pi]; }
+        // LDS reads are unconditional (the slot index is always valid) and the rare out-of-ring predecessor overrides
+        // them: written as if/else, the compiler selects between an LDS and a global POINTER and emits a flat load,
+        // whose vmcnt wait drains every outstanding row store
+        const int sl = pi & (PR - 1);
+        int b = L.beg[sl], e = L.end[sl], l = L.rl[sl], r = L.rr[sl];
+        asm volatile("" : "+v"(b), "+v"(e), "+v"(l), "+v"(r));                     // the LDS loads happen HERE
+        if (idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1]; l = c.mpl()[pi]; r = c.mpr()[pi]; }
         minb = min(minb, b); maxe = max(maxe, e + 1);
         if (e >= b) { mplv = min(mplv, l + 1); mprv = max(mprv, r + 1); }
       }
@@ -296,8 +300,9 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
             if (j > 0 && j - 1 >= b && j - 1 <= e) hd = L.H[sl][j - 1 - b];
             if (j >= b && j <= e) { hp = L.H[sl][j - b]; e1p = L.E1[sl][j - b]; e2p = L.E2[sl][j - b]; }
           } else {
-            int b, e;
-            if (idx - pi < PR) { b = L.beg[sl]; e = L.end[sl]; } else { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1]; }
+            int b = L.beg[sl], e = L.end[sl];                                  // see the note above: no pointer select
+            asm volatile("" : "+v"(b), "+v"(e));
+            if (idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1]; }
             const int po = c.rowm()[3 * pi + 2];
             if (j > 0 && j - 1 >= b && j - 1 <= e) hd = c.H()[po + (j - 1 - b)];
             if (j >= b && j <= e) { hp = c.H()[po + (j - b)]; e1p = c.E1()[po + (j - b)]; e2p = c.E2()[po + (j - b)]; }

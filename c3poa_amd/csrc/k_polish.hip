@@ -32,6 +32,10 @@
 // the draft sits in LDS and the piece bases arrive 64 rows at a time, so the row loop has no loads.
 #define EC 5
 #define EXT_DCAP 4096        // draft bases kept in LDS; longer drafts read the global copy
+// DL: the draft fits the LDS copy.  A template parameter, not a run-time flag: `dl ? ldraft[i] : draft[i]` makes the
+// compiler select between an LDS and a global pointer and emit flat loads, whose vmcnt wait drains every outstanding
+// direction-byte store -- once per row.
+template <bool DL>
 __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const uint8_t* draft, const uint8_t* ldraft, int C,
                                   int pb, int n, int dir_, int32_t* tpos, uint8_t* D, int lane) {
   const int W = a.p.dang_band, bw = 2 * W + 1;
@@ -40,7 +44,6 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
   const int NEGK = -(1 << 28);
   for (int k = lane; k < n; k += 64) tpos[pb + dir_ * k] = -1;
   if (bw > 64 * EC || (long long)(n + 1) * 512 > a.ecap) return -1;
-  const bool dl = C <= EXT_DCAP;
   int hprev[EC];
 #pragma unroll
   for (int cc = 0; cc < EC; ++cc) {           // row 0: H[0][j] = j*g for 0 <= j <= min(C, W)
@@ -69,7 +72,7 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
         int k = INT32_MIN;
         if (val) {
           if (j > 0) {
-            const int dcode = dl ? (int)ldraft[db + dir_ * (j - 1)] : (int)draft[db + dir_ * (j - 1)];
+            const int dcode = DL ? (int)ldraft[db + dir_ * (j - 1)] : (int)draft[db + dir_ * (j - 1)];
             k = hprev[cc] + ((pc == dcode) ? mt4 : mm4) + 3;
           }
           const int up = (cc + 1 < EC) ? hprev[cc + 1 < EC ? cc + 1 : cc] : nxt0;
@@ -148,8 +151,13 @@ __device__ __forceinline__ void prep_one(const PrepArgs& a, int wi, int lane, ui
     long long cells = 0;
     // ---- dangling pieces (tail: anchored at the draft start; front: at the draft end)
     if ((ht || hf) && C <= EXT_DCAP) { for (int t = lane; t < C; t += 64) ldraft[t] = draft[t]; WSYNC(); }
-    if (ht) { long long r = extend_align(a, pk, draft, ldraft, C, info->tail_beg, L - info->tail_beg, +1, tpos, eD, lane); if (r > 0) cells += r; }
-    if (hf) { long long r = extend_align(a, pk, draft, ldraft, C, info->front_end - 1, info->front_end, -1, tpos, eD, lane); if (r > 0) cells += r; }
+    if (C <= EXT_DCAP) {
+      if (ht) { long long r = extend_align<true>(a, pk, draft, ldraft, C, info->tail_beg, L - info->tail_beg, +1, tpos, eD, lane); if (r > 0) cells += r; }
+      if (hf) { long long r = extend_align<true>(a, pk, draft, ldraft, C, info->front_end - 1, info->front_end, -1, tpos, eD, lane); if (r > 0) cells += r; }
+    } else {
+      if (ht) { long long r = extend_align<false>(a, pk, draft, ldraft, C, info->tail_beg, L - info->tail_beg, +1, tpos, eD, lane); if (r > 0) cells += r; }
+      if (hf) { long long r = extend_align<false>(a, pk, draft, ldraft, C, info->front_end - 1, info->front_end, -1, tpos, eD, lane); if (r > 0) cells += r; }
+    }
     // ---- layers: kept subreads, front, tail
     const int nl = ns + hf + ht;
     const int nwin = (C + WL - 1) / WL;
