@@ -210,11 +210,15 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         ncell += wd;
         const int j = beg + lane, o = j - b;
         const bool act = j <= end;
-        int hd = NEGS, hp = NEGS, e1p = NEGS, e2p = NEGS;
-        if (act && o >= 1) hd = L.H[sl][o - 1];
-        if (act && j <= e) { hp = L.H[sl][o]; e1p = L.E1[sl][o]; e2p = L.E2[sl][o]; }
+        // all LDS reads of the row are issued together on clamped (always valid) addresses and masked afterwards: inside
+        // their own `if`s each read gets its own s_waitcnt, three LDS round trips per row instead of one
+        const int oc = min(max(o, 0), PW - 1), om = min(max(o - 1, 0), PW - 1), jq = min(max(j - 1, 0), PQW * 16 - 1);
+        const int hd_ = L.H[sl][om], hp_ = L.H[sl][oc], e1_ = L.E1[sl][oc], e2_ = L.E2[sl][oc];
+        const unsigned qw_ = L.qpk[jq >> 4];
+        const bool inp = act && j <= e;
+        const int hd = (act && o >= 1) ? hd_ : NEGS, hp = inp ? hp_ : NEGS, e1p = inp ? e1_ : NEGS, e2p = inp ? e2_ : NEGS;
         int qc = 7;
-        if (act && j > 0) qc = qlds ? (int)((L.qpk[(j - 1) >> 4] >> (((j - 1) & 15) * 2)) & 3) : c3_code_at(c.pk, qb + j - 1);
+        if (act && j > 0) qc = qlds ? (int)((qw_ >> ((jq & 15) * 2)) & 3) : c3_code_at(c.pk, qb + j - 1);
         const int M9 = (j > 0) ? hd + ((vb == qc) ? mt9 : mm9) : NEGS;
         const int a1 = hp - oe1_9, x1 = e1p - e1_9, a2 = hp - oe2_9, x2 = e2p - e2_9;
         const int E1v = max(a1, x1), E2v = max(a2, x2);
