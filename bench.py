@@ -211,7 +211,21 @@ def cpu_baseline(recs, mdist, seconds):
     t = time.perf_counter()
     res, cons = O.process_batch(synth.SPLINT1, [(r[0], r[1]) for r in sample], [r[2] for r in sample], params=P, threads=cores)
     dt = time.perf_counter() - t
+    # per-core rate ("-n 1"): one thread on a small slice of the same sample
+    one = sample[:min(len(sample), max(16, int(3.0 * rate / max(cores, 1))))]
+    t1 = time.perf_counter()
+    O.process_batch(synth.SPLINT1, [(r[0], r[1]) for r in one], [r[2] for r in one], params=P, threads=1)
+    per_core = len(one) / (time.perf_counter() - t1)
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
     return {"value": round(n / dt, 1), "unit": "reads/s", "cores": cores, "kind": "port",
+            "per_core_reads_per_s": round(per_core, 1), "cpu_model": model, "host_cpus": os.cpu_count(),
             "sample": "first %d reads of the same synthetic batch, oracle/libc3oracle.so (own CPU restatement, "
                       "-O3, OpenMP %d threads = usable host cores of %d), %.1f s" % (n, cores, os.cpu_count(), dt)}
 
