@@ -258,6 +258,7 @@ extern "C" int c3_batch_upload(c3_handle* h, int n, const char* seqs, const char
   HIPCHK(hipMemcpyAsync(h->d_sid.p, sid.data(), sizeof(int16_t) * n, hipMemcpyHostToDevice, h->stream));
   dim3 g((unsigned)std::min((n + 3) / 4, h->n_cus * 32));
   hipLaunchKernelGGL(k_pack, g, dim3(256), 0, h->stream, h->d_ascii.as<uint8_t>(), h->d_off.as<int64_t>(), h->d_woff.as<int64_t>(), n, h->d_pk.as<uint32_t>());
+  HIPCHK(hipMemsetAsync(h->d_info.p, 0, sizeof(C3Info) * (size_t)n, h->stream));   // the unused tails of peaks[] / sub_*[] read as 0
   hipLaunchKernelGGL(k_init_info, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), n);
   HIPCHK(hipEventRecord(h->ev[1], h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));

@@ -305,3 +305,31 @@ def test_window_consensus_global_scratch_path(O, monkeypatch):
     monkeypatch.setenv("C3_DEBUG_WIN_LCAP", "64")                 # every window graph is "too large" for LDS
     recs = list(synth.generate("cfg1", n_reads=24))
     _compare(O, [synth.SPLINT1], [(r[1], r[2]) for r in recs], [r[3] for r in recs], [0] * len(recs))
+
+
+def test_results_do_not_depend_on_slot_count_or_run():
+    """same batch, different numbers of resident wave slots, repeated runs: bit-identical records and consensi
+    (work is pulled from atomic queues, so scheduling differs; results must not)"""
+    from c3poa_amd import _lib
+    recs = list(synth.generate("cfg3", n_reads=96)) + list(synth.generate("cfg1", n_reads=32))
+    ref = None
+    for kw in ({}, {"slots_poa": 7, "slots_win": 5}, {"slots_poa": 64, "slots_win": 300}):
+        h = _lib.Handle(**kw)
+        h.set_splints([synth.SPLINT1])
+        h.upload([r[1] for r in recs], [r[2] for r in recs], [r[3] for r in recs])
+        for _rep in range(2):
+            h.run()
+            res, cons = h.results()
+            # the fixed-size arrays are only defined up to n_peaks / n_sub
+            rec = tuple((int(r["status"]), int(r["n_peaks"]), tuple(r["peaks"][:r["n_peaks"]].tolist()), int(r["n_sub"]),
+                         tuple(r["sub_beg"][:r["n_sub"]].tolist()), tuple(r["sub_end"][:r["n_sub"]].tolist()),
+                         int(r["has_front"]), int(r["has_tail"]), int(r["front_end"]), int(r["tail_beg"]),
+                         int(r["cons_len"]), int(r["draft_len"]), int(r["n_win"])) for r in res)
+            key = (rec, tuple(cons))
+            if ref is None:
+                ref = key
+            assert key[1] == ref[1], kw
+            assert key[0] == ref[0], kw
+            assert not res["peaks"][np.arange(256)[None, :] >= res["n_peaks"][:, None]].any()      # unused tails are zeroed
+        h.close()
+    assert sum(1 for c in ref[1] if c) >= 120
