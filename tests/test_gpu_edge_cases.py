@@ -333,3 +333,32 @@ def test_results_do_not_depend_on_slot_count_or_run():
             assert not res["peaks"][np.arange(256)[None, :] >= res["n_peaks"][:, None]].any()      # unused tails are zeroed
         h.close()
     assert sum(1 for c in ref[1] if c) >= 120
+
+
+def test_handle_reuse_across_different_batches():
+    """a handle that has processed other (larger, different) batches gives the same results as a fresh one:
+    no state leaks between batches (work lists, counters, zero-repeat flags, window records, scratch)"""
+    from c3poa_amd import _lib
+    rng = np.random.default_rng(21)
+    big = list(synth.generate("cfg3", n_reads=150))
+    s = _rand(rng, 2600)
+    zero = (s[:1300] + synth.SPLINT1 + s[700:], None)                      # one splint, overlapping ends: zero-repeat rescue
+    small = list(synth.generate("cfg1", n_reads=9, start=500))
+    small_reads = [(r[1], r[2], r[3]) for r in small] + [(zero[0], _qual(rng, len(zero[0])), "+"), (_rand(rng, 900), _qual(rng, 900), "+")]
+
+    def run(h, reads):
+        h.upload([r[0] for r in reads], [r[1] for r in reads], [r[2] for r in reads])
+        h.run()
+        res, cons = h.results()
+        return [(int(r["status"]), int(r["n_sub"]), int(r["n_peaks"]), int(r["cons_len"])) for r in res], cons
+
+    fresh = _lib.Handle(); fresh.set_splints([synth.SPLINT1])
+    want = run(fresh, small_reads)
+    fresh.close()
+    h = _lib.Handle(); h.set_splints([synth.SPLINT1])
+    run(h, [(r[1], r[2], r[3]) for r in big])
+    run(h, small_reads[-2:] * 20)                                          # many zero-repeat / no-peak reads
+    got = run(h, small_reads)
+    h.close()
+    assert got == want
+    assert want[0][-2][0] in (0, 3) and any(c for c in want[1])
