@@ -362,3 +362,39 @@ def test_handle_reuse_across_different_batches():
     h.close()
     assert got == want
     assert want[0][-2][0] in (0, 3) and any(c for c in want[1])
+
+
+def test_abi_error_paths_return_codes_not_crashes():
+    """misuse of the C ABI returns a negative c3_err (and c3_last_error text) -- nothing crosses the boundary as a crash"""
+    import ctypes as C
+    from c3poa_amd import _lib
+    lib = _lib.load()
+    h = _lib.Handle()
+    hp = h.h
+    seq = b"ACGT" * 300; q = b"I" * len(seq)
+    off = np.array([0, len(seq)], dtype=np.int64)
+    sid = np.zeros(1, dtype=np.int16); st = np.frombuffer(b"+", dtype=np.uint8)
+    up = lambda o=off, s_=sid: lib.c3_batch_upload(hp, 1, seq, q, o.ctypes.data, s_.ctypes.data, st.ctypes.data)   # noqa: E731
+    assert up() == -5 and b"c3_set_splints" in lib.c3_last_error(hp)            # C3_E_STATE: no splints yet
+    assert lib.c3_batch_run(hp, 15) < 0                                           # nothing uploaded
+    too_long = b"A" * 513
+    o2 = np.array([0, 513], dtype=np.int64)
+    assert lib.c3_set_splints(hp, 1, too_long, o2.ctypes.data) == -6              # C3_E_LIMIT
+    h.set_splints([synth.SPLINT1])
+    assert up(np.array([5, len(seq)], dtype=np.int64)) == -3                      # off[0] != 0
+    assert up(off, np.array([3], dtype=np.int16)) == -3                           # splint_id out of range
+    assert lib.c3_batch_upload(hp, 0, seq, q, off.ctypes.data, sid.ctypes.data, st.ctypes.data) == -3
+    assert up() == 0
+    out = np.zeros(10, dtype=np.int32)
+    assert lib.c3_fetch_track(hp, 0, out.ctypes.data, 10) < 0                     # stage not run yet
+    assert lib.c3_batch_run(hp, 15) == 0
+    assert lib.c3_fetch_track(hp, 0, out.ctypes.data, 10) == -6                   # capacity too small
+    assert lib.c3_fetch_track(hp, 7, out.ctypes.data, 10) == -3                   # read index out of range
+    res = np.zeros(1, dtype=_lib.RESULT_DTYPE); coff = np.zeros(2, dtype=np.int64)
+    rd = list(synth.generate("cfg1", n_reads=1))[0]
+    h.upload([rd[1]], [rd[2]], [rd[3]]); h.run()
+    tiny = np.zeros(8, dtype=np.uint8)
+    assert lib.c3_batch_results(hp, res.ctypes.data, tiny.ctypes.data, 8, coff.ctypes.data) == -6 and coff[1] > 1000   # needed size reported
+    assert lib.c3_scan_adapters(hp, None) < 0 and lib.c3_match_index_batch(hp, 0, None, None, 2, None, None, None) < 0
+    assert lib.c3_pairwise_consensus(hp, b"AC-T", b"ACGT", 4, b"ACT", 2, b"III", b"ACGT", 4, b"IIII", C.create_string_buffer(8), 8, C.byref(C.c_int())) == -3
+    h.close()
