@@ -148,3 +148,32 @@ def test_pairwise_consensus_against_reference_golden(golden):
     # identical subreads share the later quality (bin/consensus.py:77-79)
     assert shims.pairwise_consensus(["AC-GT", "ACG-T"], ["ACGT", "ACGT"], ["IIII", "5555"]) == \
         __import__("oracle.oracle_py", fromlist=["x"]).pairwise_consensus(["AC-GT", "ACG-T"], ["ACGT", "ACGT"], ["IIII", "5555"])
+
+
+def test_full_size_cfg2_properties():
+    """BASELINE cfg2 at its full size (100 000 reads in one batch): size-independent properties -- two half batches give
+    the slices of the whole, a random sample equals the oracle exactly, every read but a handful yields a consensus"""
+    import bench
+    from c3poa_amd import _lib
+    from oracle import oracle_py as O
+    n = 100000
+    recs = bench.make_reads("cfg2", n, 0, 16)                       # (seq, qual, strand, truth)
+    seqs, quals, st = [r[0] for r in recs], [r[1] for r in recs], [r[2] for r in recs]
+    h = _lib.Handle()
+    h.set_splints([synth.SPLINT1])
+    h.upload(seqs, quals, st)
+    h.run()
+    res, cons = h.results()
+    assert (res["status"] == 0).sum() >= n - 20 and all(len(c) > 1000 for c, s in zip(cons, res["status"]) if s == 0)
+    parts = []
+    for lo, hi in ((0, n // 2), (n // 2, n)):
+        h.upload(seqs[lo:hi], quals[lo:hi], st[lo:hi])
+        h.run()
+        parts += h.results()[1]
+    assert parts == cons                                                             # sharding invariance (SURVEY 8(e))
+    h.close()
+    idx = np.random.default_rng(5).choice(n, 48, replace=False)
+    _ores, ocons = O.process_batch(synth.SPLINT1, [(seqs[i], quals[i]) for i in idx], [st[i] for i in idx], threads=16)
+    assert [cons[i] for i in idx] == ocons
+    ident = [synth.identity(cons[i], recs[i][3]) for i in idx[:24] if cons[i]]
+    assert np.mean(ident) > 0.96
