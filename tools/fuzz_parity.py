@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep, GPU path against the oracle (diagnostic, slower than the test suite):
+   python tools/fuzz_parity.py [n_reads] [seed]
+Concatemers with random insert length (60..3500), repeats (0..14), flank lengths, error rate (0..25 %), strand, quality
+profile, occasional non-ACGT bytes / lower case, plus pure noise reads."""
+import sys
+import numpy as np
+sys.path.insert(0, ".")
+from c3poa_amd import _lib, synth
+from c3poa_amd.seqio import revcomp
+from oracle import oracle_py as O
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+rnd = lambda L: acgt[rng.integers(0, 4, L)].tobytes().decode()   # noqa: E731
+reads, strands = [], []
+for i in range(n):
+    kind = rng.integers(0, 20)
+    if kind == 0:
+        s = rnd(int(rng.integers(0, 4000))); q = "".join(chr(33 + int(v)) for v in rng.integers(0, 60, len(s)))
+    else:
+        ins = rnd(int(rng.integers(60, 3500)))
+        reps = int(rng.integers(0, 15)) if len(ins) < 1200 else int(rng.integers(0, 6))
+        k0, k1 = int(rng.integers(0, len(ins))), int(rng.integers(0, len(ins)))
+        clean = ins[len(ins) - k0:] + (synth.SPLINT1 + ins) * reps + synth.SPLINT1 + ins[:k1]
+        err = float(rng.choice([0.0, 0.03, 0.1, 0.1, 0.15, 0.25]))
+        sb, qb = synth._mutate(rng, np.frombuffer(clean.encode(), dtype=np.uint8), sub=err * 0.4, ins=err * 0.25, dele=err * 0.35)
+        s, q = sb.decode(), qb.decode()
+        if kind == 1:
+            q = "".join(chr(33 + int(v)) for v in rng.integers(0, 8, len(s)))            # very low qualities
+        if kind == 2 and len(s) > 50:
+            p = int(rng.integers(0, len(s) - 20)); s = s[:p] + "NNNNnnnnacgtRYKM" + s[p + 16:]
+    st = "+"
+    if rng.random() < 0.5:
+        s, q, st = revcomp(s), q[::-1], "-"
+    if rng.random() < 0.03:
+        st = "?"
+    reads.append((s, q)); strands.append(st)
+keep = [i for i, r in enumerate(reads) if len(r[0]) > 0]
+reads = [reads[i] for i in keep]; strands = [strands[i] for i in keep]
+h = _lib.Handle(); h.set_splints([synth.SPLINT1])
+h.upload([r[0] for r in reads], [r[1] for r in reads], strands)
+h.run()
+res, cons = h.results()
+ores, ocons = O.process_batch(synth.SPLINT1, reads, strands, threads=16)
+bad = 0
+for i in range(len(reads)):
+    o = ores[i]
+    same = (int(res[i]["status"]) == o.status and cons[i] == ocons[i] and (o.status not in (0, 3) or
+            (int(res[i]["n_sub"]) == o.n_sub and int(res[i]["n_peaks"]) == o.n_peaks)))
+    if not same:
+        bad += 1
+        if bad <= 10:
+            print("MISMATCH read %d len %d strand %s: gpu status %d n_sub %d cons %d | oracle status %d n_sub %d cons %d" % (
+                i, len(reads[i][0]), strands[i], res[i]["status"], res[i]["n_sub"], len(cons[i]), o.status, o.n_sub, len(ocons[i])))
+st = np.bincount(res["status"], minlength=6)
+print("reads %d  mismatches %d  statuses OK/NA/NOPEAK/NOCONS/SHORT/LIMIT = %s" % (len(reads), bad, st.tolist()))
+sys.exit(1 if bad else 0)
