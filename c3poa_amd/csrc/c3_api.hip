@@ -102,6 +102,10 @@ struct DBuf {
 enum { EV_N = 10 };
 struct c3_handle {
   c3_config cfg; std::string err; hipStream_t stream = nullptr; int n_cus = 256; size_t mem_total = 0;
+  // staged (next) batch: copied on its own stream while the resident batch is being processed
+  hipStream_t stream_up = nullptr; hipEvent_t ev_up[2] = {nullptr, nullptr};
+  struct Staged { DBuf d_ascii, d_pk, d_woff, d_qual, d_off, d_strand, d_sid; std::vector<int64_t> off, woff; std::vector<int16_t> sid; std::string strand;
+                  int n = 0; int64_t total = 0, words = 0, maxL = 0; bool pending = false; } st;
   hipEvent_t ev[EV_N];
   // splints
   int n_spl = 0, max_spl = 0; std::vector<int> sp_len; DBuf d_sp_codes, d_sp_len;
@@ -162,6 +166,8 @@ extern "C" int c3_create(const c3_config* cfg, c3_handle** out) {
   h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   h->mem_total = prop.totalGlobalMem;
   if ((e = hipStreamCreate(&h->stream)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  if ((e = hipStreamCreate(&h->stream_up)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  for (int i = 0; i < 2; ++i) if ((e = hipEventCreate(&h->ev_up[i])) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   for (int i = 0; i < EV_N; ++i) if ((e = hipEventCreate(&h->ev[i])) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   memset(&h->tm, 0, sizeof(h->tm));
   *out = h;
@@ -178,6 +184,9 @@ extern "C" void c3_destroy(c3_handle* h) {
                  &h->s_poa_i, &h->s_poa_nk, &h->s_poa_cells, &h->s_poa_b, &h->s_poa_sc, &h->s_poa_desc, &h->s_poa_jump, &h->s_eH, &h->s_eD, &h->s_lw, &h->d_wrec,
                  &h->d_wlay, &h->d_wbase, &h->d_wout, &h->s_win_i, &h->s_win_nk, &h->s_win_h, &h->s_win_d, &h->s_win_b, &h->s_win_sc, &h->s_win_desc, &h->s_zero_d, &h->d_zinfo, &h->d_zflag, &h->d_zwork, &h->d_gather, &h->d_gather_off};
   for (DBuf* b : all) b->release();
+  { DBuf* sh[] = {&h->st.d_ascii, &h->st.d_pk, &h->st.d_woff, &h->st.d_qual, &h->st.d_off, &h->st.d_strand, &h->st.d_sid}; for (DBuf* b : sh) b->release(); }
+  if (h->stream_up) { (void)hipStreamSynchronize(h->stream_up); (void)hipStreamDestroy(h->stream_up); }
+  for (int i = 0; i < 2; ++i) if (h->ev_up[i]) (void)hipEventDestroy(h->ev_up[i]);
   for (int i = 0; i < EV_N; ++i) (void)hipEventDestroy(h->ev[i]);
   (void)hipStreamDestroy(h->stream);
   delete h;
@@ -228,45 +237,80 @@ static C3Params dev_params(const c3_config& c) {
   return p;
 }
 
-extern "C" int c3_batch_upload(c3_handle* h, int n, const char* seqs, const char* quals, const int64_t* off,
-                               const int16_t* splint_id, const char* strand) {
+// Stage the NEXT batch: validation, H2D copies and the 2-bit pack run on a second stream, so they overlap the kernels of
+// the resident batch.  seqs / quals must stay valid until c3_batch_commit returns (page-locked buffers make the copies
+// truly asynchronous); off / splint_id / strand are copied before the call returns.
+extern "C" int c3_batch_stage(c3_handle* h, int n, const char* seqs, const char* quals, const int64_t* off,
+                              const int16_t* splint_id, const char* strand) {
   if (!h || n <= 0 || !seqs || !quals || !off || !strand) return C3_E_ARG;
   if (h->n_spl <= 0) return c3_fail(h, C3_E_STATE, "c3_set_splints must be called first");
+  if (h->st.pending) return c3_fail(h, C3_E_STATE, "a staged batch is waiting for c3_batch_commit");
   HIPCHK(hipSetDevice(h->cfg.device));
-  h->n = n; h->total = off[n] - off[0]; h->off.assign(off, off + n + 1); h->woff.assign(n + 1, 0); h->maxL = 0;
   if (off[0] != 0) return c3_fail(h, C3_E_ARG, "off[0] must be 0");
-  std::vector<int16_t> sid(n, 0);
+  c3_handle::Staged& t = h->st;
+  t.n = n; t.total = off[n] - off[0]; t.off.assign(off, off + n + 1); t.woff.assign(n + 1, 0); t.maxL = 0;
+  t.sid.assign((size_t)n, 0); t.strand.assign(strand, (size_t)n);
   for (int i = 0; i < n; ++i) {
     int64_t L = off[i + 1] - off[i];
     if (L < 0 || L > (1 << 30)) return c3_fail(h, C3_E_ARG, "bad read length");
-    h->maxL = std::max(h->maxL, L);
-    h->woff[i + 1] = h->woff[i] + (L + 15) / 16 + 2;          // +2 words: aligned-window overread
-    if (splint_id) { if (splint_id[i] < 0 || splint_id[i] >= h->n_spl) return c3_fail(h, C3_E_ARG, "splint_id out of range"); sid[i] = splint_id[i]; }
+    t.maxL = std::max(t.maxL, L);
+    t.woff[i + 1] = t.woff[i] + (L + 15) / 16 + 2;          // +2 words: aligned-window overread
+    if (splint_id) { if (splint_id[i] < 0 || splint_id[i] >= h->n_spl) return c3_fail(h, C3_E_ARG, "splint_id out of range"); t.sid[i] = splint_id[i]; }
   }
-  h->words = h->woff[n];
-  const size_t T = (size_t)h->total;
-  HIPCHK(h->d_ascii.ensure(T + 16)); HIPCHK(h->d_pk.ensure(sizeof(uint32_t) * (size_t)h->words + 64));
-  HIPCHK(h->d_qual.ensure(T + 16)); HIPCHK(h->d_off.ensure(sizeof(int64_t) * (n + 1))); HIPCHK(h->d_woff.ensure(sizeof(int64_t) * (n + 1)));
-  HIPCHK(h->d_strand.ensure(n)); HIPCHK(h->d_sid.ensure(sizeof(int16_t) * n)); HIPCHK(h->d_info.ensure(sizeof(C3Info) * (size_t)n));
-  HIPCHK(h->d_counter.ensure(256));
-  HIPCHK(hipEventRecord(h->ev[0], h->stream));
-  HIPCHK(hipMemcpyAsync(h->d_ascii.p, seqs, T, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d_qual.p, quals, T, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d_off.p, h->off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d_woff.p, h->woff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d_strand.p, strand, n, hipMemcpyHostToDevice, h->stream));
-  HIPCHK(hipMemcpyAsync(h->d_sid.p, sid.data(), sizeof(int16_t) * n, hipMemcpyHostToDevice, h->stream));
+  t.words = t.woff[n];
+  const size_t T = (size_t)t.total;
+  HIPCHK(t.d_ascii.ensure(T + 16)); HIPCHK(t.d_pk.ensure(sizeof(uint32_t) * (size_t)t.words + 64));
+  HIPCHK(t.d_qual.ensure(T + 16)); HIPCHK(t.d_off.ensure(sizeof(int64_t) * (n + 1))); HIPCHK(t.d_woff.ensure(sizeof(int64_t) * (n + 1)));
+  HIPCHK(t.d_strand.ensure(n)); HIPCHK(t.d_sid.ensure(sizeof(int16_t) * n));
+  hipStream_t su = h->stream_up;
+  HIPCHK(hipEventRecord(h->ev_up[0], su));
+  HIPCHK(hipMemcpyAsync(t.d_ascii.p, seqs, T, hipMemcpyHostToDevice, su));
+  HIPCHK(hipMemcpyAsync(t.d_qual.p, quals, T, hipMemcpyHostToDevice, su));
+  HIPCHK(hipMemcpyAsync(t.d_off.p, t.off.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, su));
+  HIPCHK(hipMemcpyAsync(t.d_woff.p, t.woff.data(), sizeof(int64_t) * (n + 1), hipMemcpyHostToDevice, su));
+  HIPCHK(hipMemcpyAsync(t.d_strand.p, t.strand.data(), n, hipMemcpyHostToDevice, su));
+  HIPCHK(hipMemcpyAsync(t.d_sid.p, t.sid.data(), sizeof(int16_t) * n, hipMemcpyHostToDevice, su));
   dim3 g((unsigned)std::min((n + 3) / 4, h->n_cus * 32));
-  hipLaunchKernelGGL(k_pack, g, dim3(256), 0, h->stream, h->d_ascii.as<uint8_t>(), h->d_off.as<int64_t>(), h->d_woff.as<int64_t>(), n, h->d_pk.as<uint32_t>());
+  hipLaunchKernelGGL(k_pack, g, dim3(256), 0, su, t.d_ascii.as<uint8_t>(), t.d_off.as<int64_t>(), t.d_woff.as<int64_t>(), n, t.d_pk.as<uint32_t>());
+  HIPCHK(hipEventRecord(h->ev_up[1], su));
+  HIPCHK(hipGetLastError());
+  t.pending = true;
+  return C3_E_OK;
+}
+
+// Make the staged batch the resident one (after the results of the previous batch have been fetched).
+extern "C" int c3_batch_commit(c3_handle* h) {
+  if (!h) return C3_E_ARG;
+  if (!h->st.pending) return c3_fail(h, C3_E_STATE, "no staged batch");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  HIPCHK(hipStreamSynchronize(h->stream));            // the previous batch is completely done
+  HIPCHK(hipStreamSynchronize(h->stream_up));         // the staged copies and the pack have landed
+  c3_handle::Staged& t = h->st;
+  std::swap(h->d_ascii, t.d_ascii); std::swap(h->d_pk, t.d_pk); std::swap(h->d_woff, t.d_woff); std::swap(h->d_qual, t.d_qual);
+  std::swap(h->d_off, t.d_off); std::swap(h->d_strand, t.d_strand); std::swap(h->d_sid, t.d_sid);
+  h->off.swap(t.off); h->woff.swap(t.woff);
+  h->n = t.n; h->total = t.total; h->words = t.words; h->maxL = t.maxL;
+  t.pending = false;
+  const int n = h->n;
+  HIPCHK(h->d_info.ensure(sizeof(C3Info) * (size_t)n));
+  HIPCHK(h->d_counter.ensure(256));
   HIPCHK(hipMemsetAsync(h->d_info.p, 0, sizeof(C3Info) * (size_t)n, h->stream));   // the unused tails of peaks[] / sub_*[] read as 0
   hipLaunchKernelGGL(k_init_info, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), n);
-  HIPCHK(hipEventRecord(h->ev[1], h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
-  float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev[0], h->ev[1]));
+  float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev_up[0], h->ev_up[1]));
   memset(&h->tm, 0, sizeof(h->tm)); h->tm.ms_pack = ms; h->tm.n_reads = n; h->tm.n_bases = h->total;
   h->stages_done = 0; h->injected = false; h->n_windows = 0;
   return C3_E_OK;
+}
+
+// upload = stage + commit (nothing to overlap with)
+extern "C" int c3_batch_upload(c3_handle* h, int n, const char* seqs, const char* quals, const int64_t* off,
+                               const int16_t* splint_id, const char* strand) {
+  if (h && h->st.pending) { (void)hipStreamSynchronize(h->stream_up); h->st.pending = false; }     // an abandoned staged batch is dropped
+  int rc = c3_batch_stage(h, n, seqs, quals, off, splint_id, strand);
+  if (rc != C3_E_OK) return rc;
+  return c3_batch_commit(h);
 }
 
 static int auto_slots(c3_handle* h, int want, size_t per_slot_bytes, int n_items, int waves_per_cu) {

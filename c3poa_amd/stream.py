@@ -106,33 +106,72 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None):
             parsed.put(None)
 
     def device_thread(dev):                         # one per GPU: c3_batch_run sizes its stages on the host, so it blocks
+        saw_end = [False]                           # this thread's end-of-input sentinel has been taken from the queue
+
+        def take(block=True):
+            item = parsed.get() if block else parsed.get_nowait()
+            if item is None:
+                saw_end[0] = True
+            return item
+
         try:
             h = _lib.Handle(device=dev, mdistcutoff=args.mdistcutoff, zero=1 if getattr(args, "zero", True) else 0)
             h.set_splints([splint_dict[n][0] for n in splint_names])
-            while True:
-                item = parsed.get()
-                if item is None:
-                    break
-                if errors:
-                    continue
-                hb, sid, st = item
+            # software pipeline on one handle: while batch i runs, batch i+1 (if the reader already has it) is copied
+            # and 2-bit packed on the handle's second stream (c3_batch_stage); c3_batch_commit makes it resident once
+            # the results of batch i have been fetched
+            cur = take()
+            if cur is not None and not errors:
                 t0 = time.perf_counter()
-                h.upload_host(hb, st, np.maximum(sid, 0))
+                h.upload_host(cur[0], cur[2], np.maximum(cur[1], 0))
+                with lock:
+                    t["upload"] += time.perf_counter() - t0
+            done = cur is None
+            while not done and not errors:
+                hb, sid, st = cur
+                nxt, staged = None, False
+                try:
+                    nxt = take(False)
+                    if nxt is not None:
+                        t0 = time.perf_counter()
+                        h.stage_host(nxt[0], nxt[2], np.maximum(nxt[1], 0))
+                        staged = True
+                        with lock:
+                            t["upload"] += time.perf_counter() - t0
+                    else:
+                        done = True
+                except queue.Empty:
+                    pass
                 t1 = time.perf_counter()
-                up_dev = h.timing()["ms_pack"] * 1e-3
                 h.run()
                 t2 = time.perf_counter()
+                up_dev = h.timing()["ms_pack"] * 1e-3
+                run_dev = h.timing()["ms_total"] * 1e-3
                 res, buf, coff = h.results_raw()
                 t3 = time.perf_counter()
                 with lock:
-                    t["upload_dev"] += up_dev; t["run_dev"] += h.timing()["ms_total"] * 1e-3
-                    t["upload"] += t1 - t0; t["run"] += t2 - t1; t["fetch"] += t3 - t2
+                    t["upload_dev"] += up_dev; t["run_dev"] += run_dev
+                    t["run"] += t2 - t1; t["fetch"] += t3 - t2
                 to_write.put((hb, sid, res, buf, coff))
+                if done:
+                    break
+                if nxt is None:                                   # the reader was not ahead: wait for it now
+                    nxt = take()
+                    if nxt is None:
+                        break
+                t0 = time.perf_counter()
+                if staged:
+                    h.commit()
+                else:
+                    h.upload_host(nxt[0], nxt[2], np.maximum(nxt[1], 0))
+                with lock:
+                    t["upload"] += time.perf_counter() - t0
+                cur = nxt
             h.close()
         except Exception as e:                      # noqa: BLE001
             errors.append(e)
-            while parsed.get() is not None:
-                pass
+        while not saw_end[0]:                       # keep draining so the reader never blocks on a full queue
+            take()
         to_write.put(None)
 
     def writer_thread():                            # c3_write_group releases the GIL: overlaps parsing and the GPUs

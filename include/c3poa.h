@@ -102,6 +102,13 @@ int c3_set_splints(c3_handle* h, int n, const char* cat, const int64_t* off);
 int c3_batch_upload(c3_handle* h, int n, const char* seqs, const char* quals, const int64_t* off,
                     const int16_t* splint_id, const char* strand);
 
+/* double buffering: c3_batch_stage copies (and 2-bit packs) the NEXT batch on a second stream while the resident batch
+ * is being processed; c3_batch_commit makes it resident once the results of the previous batch have been fetched.
+ * seqs / quals must stay valid until c3_batch_commit returns; c3_batch_upload = stage + commit. */
+int c3_batch_stage(c3_handle* h, int n, const char* seqs, const char* quals, const int64_t* off,
+                   const int16_t* splint_id, const char* strand);
+int c3_batch_commit(c3_handle* h);
+
 /* run the resident batch through the hot path (asynchronous on the library's stream).
  * stages: bit0 conk, bit1 peaks+split, bit2 POA/draft, bit3 polish.  C3_STAGES_ALL = whole path
  * = one call of analyze_reads (C3POa.py:110-173) minus file I/O. */

@@ -398,3 +398,40 @@ def test_abi_error_paths_return_codes_not_crashes():
     assert lib.c3_scan_adapters(hp, None) < 0 and lib.c3_match_index_batch(hp, 0, None, None, 2, None, None, None) < 0
     assert lib.c3_pairwise_consensus(hp, b"AC-T", b"ACGT", 4, b"ACT", 2, b"III", b"ACGT", 4, b"IIII", C.create_string_buffer(8), 8, C.byref(C.c_int())) == -3
     h.close()
+
+
+def test_staged_upload_pipeline_equals_plain_upload(tmp_path):
+    """c3_batch_stage / c3_batch_commit (next batch copied on a second stream while the resident one runs) give the
+    results of plain uploads, batch after batch; misuse returns C3_E_STATE"""
+    from c3poa_amd import _lib
+    recs = list(synth.generate("cfg1", n_reads=48))
+    fq = str(tmp_path / "r.fastq")
+    with open(fq, "w") as fh:
+        for r in recs:
+            fh.write("@%s\n%s\n+\n%s\n" % (r[0], r[1], r[2]))
+    strand_of = {r[0]: r[3] for r in recs}
+
+    def plain(h, batch):
+        h.upload([r[1] for r in batch], [r[2] for r in batch], [r[3] for r in batch])
+        h.run()
+        return h.results()[1]
+
+    h = _lib.Handle(); h.set_splints([synth.SPLINT1])
+    want = [plain(h, recs[i:i + 16]) for i in range(0, 48, 16)]
+    assert h.lib.c3_batch_commit(h.h) == -5                                   # nothing staged
+    rd = _lib.Reader(fq, n_sets=3)
+    hbs = [rd.next(16) for _ in range(3)]
+    st = [bytes(ord(strand_of[n]) for n in hb.names()) for hb in hbs]
+    sid = np.zeros(16, dtype=np.int16)
+    got = []
+    h.upload_host(hbs[0], st[0], sid)
+    for k in range(3):
+        if k + 1 < 3:
+            h.stage_host(hbs[k + 1], st[k + 1], sid)                           # overlaps the run below
+            assert h.lib.c3_batch_stage(h.h, 16, hbs[k].c.seqs, hbs[k].c.quals, hbs[k].c.off, sid.ctypes.data, st[k]) == -5   # one at a time
+        h.run()
+        got.append(h.results()[1])
+        if k + 1 < 3:
+            h.commit()
+    assert got == want
+    h.close()
