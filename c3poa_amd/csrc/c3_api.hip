@@ -161,6 +161,9 @@ extern "C" int c3_create(const c3_config* cfg, c3_handle** out) {
   c3_handle* h = new c3_handle();
   h->cfg = *cfg;
   if ((e = hipSetDevice(cfg->device)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  // synchronisation points sleep instead of spinning: the stages are milliseconds long, and a spinning waiter per
+  // handle eats the CPU quota the reader / writer threads need (refused once the context exists: ignored)
+  (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError();
   hipDeviceProp_t prop;
   if ((e = hipGetDeviceProperties(&prop, cfg->device)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   h->n_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;

@@ -84,7 +84,8 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None):
     rd = _lib.Reader(args.reads, n_sets=n_sets)
     tokens = threading.Semaphore(n_sets - 1)        # a buffer set is reused only after its group has been written
     parsed, to_write = queue.Queue(maxsize=n_work), queue.Queue(maxsize=n_work)
-    t = dict(parse=0.0, assign=0.0, upload=0.0, upload_dev=0.0, run=0.0, run_dev=0.0, fetch=0.0, write=0.0, reads=0, batches=0)
+    t = dict(parse=0.0, assign=0.0, upload=0.0, upload_dev=0.0, run=0.0, run_dev=0.0, fetch=0.0, write=0.0, wait_in=0.0, wait_out=0.0,
+             setup=0.0, close=0.0, reads=0, batches=0)
     errors, lock = [], threading.Lock()
 
     def reader_thread():                            # parse + splint/strand lookup, ahead of the GPUs
@@ -109,14 +110,22 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None):
         saw_end = [False]                           # this thread's end-of-input sentinel has been taken from the queue
 
         def take(block=True):
-            item = parsed.get() if block else parsed.get_nowait()
+            tw = time.perf_counter()
+            try:
+                item = parsed.get() if block else parsed.get_nowait()
+            finally:
+                with lock:
+                    t["wait_in"] += time.perf_counter() - tw
             if item is None:
                 saw_end[0] = True
             return item
 
         try:
+            ts = time.perf_counter()
             h = _lib.Handle(device=dev, mdistcutoff=args.mdistcutoff, zero=1 if getattr(args, "zero", True) else 0)
             h.set_splints([splint_dict[n][0] for n in splint_names])
+            with lock:
+                t["setup"] += time.perf_counter() - ts
             # software pipeline on one handle: while batch i runs, batch i+1 (if the reader already has it) is copied
             # and 2-bit packed on the handle's second stream (c3_batch_stage); c3_batch_commit makes it resident once
             # the results of batch i have been fetched
@@ -152,7 +161,10 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None):
                 with lock:
                     t["upload_dev"] += up_dev; t["run_dev"] += run_dev
                     t["run"] += t2 - t1; t["fetch"] += t3 - t2
+                tw = time.perf_counter()
                 to_write.put((hb, sid, res, buf, coff))
+                with lock:
+                    t["wait_out"] += time.perf_counter() - tw
                 if done:
                     break
                 if nxt is None:                                   # the reader was not ahead: wait for it now
@@ -167,7 +179,10 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None):
                 with lock:
                     t["upload"] += time.perf_counter() - t0
                 cur = nxt
+            tc = time.perf_counter()
             h.close()
+            with lock:
+                t["close"] += time.perf_counter() - tc
         except Exception as e:                      # noqa: BLE001
             errors.append(e)
         while not saw_end[0]:                       # keep draining so the reader never blocks on a full queue
