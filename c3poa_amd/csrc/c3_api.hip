@@ -82,7 +82,10 @@ __global__ void k_summary(const C3Info* info, const int64_t* off, int n, Summary
   out[i] = s;
 }
 
-#define DBG(...) do { if (getenv("C3_DEBUG")) { fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
+#include <chrono>
+static inline double dbg_now_ms() { using namespace std::chrono; return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count(); }
+// C3_DEBUG=1: progress lines on stderr, each stamped with the host clock (ms) -- shows the host gaps between the stages
+#define DBG(...) do { if (getenv("C3_DEBUG")) { fprintf(stderr, "[c3 %.3f] ", dbg_now_ms()); fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
 
 // ---- handle -----------------------------------------------------------------------------
 struct DBuf {
@@ -572,6 +575,7 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
   int rc;
   float ms;
   hipEvent_t t0 = h->ev[0], t1 = h->ev[1], t2 = h->ev[2], t3 = h->ev[3], t4 = h->ev[4];
+  DBG("run: start n=%d\n", h->n);
   HIPCHK(hipEventRecord(t0, h->stream));
   if (stages & C3_STAGE_CONK) { if ((rc = run_conk(h))) return rc; h->tm.cells_conk = 0; for (int i = 0; i < h->n; ++i) h->tm.cells_conk += (h->off[i + 1] - h->off[i]) * (int64_t)h->max_spl; }
   HIPCHK(hipEventRecord(t1, h->stream));
@@ -579,7 +583,9 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
   HIPCHK(hipEventRecord(t2, h->stream));
   float ms_prep = 0, ms_win = 0, ms_st = 0;
   if (stages & (C3_STAGE_POA | C3_STAGE_POLISH)) {
+    DBG("run: conk+peaks launched\n");
     if ((rc = fetch_summary(h))) return rc;
+    DBG("run: work list ready (%zu reads)\n", h->work.size());
     HIPCHK(hipEventRecord(t3, h->stream));
     if (stages & C3_STAGE_POA) {
       if ((rc = run_poa(h))) return rc;
@@ -590,11 +596,13 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
       HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 64, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       if (!h->work.empty()) h->tm.cells_poa = *(long long*)(cnt + 2);
+      DBG("run: poa done\n");
       HIPCHK(hipEventElapsedTime(&ms, t3, t4)); h->tm.ms_poa = ms;
     }
     if (stages & C3_STAGE_POLISH) { if ((rc = run_polish(h, &ms_prep, &ms_win, &ms_st))) return rc; }
   }
   HIPCHK(hipStreamSynchronize(h->stream));
+  DBG("run: done\n");
   HIPCHK(hipGetLastError());
   if (stages & C3_STAGE_CONK) { HIPCHK(hipEventElapsedTime(&ms, t0, t1)); h->tm.ms_conk = ms; }
   if (stages & C3_STAGE_PEAKS) { HIPCHK(hipEventElapsedTime(&ms, t1, t2)); h->tm.ms_peaks = ms; }
