@@ -21,7 +21,7 @@ EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_create", "c
            "c3_call_peaks", "c3_poa_msa", "c3_pairwise_consensus", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
            "c3_reader_open", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_write_group",
            "c3_scan_adapters", "c3_match_index", "c3_match_index_batch",
-           "c3_assign_open", "c3_assign_close", "c3_assign_batch", "c3_assign_seen"]
+           "c3_assign_open", "c3_assign_close", "c3_assign_batch", "c3_assign_seen", "c3_write_splint_psl"]
 
 
 class Config(C.Structure):
@@ -104,6 +104,7 @@ def load():
     lib.c3_assign_close.restype = None
     lib.c3_assign_batch.argtypes = [vp, C.POINTER(HostBatchStruct), vp, vp]
     lib.c3_assign_seen.argtypes = [vp, vp, vp]
+    lib.c3_write_splint_psl.argtypes = [C.POINTER(HostBatchStruct), vp, vp, vp, C.c_int, C.POINTER(cp), vp, C.c_int, cp, vp]
     lib.c3_reader_open.argtypes = [cp, C.c_int, C.POINTER(vp)]
     lib.c3_reader_close.argtypes = [vp]
     lib.c3_reader_close.restype = None
@@ -445,6 +446,22 @@ class Reader:
             self.close()
         except Exception:
             pass
+
+
+def write_splint_psl(hb, table, splint_id, strand, splint_names, splint_lens, match, path):
+    """c3_write_splint_psl: PSL rows of the assigned reads of one group, appended to `path`; returns the row count"""
+    lib = load()
+    names = (C.c_char_p * len(splint_names))(*[_b(n) for n in splint_names])
+    lens = np.ascontiguousarray(splint_lens, dtype=np.int32)
+    tab = np.ascontiguousarray(table, dtype=np.int32)
+    sid = np.ascontiguousarray(splint_id, dtype=np.int16)
+    st = np.frombuffer(_b(strand), dtype=np.uint8)
+    rows = C.c_int64(0)
+    rc = lib.c3_write_splint_psl(C.byref(hb.c), tab.ctypes.data, sid.ctypes.data, st.ctypes.data, len(splint_names), names,
+                                 lens.ctypes.data, int(match), _b(str(path)), C.byref(rows))
+    if rc != 0:
+        raise OSError("c3_write_splint_psl failed (%d)" % rc)
+    return int(rows.value)
 
 
 class Assigner:

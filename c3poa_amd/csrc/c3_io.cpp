@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <climits>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -459,5 +460,49 @@ extern "C" int c3_assign_seen(const c3_assign* a, uint8_t* flags, int64_t* rows_
   if (!a || !flags) return C3_E_ARG;
   memcpy(flags, a->seen.data(), a->seen.size());
   if (rows_kept) *rows_kept = a->rows_kept;
+  return C3_E_OK;
+}
+
+// ---- PSL rows of the GPU splint finder (c3_scan_splints) written natively ------------------------------------------
+// One 21-column row per assigned read of the group, appended to `path`: col 0 = equivalent perfect-match length m of the
+// track maximum (match*m*(m+1)/2 = max, capped at the splint length), col 5 = 0, strand, read name, read length, query
+// span, splint name / length -- the row psl_row() of c3poa_amd/preprocess.py states in Python.
+extern "C" int c3_write_splint_psl(const c3_host_batch* b, const int32_t* table, const int16_t* splint_id, const char* strand,
+                                   int n_splints, const char* const* splint_names, const int32_t* splint_lens, int match,
+                                   const char* path, int64_t* rows_written) {
+  if (!b || !table || !splint_id || !strand || n_splints <= 0 || !splint_names || !splint_lens || match <= 0 || !path) return C3_E_ARG;
+  std::string out;
+  out.reserve((size_t)b->n * 96);
+  int64_t rows = 0;
+  char tmp[256];
+  for (int i = 0; i < b->n; ++i) {
+    const int s = splint_id[i];
+    if (s < 0 || s >= n_splints) continue;
+    const int rc = strand[i] == '-' ? 1 : 0;
+    const int32_t* e = table + (((size_t)i * n_splints + s) * 2 + rc) * 4;
+    const long long L = b->off[i + 1] - b->off[i];
+    const int S = splint_lens[s];
+    const long long score = e[0] > 0 ? e[0] : 0;
+    long long m = (long long)((std::sqrt(1.0 + 8.0 * (double)score / (double)match) - 1.0) / 2.0);
+    if (m > S) m = S;
+    long long q0 = e[1]; if (q0 < 0) q0 = 0; if (q0 > L) q0 = L;
+    long long q1 = q0 + S; if (q1 > L) q1 = L;
+    int k = snprintf(tmp, sizeof(tmp), "%lld\t%lld\t0\t0\t0\t0\t0\t0\t%c\t", m, (long long)S - m, rc ? '-' : '+');
+    out.append(tmp, (size_t)k);
+    out.append(b->names + b->name_off[i], (size_t)(b->name_off[i + 1] - b->name_off[i]));
+    k = snprintf(tmp, sizeof(tmp), "\t%lld\t%lld\t%lld\t", L, q0, q1);
+    out.append(tmp, (size_t)k);
+    out.append(splint_names[s]);
+    k = snprintf(tmp, sizeof(tmp), "\t%d\t0\t%d\t1\t%d,\t%lld,\t0,\n", S, S, S, q0);
+    out.append(tmp, (size_t)k);
+    ++rows;
+  }
+  if (!out.empty()) {
+    FILE* f = fopen(path, "ab");
+    if (!f) return C3_E_ARG;
+    size_t w = fwrite(out.data(), 1, out.size(), f);
+    if (fclose(f) != 0 || w != out.size()) return C3_E_ARG;
+  }
+  if (rows_written) *rows_written = rows;
   return C3_E_OK;
 }

@@ -63,29 +63,16 @@ def gpu_find_splints(args, align_psl, batch_reads=131072, handle=None):
     h.set_splints([s[1] for s in splints])
     rd = _lib.Reader(args.reads, n_sets=1)
     n_rows = 0
-    with open(align_psl + ".part", "w") as out:
-        while True:
-            hb = rd.next(batch_reads, args.lencutoff, 1 << 30)
-            if hb.n == 0:
-                break
-            h.upload_host(hb, b"?" * hb.n, np.zeros(hb.n, dtype=np.int16))
-            tab, sid, st = h.scan_splints()
-            names, lens = hb.names(), np.diff(hb.off)
-            # vectorised PSL fields (psl_row is the scalar statement of the same row)
-            acc = np.nonzero(sid >= 0)[0]
-            k = sid[acc].astype(np.int64)
-            rc = (np.frombuffer(st, dtype=np.uint8)[acc] == 45).astype(np.int64)
-            e = tab[acc, k, rc]
-            slen = np.array([len(s[1]) for s in splints], dtype=np.int64)[k]
-            m = np.minimum(((np.sqrt(1.0 + 8.0 * np.maximum(e[:, 0], 0) / h.cfg.conk_match) - 1.0) / 2.0).astype(np.int64), slen)
-            q0 = np.clip(e[:, 1].astype(np.int64), 0, lens[acc])
-            q1 = np.minimum(lens[acc], q0 + slen)
-            rows = ["%d\t%d\t0\t0\t0\t0\t0\t0\t%s\t%s\t%d\t%d\t%d\t%s\t%d\t0\t%d\t1\t%d,\t%d,\t0," %
-                    (m[x], slen[x] - m[x], "-" if rc[x] else "+", names[i], lens[i], q0[x], q1[x], splints[k[x]][0], slen[x], slen[x], slen[x], q0[x])
-                    for x, i in enumerate(acc.tolist())]
-            if rows:
-                out.write("\n".join(rows) + "\n")
-            n_rows += len(rows)
+    open(align_psl + ".part", "w").close()
+    names_s, lens_s = [s[0] for s in splints], [len(s[1]) for s in splints]
+    while True:
+        hb = rd.next(batch_reads, args.lencutoff, 1 << 30)
+        if hb.n == 0:
+            break
+        h.upload_host(hb, b"?" * hb.n, np.zeros(hb.n, dtype=np.int16))
+        tab, sid, st = h.scan_splints()
+        # rows formatted natively (c3_write_splint_psl); psl_row() above is the scalar statement of the same row
+        n_rows += _lib.write_splint_psl(hb, tab, sid, st, names_s, lens_s, h.cfg.conk_match, align_psl + ".part")
     rd.close()
     os.replace(align_psl + ".part", align_psl)
     if handle is None:

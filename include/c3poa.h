@@ -225,6 +225,12 @@ int c3_assign_batch(const c3_assign* a, const c3_host_batch* b, int16_t* splint_
 /* adapter_set (bin/preprocess.py:34,43): flags[s] = 1 when a counted row names splint s; *rows_kept = counted rows */
 int c3_assign_seen(const c3_assign* a, uint8_t* flags, int64_t* rows_kept);
 
+/* PSL rows of the GPU splint finder, appended to `path` (one 21-column row per assigned read of the group; table /
+ * splint_id / strand as returned by c3_scan_splints; the row format is stated by psl_row() in c3poa_amd/preprocess.py) */
+int c3_write_splint_psl(const c3_host_batch* b, const int32_t* table, const int16_t* splint_id, const char* strand,
+                        int n_splints, const char* const* splint_names, const int32_t* splint_lens, int match,
+                        const char* path, int64_t* rows_written);
+
 /* match_index for a whole batch on the GPU (one lane per piece): pieces = n slots of 64 bytes, lens[n] <= 64, at most
  * 16 indexes of at most 32 bases; out[i] = winning index number or -1.  Same function as c3_match_index below. */
 int c3_match_index_batch(c3_handle* h, int n, const char* pieces, const int32_t* lens, int n_idx,

@@ -236,3 +236,33 @@ def test_native_assignment_matches_python_psl_parse(tmp_path):
     seen, kept = asg.seen()
     assert seen == aset and kept == sum(1 for r in rows if "NotInFile" not in r and float(r.split("\t")[0]) > 50 and float(r.split("\t")[5]) < 50)
     asg.close()
+
+
+def test_native_splint_psl_rows_match_python_statement(tmp_path):
+    """c3_write_splint_psl writes, for every assigned read, exactly the row psl_row() states (perfect squares included)"""
+    from c3poa_amd import preprocess
+    rng = np.random.default_rng(13)
+    n = 300
+    recs = [("read_%d" % i, "ACGT" * int(rng.integers(3, 40)), None) for i in range(n)]
+    recs = [(a, b, "I" * len(b)) for a, b, _ in recs]
+    fq = str(tmp_path / "r.fastq")
+    _write_fastq(fq, recs)
+    hb = _lib.Reader(fq).next(1000)
+    splints = [("SpA", 284), ("SpB", 97), ("SpC", 333)]
+    tab = np.zeros((n, 3, 2, 4), dtype=np.int32)
+    tab[..., 0] = rng.integers(0, 200000, (n, 3, 2))
+    tab[..., 1] = rng.integers(-5, 200, (n, 3, 2))
+    for k, m in enumerate((50, 51, 52, 100, 283, 284, 285, 400)):         # scores that are exactly match*m*(m+1)/2
+        tab[k, :, :, 0] = 5 * m * (m + 1) // 2
+    sid = rng.integers(-1, 3, n).astype(np.int16)
+    st = bytes(rng.choice([43, 45], n).astype(np.uint8))
+    psl = str(tmp_path / "f.psl")
+    rows = _lib.write_splint_psl(hb, tab, sid, st, [s[0] for s in splints], [s[1] for s in splints], 5, psl)
+    rows += _lib.write_splint_psl(hb, tab, sid, st, [s[0] for s in splints], [s[1] for s in splints], 5, psl)      # appends
+    want = []
+    for i in range(n):
+        if sid[i] < 0:
+            continue
+        e = tab[i, sid[i], 1 if st[i] == 45 else 0]
+        want.append(preprocess.psl_row(recs[i][0], len(recs[i][1]), splints[sid[i]][0], splints[sid[i]][1], chr(st[i]), e[0], e[1], 5))
+    assert open(psl).read().splitlines() == want + want and rows == 2 * len(want) and len(want) > 100
