@@ -104,35 +104,46 @@ def main(args):
     splint_dict = {}
     for splint in fastx_read(args.splint_file):
         splint_dict[splint[0]] = [splint[1], revcomp(splint[1])]
-    # splint / strand per read from the PSL (bin/preprocess.py:12-45).  The PSL is reused when it exists, otherwise
-    # written by the GPU finder (or blat); it is then held in a native name -> (splint, strand) table, and the first
-    # pass over the reads (C3POa.py:200-207) only counts: no Python object per read.
-    assigner = _lib.Assigner(ensure_psl(blat, args, tmp_dir), sorted(splint_dict))
-    t_main.append(time.perf_counter())
-    total_reads, short_reads, no_splint = stream.count_reads(args.reads, args.lencutoff, assigner)
-    adapter_set, _rows = assigner.seen()
-    for adapter in adapter_set:
-        os.makedirs(args.out_path + adapter, exist_ok=True)
-    t_main.append(time.perf_counter())
+    n_dev = max(1, min(max(1, args.numThreads), _lib.device_count()))        # -n = GPUs that share the groups
+    align_psl = tmp_dir + "splint_to_read_alignments.psl"
+    have_psl = os.path.exists(align_psl) and os.stat(align_psl).st_size > 0
+    if not have_psl and getattr(args, "splint_finder", "gpu") == "gpu":
+        # no PSL yet: ONE pass over the reads -- every batch is scored against all splints on both strands on the GPU,
+        # assigned, processed; the PSL (written on the way) makes a rerun take the route below
+        print("Assigning splints to reads on the GPU", file=sys.stderr)
+        st = {}
+        stream.run(args, splint_dict, None, None, n_dev, stats=st, finder_psl=align_psl)
+        total_reads, short_reads, no_splint = st["reads"], st["short"], st["reads"] - st["assigned"]
+        t_main += [time.perf_counter()] * 3
+    else:
+        # splint / strand per read from the PSL (bin/preprocess.py:12-45).  The PSL is reused when it exists (or written by
+        # blat); it is held in a native name -> (splint, strand) table, and the first pass over the reads
+        # (C3POa.py:200-207) only counts: no Python object per read.
+        assigner = _lib.Assigner(ensure_psl(blat, args, tmp_dir), sorted(splint_dict))
+        t_main.append(time.perf_counter())
+        total_reads, short_reads, no_splint = stream.count_reads(args.reads, args.lencutoff, assigner)
+        adapter_set, _rows = assigner.seen()
+        for adapter in adapter_set:
+            os.makedirs(args.out_path + adapter, exist_ok=True)
+        t_main.append(time.perf_counter())
+        # streaming pipeline: native reader -> GPU batches -> native writer (c3poa_amd/stream.py); the tail group is
+        # processed too (deliberate fix of SURVEY.md App. A.12)
+        stream.run(args, splint_dict, assigner, adapter_set, n_dev)
+        assigner.close()
+        t_main.append(time.perf_counter())
 
     all_reads = total_reads + short_reads
     print("C3POa version:", VERSION, file=log_file)
     print("Total reads:", all_reads, file=log_file)
-    print("No splint reads:", no_splint, "({:.2f}%)".format((no_splint / all_reads) * 100), file=log_file)
-    print("Under len cutoff:", short_reads, "({:.2f}%)".format((short_reads / all_reads) * 100), file=log_file)
-    print("Total thrown away reads:", short_reads + no_splint,
-          "({:.2f}%)".format(((short_reads + no_splint) / all_reads) * 100), file=log_file)
+    if all_reads:
+        print("No splint reads:", no_splint, "({:.2f}%)".format((no_splint / all_reads) * 100), file=log_file)
+        print("Under len cutoff:", short_reads, "({:.2f}%)".format((short_reads / all_reads) * 100), file=log_file)
+        print("Total thrown away reads:", short_reads + no_splint,
+              "({:.2f}%)".format(((short_reads + no_splint) / all_reads) * 100), file=log_file)
     print("Reads after preprocessing:", all_reads - (short_reads + no_splint), file=log_file)
     log_file.close()
-
-    n_dev = max(1, min(max(1, args.numThreads), _lib.device_count()))        # -n = GPUs that share the groups
-    # streaming pipeline: native reader -> GPU batches -> native writer (c3poa_amd/stream.py); the tail group is
-    # processed too (deliberate fix of SURVEY.md App. A.12)
-    stream.run(args, splint_dict, assigner, adapter_set, n_dev)
-    assigner.close()
     if os.environ.get("C3_STREAM_STATS"):
-        t_main.append(time.perf_counter())
-        print("main: psl=%.3f count=%.3f consensus=%.3f" % tuple(b - a for a, b in zip(t_main, t_main[1:])), file=sys.stderr)
+        print("main: psl=%.3f count=%.3f consensus=%.3f" % tuple(b - a for a, b in zip(t_main, t_main[1:4])), file=sys.stderr)
 
 
 if __name__ == "__main__":

@@ -16,7 +16,7 @@ STAGE_CONK, STAGE_PEAKS, STAGE_POA, STAGE_POLISH, STAGES_ALL = 1, 2, 4, 8, 15
 ST_OK, ST_NOT_ASSIGNED, ST_NO_PEAKS, ST_NO_CONSENSUS, ST_TOO_SHORT, ST_LIMIT = range(6)
 
 EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_create", "c3_destroy", "c3_last_error", "c3_set_splints",
-           "c3_batch_upload", "c3_batch_stage", "c3_batch_commit", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_timing",
+           "c3_batch_upload", "c3_batch_stage", "c3_batch_commit", "c3_batch_assign", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_timing",
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
            "c3_call_peaks", "c3_poa_msa", "c3_pairwise_consensus", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
            "c3_reader_open", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_write_group",
@@ -82,6 +82,7 @@ def load():
     lib.c3_batch_upload.argtypes = [vp, C.c_int, vp, vp, i64p, vp, vp]
     lib.c3_batch_stage.argtypes = [vp, C.c_int, vp, vp, i64p, vp, vp]
     lib.c3_batch_commit.argtypes = [vp]
+    lib.c3_batch_assign.argtypes = [vp, vp, vp]
     lib.c3_batch_run.argtypes = [vp, C.c_int]
     lib.c3_batch_sync.argtypes = [vp]
     lib.c3_batch_results.argtypes = [vp, vp, vp, C.c_int64, i64p]
@@ -224,6 +225,13 @@ class Handle:
         self._chk(self.lib.c3_batch_commit(self.h))
         self.n, self.off, _keep = self._staged
         self._staged = None
+
+    def assign(self, splint_ids, strands):
+        """c3_batch_assign: splint row / strand of the resident batch (e.g. from scan_splints)"""
+        sid = np.ascontiguousarray(splint_ids, dtype=np.int16)
+        st = np.frombuffer(_b(strands), dtype=np.uint8)
+        assert len(sid) == len(st) == self.n
+        self._chk(self.lib.c3_batch_assign(self.h, sid.ctypes.data, st.ctypes.data))
 
     def run(self, stages=STAGES_ALL):
         self._chk(self.lib.c3_batch_run(self.h, stages))

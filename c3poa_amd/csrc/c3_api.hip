@@ -310,6 +310,24 @@ extern "C" int c3_batch_commit(c3_handle* h) {
   return C3_E_OK;
 }
 
+// Overwrite the splint row / strand of every read of the resident batch (after c3_scan_splints, before c3_batch_run):
+// strand[i] = '+' / '-', anything else = not assigned; splint_id[i] < 0 is stored as 0 for such reads.
+extern "C" int c3_batch_assign(c3_handle* h, const int16_t* splint_id, const char* strand) {
+  if (!h || h->n <= 0 || !splint_id || !strand) return C3_E_ARG;
+  HIPCHK(hipSetDevice(h->cfg.device));
+  std::vector<int16_t> sid((size_t)h->n);
+  for (int i = 0; i < h->n; ++i) {
+    const bool on = strand[i] == '+' || strand[i] == '-';
+    if (on && (splint_id[i] < 0 || splint_id[i] >= h->n_spl)) return c3_fail(h, C3_E_ARG, "splint_id out of range");
+    sid[(size_t)i] = on ? splint_id[i] : (int16_t)0;
+  }
+  HIPCHK(hipMemcpyAsync(h->d_strand.p, strand, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipMemcpyAsync(h->d_sid.p, sid.data(), sizeof(int16_t) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->stages_done = 0;
+  return C3_E_OK;
+}
+
 // upload = stage + commit (nothing to overlap with)
 extern "C" int c3_batch_upload(c3_handle* h, int n, const char* seqs, const char* quals, const int64_t* off,
                                const int16_t* splint_id, const char* strand) {

@@ -59,16 +59,23 @@ class DictAssigner:
         return sid, bytes(st), k
 
 
-def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None):
+def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, finder_psl=None):
     """the second pass of C3POa.py:236-271.  assigner: _lib.Assigner (native PSL table) or an adapter_dict.
-    returns the number of reads sent to the GPUs."""
+    assigner=None is the fused mode: no PSL exists yet, so every batch is first scored against all splints on both
+    strands (c3_scan_splints), assigned on the device (c3_batch_assign) and its PSL rows appended to finder_psl -- one pass
+    over the reads instead of finder pass + counting pass + consensus pass.  returns the number of reads sent to the GPUs."""
     splint_names = sorted(splint_dict)
     if isinstance(assigner, dict):
         assigner = DictAssigner(assigner, splint_names)
     compress = bool(getattr(args, "compress_output", False))
     cons_paths = [args.out_path + n + "/R2C2_Consensus.fasta" for n in splint_names]
     sub_paths = [args.out_path + n + "/R2C2_Subreads.fastq" for n in splint_names]
+    fused = assigner is None
     used = set(adapter_set or ())                                             # cat_files runs per adapter_set entry (C3POa.py:259)
+    if fused:
+        used = set(splint_names)                    # not known yet: directories of splints nobody used are removed at the end
+        open(finder_psl + ".part", "w").close()
+        sp_lens = [len(splint_dict[n][0]) for n in splint_names]
     if isinstance(assigner, DictAssigner):
         used |= set(v[0] for v in assigner.d.values())
     for n, cp, sp in zip(splint_names, cons_paths, sub_paths):
@@ -85,7 +92,8 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None):
     tokens = threading.Semaphore(n_sets - 1)        # a buffer set is reused only after its group has been written
     parsed, to_write = queue.Queue(maxsize=n_work), queue.Queue(maxsize=n_work)
     t = dict(parse=0.0, assign=0.0, upload=0.0, upload_dev=0.0, run=0.0, run_dev=0.0, fetch=0.0, write=0.0, wait_in=0.0, wait_out=0.0,
-             setup=0.0, close=0.0, reads=0, batches=0)
+             setup=0.0, close=0.0, scan=0.0, reads=0, batches=0, short=0, assigned=0)
+    seen = set()
     errors, lock = [], threading.Lock()
 
     def reader_thread():                            # parse + splint/strand lookup, ahead of the GPUs
@@ -96,10 +104,14 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None):
                 hb = rd.next(batch_reads, args.lencutoff, GPU_BATCH_BASES)
                 t1 = time.perf_counter()
                 if hb.n == 0:
+                    t["short"] += hb.n_short
                     break
-                sid, st, _k = assigner.batch(hb)
+                if fused:
+                    sid, st, k = np.zeros(hb.n, dtype=np.int16), b"?" * hb.n, 0
+                else:
+                    sid, st, k = assigner.batch(hb)
                 t["parse"] += t1 - t0; t["assign"] += time.perf_counter() - t1
-                t["reads"] += hb.n; t["batches"] += 1
+                t["reads"] += hb.n; t["batches"] += 1; t["short"] += hb.n_short; t["assigned"] += k
                 parsed.put((hb, sid, st))
         except Exception as e:                      # noqa: BLE001 -- re-raised by the caller's thread
             errors.append(e)
@@ -138,6 +150,14 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None):
             done = cur is None
             while not done and not errors:
                 hb, sid, st = cur
+                if fused:                                         # splint / strand of the resident batch from the GPU finder
+                    ts = time.perf_counter()
+                    tab, sid, st = h.scan_splints()
+                    h.assign(sid, st)
+                    with lock:
+                        k = _lib.write_splint_psl(hb, tab, sid, st, splint_names, sp_lens, h.cfg.conk_match, finder_psl + ".part")
+                        t["assigned"] += k; t["scan"] += time.perf_counter() - ts
+                        seen.update(splint_names[x] for x in np.unique(sid[sid >= 0]))
                 nxt, staged = None, False
                 try:
                     nxt = take(False)
@@ -217,6 +237,18 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None):
         raise errors[0]
     threads[0].join()
     rd.close()
+    if fused:
+        os.replace(finder_psl + ".part", finder_psl)              # a rerun finds the PSL and takes the two-pass route
+        for n, cp, sp in zip(splint_names, cons_paths, sub_paths):
+            if n not in seen:                                       # adapter_set of bin/preprocess.py:34,43 = splints that were hit
+                for p in (cp, sp):
+                    if os.path.exists(p) and os.stat(p).st_size == 0:
+                        os.remove(p)
+                try:
+                    os.rmdir(args.out_path + n)
+                except OSError:
+                    pass
+        t["adapter_set"] = sorted(seen)
     if compress:                                                        # -co (C3POa.py:88-90)
         for p in cons_paths + sub_paths:
             if os.path.exists(p):
@@ -226,5 +258,5 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None):
     if stats is not None:
         stats.update(t)
     if os.environ.get("C3_STREAM_STATS"):
-        print("stream: " + " ".join("%s=%.3f" % (k, v) if isinstance(v, float) else "%s=%d" % (k, v) for k, v in t.items()), file=sys.stderr)
+        print("stream: " + " ".join("%s=%.3f" % (k, v) if isinstance(v, float) else "%s=%s" % (k, v) for k, v in t.items()), file=sys.stderr)
     return t["reads"]

@@ -109,6 +109,9 @@ int c3_batch_stage(c3_handle* h, int n, const char* seqs, const char* quals, con
                    const int16_t* splint_id, const char* strand);
 int c3_batch_commit(c3_handle* h);
 
+/* overwrite the splint row / strand of the resident batch (e.g. with the output of c3_scan_splints) before c3_batch_run */
+int c3_batch_assign(c3_handle* h, const int16_t* splint_id, const char* strand);
+
 /* run the resident batch through the hot path (asynchronous on the library's stream).
  * stages: bit0 conk, bit1 peaks+split, bit2 POA/draft, bit3 polish.  C3_STAGES_ALL = whole path
  * = one call of analyze_reads (C3POa.py:110-173) minus file I/O. */
