@@ -435,3 +435,32 @@ def test_staged_upload_pipeline_equals_plain_upload(tmp_path):
             h.commit()
     assert got == want
     h.close()
+
+
+def test_scan_then_assign_equals_upload_with_known_strands():
+    """the fused CLI route: upload unassigned -> c3_scan_splints -> c3_batch_assign -> run gives what an upload with the
+    true splint / strand gives; c3_batch_assign rejects a splint row outside the table"""
+    from c3poa_amd import _lib
+    rng = np.random.default_rng(17)
+    other = _rand(rng, 180)
+    recs = list(synth.generate("cfg1", n_reads=20))
+    reads = [(r[1], r[2], r[3], 0) for r in recs]
+    for i in range(6):
+        s, q = _concatemer(rng, other, 800, 3, 90, 90)
+        if i % 2:
+            s, q = revcomp(s), q[::-1]
+        reads.append((s, q, "+-"[i % 2], 1))
+    reads.append((_rand(rng, 2500), _qual(rng, 2500), "?", 0))
+    h = _lib.Handle(); h.set_splints([synth.SPLINT1, other])
+    h.upload([r[0] for r in reads], [r[1] for r in reads], [r[2] for r in reads], np.array([r[3] for r in reads], dtype=np.int16))
+    h.run()
+    want = h.results()[1]
+    h.upload([r[0] for r in reads], [r[1] for r in reads], "?" * len(reads))
+    _tab, sid, st = h.scan_splints()
+    assert [chr(c) for c in st] == [r[2] for r in reads] and [int(x) for x in sid[:-1]] == [r[3] for r in reads[:-1]] and sid[-1] == -1
+    bad = sid.copy(); bad[0] = 5
+    assert h.lib.c3_batch_assign(h.h, bad.ctypes.data, st) == -3
+    h.assign(sid, st)
+    h.run()
+    assert h.results()[1] == want and sum(1 for c in want if c) >= 25
+    h.close()
