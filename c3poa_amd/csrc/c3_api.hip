@@ -439,9 +439,21 @@ static int fetch_summary(c3_handle* h) {
   const int n = h->n;
   h->work.clear();
   for (int i = 0; i < n; ++i) if (h->sum[i].status == C3_ST_OK && h->sum[i].n_sub >= 1) h->work.push_back(i);
-  // longest first: better tail behaviour of the dynamic work queues
-  std::stable_sort(h->work.begin(), h->work.end(), [&](int x, int y) {
-    long cx = (long)h->sum[x].sum_sub * h->sum[x].n_sub, cy = (long)h->sum[y].sum_sub * h->sum[y].n_sub; return cx > cy; });
+  // longest first: better tail behaviour of the dynamic work queues.  Same order as a stable sort by descending cost
+  // (ties: read order), done on packed (inverted cost, read) keys -- the GPU is idle while this runs
+  if (n < (1 << 24)) {
+    std::vector<uint64_t> keys(h->work.size());
+    for (size_t k = 0; k < h->work.size(); ++k) {
+      const int i = h->work[k];
+      const uint64_t cost = (uint64_t)h->sum[i].sum_sub * (uint64_t)h->sum[i].n_sub;          // < 2^40
+      keys[k] = ((((uint64_t)1 << 40) - 1 - cost) << 24) | (uint64_t)i;
+    }
+    std::sort(keys.begin(), keys.end());
+    for (size_t k = 0; k < keys.size(); ++k) h->work[k] = (int)(keys[k] & 0xffffff);
+  } else {
+    std::stable_sort(h->work.begin(), h->work.end(), [&](int x, int y) {
+      long cx = (long)h->sum[x].sum_sub * h->sum[x].n_sub, cy = (long)h->sum[y].sum_sub * h->sum[y].n_sub; return cx > cy; });
+  }
   HIPCHK(h->d_work.ensure(sizeof(int) * std::max<size_t>(h->work.size(), 1)));
   if (!h->work.empty()) HIPCHK(hipMemcpyAsync(h->d_work.p, h->work.data(), sizeof(int) * h->work.size(), hipMemcpyHostToDevice, h->stream));
   return 0;
