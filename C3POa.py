@@ -12,11 +12,8 @@ the last, short group is flushed (the reference never dispatches it, SURVEY.md A
 racon/blat config entries are accepted, racon is never executed.
 """
 import argparse
-import gzip
 import os
-import shutil
 import sys
-from glob import glob
 
 PATH = os.path.dirname(os.path.realpath(__file__))
 sys.path.insert(0, PATH)
@@ -68,20 +65,6 @@ def configReader(path, configIn):
         progs[missing] = missing
         sys.stderr.write("Using " + str(missing) + " from your path, not the config file.\n")
     return progs
-
-
-def cat_files(path, pattern, output, compress):
-    """C3POa.py:86-99"""
-    if compress:
-        output += ".gz"
-        final_fh = gzip.open(output, "wb+")
-    else:
-        final_fh = open(output, "w+")
-    for f in sorted(glob(path + pattern)):
-        with open(f) as fh:
-            for line in fh:
-                final_fh.write(line.encode() if compress else line)
-    final_fh.close()
 
 
 def main(args):

@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- R2C2 reads->consensus/sec on MI355X (BASELINE.json metric, config cfg2).
+"""bench.py -- R2C2 reads->consensus/sec on MI355X (BASELINE.json metric; default workload cfg2).
 
-A "step" is one pass of the whole hot path (conk -> peaks/split -> POA draft -> polish) over one
-batch of synthetic reads that is ALREADY RESIDENT in HBM (packed 2-bit bases + quality bytes);
-the consensus sequences are left in HBM.  One process per GPU; reads are sharded, there is no
-data-path collective -> weak scaling: every rank processes --reads reads/step.
+A "step" is one pass of the whole hot path (conk -> peaks/split -> POA draft -> polish) over one batch of synthetic
+reads, run as the steady state of the streaming pipeline the CLI uses ("first batch submit -> last
+result fetched"):
+
+    c3_batch_stage(next batch)      H2D + 2-bit pack on the library's second stream, overlapped with ...
+    c3_batch_run(resident batch)    ... the kernels of the resident batch
+    c3_batch_results(...)           per-read records + consensus bytes fetched to the host
+    c3_batch_commit()               the staged batch becomes resident
+
+so the input of every timed step is already resident in HBM when the step starts (it was staged during the step before),
+and the timed region still pays for the copy engine traffic, the result fetch and every host gap.  `value` is that rate;
+`config.resident_only_reads_per_s` is the kernels-only rate of the same steps (sum of c3_batch_run times).
+
+One process per GPU; reads are sharded by rank, there is no data-path collective -> weak scaling: every
+rank processes --reads reads per step.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...            # WORLD_SIZE unset: starts N workers itself (child torch.distributed.run)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0.  roofline = algorithmic HBM bytes of the dominant kernel per launch
-/ its HIP-event duration (events recorded by the library on its own stream);
-cpu_baseline = the oracle (own CPU restatement, "port") on a bounded sample, rank 0, N=1 only.
+Prints ONE JSON line on rank 0.  roofline = algorithmic HBM bytes of the dominant kernel per launch / its HIP-event
+duration (events recorded by the library on its own stream); cpu_baseline = the oracle (own CPU restatement, "port") on
+a bounded sample, rank 0, N=1 only.
 """
 import argparse
 import json
 import multiprocessing as mp
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,6 +41,15 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+# per-GPU reads per step: BASELINE.json configs (cfg3: 1M reads over 8 GPUs)
+DEFAULT_READS = {"cfg1": 1000, "cfg2": 100000, "cfg3": 125000, "cfg4": 100000, "cfg5": 131072}
+WORKLOAD_TEXT = {
+    "cfg1": "5 kb, 3x1.5 kb repeats (plumbing case)",
+    "cfg2": "5 kb, 3x1.5 kb repeats, Splint1, 10% error",
+    "cfg3": "mixed 2-10 subreads, 1 kb insert (1M reads read-sharded over 8 GPUs -> 125k per GPU)",
+    "cfg4": "20 kb, 12 subreads, -d 1500 (wide adaptive band)",
+    "cfg5": "cfg2 shape, one GPU batch of the streamed CLI",
+}
 
 
 def _gen_shard(args):
@@ -47,21 +70,59 @@ def make_reads(cfg, n, start, procs):
     return [r for p in parts for r in p]
 
 
-def main():
+def visible_gpus():
+    """GPUs visible to this process WITHOUT initialising the HIP runtime (the launcher must stay GPU-free: its children
+    are separate processes, and a process that has touched the GPU must never exec)."""
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launch_workers(n_gpus, argv, have=None):
+    """`python bench.py --gpus N` with WORLD_SIZE unset: start N ranks as CHILD processes (torch.distributed.run), forward
+    their output and return their exit code.  Fails loudly when fewer than N GPUs are visible."""
+    have = visible_gpus() if have is None else have
+    if have < n_gpus:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node" % (n_gpus, have))
+    cmd = worker_command(n_gpus, argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def worker_command(n_gpus, argv, port=None):
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--reads", type=int, default=100000, help="reads per step per GPU (cfg2: 100k)")
+    ap.add_argument("--reads", type=int, default=0, help="reads per step per GPU (0 = the config's size: cfg2 100k)")
     ap.add_argument("--cfg", default="cfg2")
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic reads generated per rank (0 = all)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
+    if a.reads <= 0:
+        a.reads = DEFAULT_READS.get(a.cfg, 100000)
+    return a
 
+
+def main():
+    a = parse_args()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_workers(a.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     dist = None
     # generate inputs BEFORE anything touches the GPU (fork-based pool)
     from c3poa_amd import synth
@@ -93,38 +154,51 @@ def main():
     lens = np.array([len(s) for s in seqs], dtype=np.int64)
     off = np.zeros(len(lens) + 1, dtype=np.int64)
     np.cumsum(lens, out=off[1:])
-    seq_cat, qual_cat = "".join(seqs).encode(), "".join(quals).encode()   # the boundary hands over flat host buffers
+    # the boundary hands over flat host buffers; page-locked, as the native reader's are (c3_reader_*)
+    host = _lib.PinnedBatch("".join(seqs).encode(), "".join(quals).encode(), off, "".join(strands))
     del seqs, quals
-    h.upload_flat(seq_cat, qual_cat, off, "".join(strands))               # first call also allocates the device buffers
+    h.upload_pinned(host)                                                  # first call also allocates the device buffers
     t_up = time.perf_counter()
-    h.upload_flat(seq_cat, qual_cat, off, "".join(strands))               # H2D + 2-bit pack: outside the timed region
+    h.upload_pinned(host)                                                  # un-overlapped H2D + 2-bit pack, for reference
     t_up = time.perf_counter() - t_up
-    del seq_cat, qual_cat
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    stage_ms, run_s, fetch_s = {}, [], []
+
+    def step(timed):
+        h.stage_pinned(host)                     # next batch: copy engine + pack kernel on the second stream
+        t1 = time.perf_counter()
+        h.run()                                  # resident batch: conk -> peaks -> POA -> polish
+        t2 = time.perf_counter()
+        out = h.results_raw()                    # per-read records + consensus bytes on the host
+        t3 = time.perf_counter()
+        h.commit()
+        if timed:
+            run_s.append(t2 - t1); fetch_s.append(t3 - t2)
+            for k, v in h.last_timing.items():
+                if k.startswith("ms_") and k not in ("ms_pack", "ms_total"):
+                    stage_ms.setdefault(k, []).append(v)
+        return out
+
     for _ in range(a.warmup):
-        h.run()
-    stage_ms = {}
+        step(False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        h.run()                                  # synchronous on return (library stream drained)
-        tm = h.timing()
-        for k, v in tm.items():
-            if k.startswith("ms_") and k not in ("ms_pack", "ms_total"):
-                stage_ms.setdefault(k, []).append(v)
+        h.last_timing = None
+        res_raw = step(True)
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    res, cons = h.results(with_consensus=(rank == 0))
-    tm = h.timing()
+    tm = h.last_timing
+    res, cbuf, coff = res_raw
     ok = res["status"] == 0
 
     out = None
@@ -139,38 +213,46 @@ def main():
         cells = tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish"]
         # consensus % identity vs the synthetic truth (second half of BASELINE.json's metric), on a sample
         n_id = min(200, n_unique)
-        idents = np.array([synth.identity(cons[i], recs[i][3]) if cons[i] else 0.0 for i in range(n_id)])
-        # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process;
-        # the number comes from the committed rocprofv3 pass of THIS command when the workload matches
-        traffic = None
-        try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic_cfg2_100k.json")))
-            if a.cfg == "cfg2" and a.reads == 100000:
+        raw = cbuf.tobytes()
+        idents = np.array([synth.identity(raw[coff[i]:coff[i + 1]].decode(), recs[i][3]) if coff[i + 1] > coff[i] else 0.0
+                           for i in range(n_id)])
+        # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the number
+        # comes from the committed rocprofv3 passes of THIS command when the workload matches
+        traffic, tsrc = None, None
+        for tag in ("r02", "r01"):
+            try:
+                name = "%s_pmc_traffic_%s_%dk.json" % (tag, a.cfg, a.reads // 1000)
+                pm = json.load(open(os.path.join(ROOT, "profiles", name)))
                 traffic = pm["kernels"][dom.replace("ms_", "k_")]["hbm_bytes_per_launch"]
-        except Exception:
-            traffic = None
+                tsrc = "profiles/%s (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024)" % name
+                break
+            except Exception:
+                continue
         out = {
             "metric": "R2C2 reads->consensus/sec", "value": round(value, 1), "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic (c3poa_amd.synth %s: %d distinct reads%s)" % (
                 a.cfg, n_unique, "" if reps == 1 else ", tiled x%d" % reps),
-            "config": {"workload": "%s: %d reads/GPU/step, 5 kb, 3x1.5 kb repeats, Splint1, 10%% error" % (a.cfg, a.reads)
-                       if a.cfg == "cfg2" else "%s: %d reads/GPU/step" % (a.cfg, a.reads),
-                       "stages": "conk+peaks/split+POA+polish", "reads_per_gpu_step": a.reads,
+            "config": {"workload": "%s: %d reads/GPU/step, %s" % (a.cfg, a.reads, WORKLOAD_TEXT.get(a.cfg, "")),
+                       "stages": "stage(H2D+pack, overlapped) | conk+peaks/split+POA+polish | results(D2H) | commit",
+                       "reads_per_gpu_step": a.reads,
                        "consensus_ok": int(ok.sum()), "mean_read_len": float(lens.mean()),
                        "identity_vs_truth": {"mean": round(float(idents.mean()), 5), "median": round(float(np.median(idents)), 5), "reads": int(n_id)},
-                       "upload_ms": round(t_up * 1e3, 1),
-                       "pcie_inclusive_reads_per_s": round(a.reads * world / (dt / a.steps + t_up), 1)},
+                       "resident_only_reads_per_s": round(a.reads * world / float(np.mean(run_s)), 1),
+                       "run_ms": round(float(np.mean(run_s)) * 1e3, 2), "fetch_ms": round(float(np.mean(fetch_s)) * 1e3, 2),
+                       "upload_ms_unoverlapped": round(t_up * 1e3, 1)},
             "roofline": {"bound": "hbm", "kernel": dom.replace("ms_", "k_"), "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                         "traffic": traffic, "traffic_source": "profiles/r01_pmc_traffic_cfg2_100k.json (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024)" if traffic else None,
+                         "traffic": traffic, "traffic_source": tsrc,
                          "alg_bytes_per_launch": alg_bytes,
                          "kernel_ms": {k: round(v, 3) for k, v in avg.items()},
+                         "cells_per_step": int(cells),
                          "gcups": round(cells / (sum(avg.values()) * 1e-3) / 1e9, 2)},
             "gen_s": round(t_gen, 1),
         }
     h.close()
+    host.close()
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(recs, md, a.cpu_seconds)
     if dist is not None:

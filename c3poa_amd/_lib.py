@@ -19,9 +19,10 @@ EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_create", "c
            "c3_batch_upload", "c3_batch_stage", "c3_batch_commit", "c3_batch_assign", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_timing",
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
            "c3_call_peaks", "c3_poa_msa", "c3_pairwise_consensus", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
-           "c3_reader_open", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_write_group",
+           "c3_reader_open", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_reader_next_set", "c3_write_group",
            "c3_scan_adapters", "c3_match_index", "c3_match_index_batch",
-           "c3_assign_open", "c3_assign_close", "c3_assign_batch", "c3_assign_seen", "c3_write_splint_psl"]
+           "c3_assign_open", "c3_assign_close", "c3_assign_batch", "c3_assign_seen", "c3_write_splint_psl",
+           "c3_host_alloc", "c3_host_free"]
 
 
 class Config(C.Structure):
@@ -106,6 +107,9 @@ def load():
     lib.c3_assign_batch.argtypes = [vp, C.POINTER(HostBatchStruct), vp, vp]
     lib.c3_assign_seen.argtypes = [vp, vp, vp]
     lib.c3_write_splint_psl.argtypes = [C.POINTER(HostBatchStruct), vp, vp, vp, C.c_int, C.POINTER(cp), vp, C.c_int, cp, vp]
+    lib.c3_host_alloc.argtypes = [C.c_int64, C.POINTER(vp)]
+    lib.c3_host_free.argtypes = [vp]
+    lib.c3_host_free.restype = None
     lib.c3_reader_open.argtypes = [cp, C.c_int, C.POINTER(vp)]
     lib.c3_reader_close.argtypes = [vp]
     lib.c3_reader_close.restype = None
@@ -114,6 +118,7 @@ def load():
     lib.c3_reader_names_only.restype = None
     lib.c3_reader_error.restype = C.c_char_p
     lib.c3_reader_next.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.POINTER(HostBatchStruct)]
+    lib.c3_reader_next_set.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(HostBatchStruct)]
     lib.c3_write_group.argtypes = [C.POINTER(HostBatchStruct), vp, vp, vp, vp, C.c_int, C.POINTER(cp), C.POINTER(cp), C.c_int]
     lib.c3_determine_consensus.argtypes = [vp, C.c_int, C.POINTER(cp), C.POINTER(cp), ip, cp, cp, C.c_int,
                                            cp, cp, C.c_int, vp, C.c_int, ip, vp, C.c_int, ip]
@@ -233,21 +238,30 @@ class Handle:
         assert len(sid) == len(st) == self.n
         self._chk(self.lib.c3_batch_assign(self.h, sid.ctypes.data, st.ctypes.data))
 
+    def upload_pinned(self, pb, splint_ids=None):
+        """c3_batch_upload straight from a PinnedBatch (page-locked buffers: DMA, no staging copy)"""
+        sid = np.ascontiguousarray(splint_ids, dtype=np.int16) if splint_ids is not None else None
+        self._chk(self.lib.c3_batch_upload(self.h, pb.n, pb.seqs, pb.quals, pb.off.ctypes.data,
+                                           sid.ctypes.data if sid is not None else None, pb.strand.ctypes.data))
+        self.n, self.off = pb.n, pb.off
+
+    def stage_pinned(self, pb, splint_ids=None):
+        """c3_batch_stage from a PinnedBatch; the batch must stay alive until commit()"""
+        sid = np.ascontiguousarray(splint_ids, dtype=np.int16) if splint_ids is not None else None
+        self._chk(self.lib.c3_batch_stage(self.h, pb.n, pb.seqs, pb.quals, pb.off.ctypes.data,
+                                          sid.ctypes.data if sid is not None else None, pb.strand.ctypes.data))
+        self._staged = (pb.n, pb.off, pb)
+
     def run(self, stages=STAGES_ALL):
         self._chk(self.lib.c3_batch_run(self.h, stages))
+        self.last_timing = self.timing()         # c3_batch_commit clears the library's copy
 
-    def results_raw(self):
-        """(results structured array, consensus byte buffer, cons_off[n+1]) without building Python strings"""
-        coff = np.zeros(self.n + 1, dtype=np.int64)
-        cap = int(self.off[-1]) + 16
-        pool = self.__dict__.setdefault("_cons_pool", [[None, None] for _ in range(4)])   # the 3 previous results stay valid
-        k = self.__dict__["_cons_k"] = (self.__dict__.get("_cons_k", -1) + 1) % len(pool)
-        buf, rbuf = pool[k]
-        if buf is None or len(buf) < cap:                      # grow-only: no page faults per batch
-            buf = pool[k][0] = np.empty(cap + cap // 4, dtype=np.uint8)
-        if rbuf is None or len(rbuf) < self.n:
-            rbuf = pool[k][1] = np.empty(self.n + self.n // 4 + 1, dtype=RESULT_DTYPE)
-        res = rbuf[:self.n]
+    def results_raw(self, into=None):
+        """(results structured array, consensus byte buffer, cons_off[n+1]) without building Python strings.
+        `into`: a ResultBuffers object owned by the caller (pipelines that keep several results alive at once hand each one
+        back to their own free list); without it ONE grow-only set per handle is reused, valid until the next call."""
+        rb = into if into is not None else self.__dict__.setdefault("_own_rb", ResultBuffers())
+        res, buf, coff = rb.fit(self.n, int(self.off[-1]) + 16)
         self._chk(self.lib.c3_batch_results(self.h, res.ctypes.data, buf.ctypes.data, len(buf), coff.ctypes.data))
         return res, buf, coff
 
@@ -402,6 +416,51 @@ def device_count():
     return int(load().c3_device_count())
 
 
+class ResultBuffers:
+    """grow-only host buffers for one batch of results (no page faults per batch); owned by whoever holds the object"""
+
+    def __init__(self):
+        self.res = self.buf = None
+
+    def fit(self, n, cons_cap):
+        if self.buf is None or len(self.buf) < cons_cap:
+            self.buf = np.empty(cons_cap + cons_cap // 4, dtype=np.uint8)
+        if self.res is None or len(self.res) < n:
+            self.res = np.empty(n + n // 4 + 1, dtype=RESULT_DTYPE)
+        return self.res[:n], self.buf, np.zeros(n + 1, dtype=np.int64)
+
+
+class PinnedBatch:
+    """one batch in flat host buffers from c3_host_alloc (page-locked when a GPU is present): what the boundary is handed"""
+
+    def __init__(self, seq_cat, qual_cat, off, strands):
+        self.lib = load()
+        self.off = np.ascontiguousarray(off, dtype=np.int64)
+        self.n = len(self.off) - 1
+        st = _b(strands)
+        assert len(st) == self.n and len(seq_cat) == self.off[-1] == len(qual_cat)
+        self.strand = np.frombuffer(st, dtype=np.uint8).copy()
+        self._p = []
+        for src in (seq_cat, qual_cat):
+            p = C.c_void_p()
+            if self.lib.c3_host_alloc(len(src) + 64, C.byref(p)) != 0:
+                raise MemoryError("c3_host_alloc(%d)" % len(src))
+            C.memmove(p, src, len(src))
+            self._p.append(p)
+        self.seqs, self.quals = self._p[0].value, self._p[1].value
+
+    def close(self):
+        for p in self._p:
+            self.lib.c3_host_free(p)
+        self._p = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class HostBatch:
     """one group of reads held by the native reader (valid until the reader reuses its buffer set)"""
 
@@ -437,12 +496,18 @@ class Reader:
         if names_only:
             self.lib.c3_reader_names_only(self.r, 1)
 
-    def next(self, max_reads, min_len=0, max_bases=0):
+    def next(self, max_reads, min_len=0, max_bases=0, set_index=None):
+        """next group; set_index names the buffer set to fill (caller-managed free list), None = round-robin"""
         c = HostBatchStruct()
-        rc = self.lib.c3_reader_next(self.r, int(max_reads), int(max_bases), int(min_len), C.byref(c))
+        if set_index is None:
+            rc = self.lib.c3_reader_next(self.r, int(max_reads), int(max_bases), int(min_len), C.byref(c))
+        else:
+            rc = self.lib.c3_reader_next_set(self.r, int(set_index), int(max_reads), int(max_bases), int(min_len), C.byref(c))
         if rc != 0:
             raise ValueError("c3_reader_next: %s" % self.lib.c3_reader_error(self.r).decode())
-        return HostBatch(c, self)
+        hb = HostBatch(c, self)
+        hb.set_index = set_index
+        return hb
 
     def close(self):
         if self.r:

@@ -323,7 +323,10 @@ extern "C" int c3_batch_assign(c3_handle* h, const int16_t* splint_id, const cha
   }
   HIPCHK(hipMemcpyAsync(h->d_strand.p, strand, (size_t)h->n, hipMemcpyHostToDevice, h->stream));
   HIPCHK(hipMemcpyAsync(h->d_sid.p, sid.data(), sizeof(int16_t) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+  // a read that was unassigned in an earlier run carries C3_ST_NOT_ASSIGNED: every record starts over
+  hipLaunchKernelGGL(k_init_info, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), h->n);
   HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipGetLastError());
   h->stages_done = 0;
   return C3_E_OK;
 }
@@ -548,7 +551,9 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 64, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->tm.cells_polish += *(long long*)(cnt + 2);
-  const int n_win = cnt[8];
+  // k_prep reserves windows with an atomicAdd BEFORE its capacity check: after an overflow the counter exceeds wcap, and
+  // the records past wcap were never written (the reads that overflowed carry C3_ST_LIMIT and n_win = 0)
+  const int n_win = (int)std::min<long long>(cnt[8], std::min<long long>(wcap, 0x7fffffff));
   h->n_windows = n_win;
   DBG("prep done: n_win=%d\n", n_win);
   const int wout_cap = 3 * WL + 64;
@@ -606,6 +611,11 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
   float ms;
   hipEvent_t t0 = h->ev[0], t1 = h->ev[1], t2 = h->ev[2], t3 = h->ev[3], t4 = h->ev[4];
   DBG("run: start n=%d\n", h->n);
+  // per-run figures start from zero: repeated runs of one resident batch (bench.py, tools/) must not accumulate
+  if (stages & C3_STAGE_CONK) { h->tm.ms_conk = 0; h->tm.cells_conk = 0; }
+  if (stages & C3_STAGE_PEAKS) h->tm.ms_peaks = 0;
+  if (stages & C3_STAGE_POA) { h->tm.ms_poa = 0; h->tm.cells_poa = 0; }
+  if (stages & C3_STAGE_POLISH) { h->tm.ms_prep = h->tm.ms_window = h->tm.ms_stitch = 0; h->tm.cells_polish = 0; h->tm.n_windows = 0; }
   HIPCHK(hipEventRecord(t0, h->stream));
   if (stages & C3_STAGE_CONK) { if ((rc = run_conk(h))) return rc; h->tm.cells_conk = 0; for (int i = 0; i < h->n; ++i) h->tm.cells_conk += (h->off[i + 1] - h->off[i]) * (int64_t)h->max_spl; }
   HIPCHK(hipEventRecord(t1, h->stream));

@@ -122,6 +122,23 @@ int fail(c3_reader* r, const char* msg) { r->err = msg; return C3_E_ARG; }
 
 }  // namespace
 
+// page-locked host memory for callers that build their own batches (bench.py, tests): the same kind of buffer the reader
+// hands out, so c3_batch_stage / c3_batch_upload copy it by DMA.  Plain malloc when no GPU runtime is present.
+extern "C" int c3_host_alloc(int64_t bytes, void** out) {
+  if (!out || bytes <= 0) return C3_E_ARG;
+  HostBuf b;                                      // 64-byte header in front of the user pointer: byte 0 = page-locked?
+  if (!b.reserve((size_t)bytes + 64, 0)) return C3_E_NOMEM;
+  b.p[0] = b.pinned ? 1 : 0;
+  *out = b.p + 64;
+  b.p = nullptr; b.cap = 0;                       // ownership moves to the caller (c3_host_free)
+  return C3_E_OK;
+}
+extern "C" void c3_host_free(void* p) {
+  if (!p) return;
+  char* base = (char*)p - 64;
+  if (base[0]) (void)hipHostFree(base); else free(base);
+}
+
 extern "C" int c3_reader_open(const char* path, int n_sets, c3_reader** out) {
   if (!path || !out) return C3_E_ARG;
   c3_reader* r = new c3_reader();
@@ -152,8 +169,15 @@ extern "C" const char* c3_reader_error(const c3_reader* r) { return r ? r->err.c
 // One group of reads.  Records shorter than min_len are skipped and counted in out->n_short (C3POa.py:202-204,240-241).
 // Stops after max_reads kept reads or once max_bases kept bases are exceeded (0 = no limit).  out->n == 0 at end of file.
 extern "C" int c3_reader_next(c3_reader* r, int max_reads, int64_t max_bases, int min_len, c3_host_batch* out) {
-  if (!r || !out || max_reads <= 0) return C3_E_ARG;
-  r->cur = (r->cur + 1) % (int)r->sets.size();
+  if (!r) return C3_E_ARG;
+  return c3_reader_next_set(r, (r->cur + 1) % (int)r->sets.size(), max_reads, max_bases, min_len, out);
+}
+
+// The same, into buffer set `set` (0 .. n_sets-1) chosen by the caller: with several consumers finishing out of order the
+// caller keeps a free list of sets and hands one back only after its group has been written.
+extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t max_bases, int min_len, c3_host_batch* out) {
+  if (!r || !out || max_reads <= 0 || set < 0 || set >= (int)r->sets.size()) return C3_E_ARG;
+  r->cur = set;
   BatchSet& s = r->sets[(size_t)r->cur];
   s.name_off.assign(1, 0); s.off.assign(1, 0);
   if (!r->names_only && r->hint_bases) {

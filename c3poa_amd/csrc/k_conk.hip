@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
     // (stored by every lane: a divergent `if (lane == 0)` right before `continue` can livelock the
     // persistent loop -- see prep_one in k_polish.hip)
     if (!SCAN && st != '+' && st != '-') { a.info[rid].status = C3_ST_NOT_ASSIGNED; continue; }
+    if (!SCAN) a.info[rid].status = C3_ST_OK;          // a re-run after c3_batch_assign must not see a stale NOT_ASSIGNED
     const int sid = SCAN ? (item >> 1) % a.n_spl : a.b.splint_id[rid];
     const int S = a.sp_len[sid];
     const uint8_t* sp = a.sp_codes + ((size_t)sid * 2 + (st == '-')) * C3_SPLINT_MAX;

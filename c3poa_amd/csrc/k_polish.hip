@@ -174,7 +174,15 @@ __device__ __forceinline__ void prep_one(const PrepArgs& a, int wi, int lane, ui
     int wbase = 0;
     if (lane == 0) wbase = atomicAdd(a.n_windows, nwin);
     wbase = wave_first(wbase);
-    if (wbase + nwin > a.wcap) { info->status = C3_ST_LIMIT; info->n_win = 0; a.win_base[rid] = 0; return; }
+    if (wbase + nwin > a.wcap) {
+      // the reservation cannot be undone: the slots below wcap become empty windows (no layers, no backbone), so k_window
+      // and k_stitch never see a record nobody wrote
+      for (int w = lane; w < nwin && wbase + w < a.wcap; w += 64) {
+        WinRec r; r.rid = rid; r.w = w; r.n_layers = 0; r.blen = 0; r.tgs = 0; r.out_len = 0; r.polished = 0; r.pad_ = 0;
+        a.wrec[wbase + w] = r;
+      }
+      info->status = C3_ST_LIMIT; info->n_win = 0; a.win_base[rid] = 0; return;
+    }
     for (int i = lane; i < nl * nwin; i += 64) { lwf[i] = INT32_MAX; lwl[i] = -1; }
     for (int w = lane; w < nwin; w += 64) {
       WinRec r; r.rid = rid; r.w = w; r.n_layers = 0; r.blen = (w * WL + WL <= C) ? WL : C - w * WL; r.tgs = tgs; r.out_len = 0; r.polished = 0; r.pad_ = 0;

@@ -101,4 +101,4 @@ def determine_consensus(args, read, subreads, sub_qual, dangling_subreads, qual_
             fh.write(subread_records(name, subreads, sub_qual, dangling_subreads, qual_dangling_subreads))
     h = _handle(mdistcutoff=getattr(args, "mdistcutoff", 500))
     cons = h.determine_consensus(subreads, sub_qual, front, tail)
-    return cons, (repeats if cons else repeats)
+    return cons, repeats

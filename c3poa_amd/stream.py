@@ -6,8 +6,8 @@ batch i+1 and writes the records of batch i-1.  No per-read Python objects are c
 reader fills page-locked SoA buffers that c3_batch_upload copies by DMA and c3_write_group slices for the subread file.
 
 The reference's -g (group size) only decides how reads are partitioned into <splint>/tmp<k>/ directories that are
-concatenated and deleted at the end (C3POa.py:259-271); here a GPU batch is max(-g, GPU_BATCH_READS) reads and records
-are appended to the final files directly (same output tree, no double write).
+concatenated and deleted at the end (C3POa.py:259-271); here a GPU batch is max(-g, GPU_BATCH_READS) reads (or
+C3_GPU_BATCH_READS when set) and records are appended to the final files directly (same output tree, no double write).
 """
 import gzip
 import os
@@ -85,11 +85,22 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                 open(p, "w").close()
                 if os.path.exists(p + ".gz"):
                     os.remove(p + ".gz")
-    batch_reads = max(int(args.groupSize), GPU_BATCH_READS)
+    # C3_GPU_BATCH_READS overrides the GPU batch size (tests drive the multi-batch pipeline with small inputs)
+    gpu_batch = int(os.environ.get("C3_GPU_BATCH_READS", "0"))
+    batch_reads = gpu_batch if gpu_batch > 0 else max(int(args.groupSize), GPU_BATCH_READS)
     n_work = n_dev * int(os.environ.get("C3_HANDLES_PER_GPU", HANDLES_PER_GPU))
     n_sets = 2 * n_work + 3
     rd = _lib.Reader(args.reads, n_sets=n_sets)
-    tokens = threading.Semaphore(n_sets - 1)        # a buffer set is reused only after its group has been written
+    # Ownership of the host buffers is explicit: the reader fills buffer set k only after taking k from this free list,
+    # and the writer puts k back once the group has been written (device threads finish out of order, so a counting
+    # semaphore over round-robin sets would let the reader overwrite a set a lagging device still holds).  Result buffers
+    # follow the same rule: one object per batch in flight, returned by the writer.
+    free_sets = queue.Queue()
+    for k in range(n_sets):
+        free_sets.put(k)
+    free_results = queue.Queue()
+    for _k in range(2 * n_work + 2):
+        free_results.put(_lib.ResultBuffers())
     parsed, to_write = queue.Queue(maxsize=n_work), queue.Queue(maxsize=n_work)
     t = dict(parse=0.0, assign=0.0, upload=0.0, upload_dev=0.0, run=0.0, run_dev=0.0, fetch=0.0, write=0.0, wait_in=0.0, wait_out=0.0,
              setup=0.0, close=0.0, scan=0.0, reads=0, batches=0, short=0, assigned=0)
@@ -99,12 +110,13 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
     def reader_thread():                            # parse + splint/strand lookup, ahead of the GPUs
         try:
             while not errors:
-                tokens.acquire()
+                ks = free_sets.get()
                 t0 = time.perf_counter()
-                hb = rd.next(batch_reads, args.lencutoff, GPU_BATCH_BASES)
+                hb = rd.next(batch_reads, args.lencutoff, GPU_BATCH_BASES, set_index=ks)
                 t1 = time.perf_counter()
                 if hb.n == 0:
                     t["short"] += hb.n_short
+                    free_sets.put(ks)
                     break
                 if fused:
                     sid, st, k = np.zeros(hb.n, dtype=np.int16), b"?" * hb.n, 0
@@ -176,13 +188,14 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                 t2 = time.perf_counter()
                 up_dev = h.timing()["ms_pack"] * 1e-3
                 run_dev = h.timing()["ms_total"] * 1e-3
-                res, buf, coff = h.results_raw()
+                rb = free_results.get()
+                res, buf, coff = h.results_raw(into=rb)
                 t3 = time.perf_counter()
                 with lock:
                     t["upload_dev"] += up_dev; t["run_dev"] += run_dev
                     t["run"] += t2 - t1; t["fetch"] += t3 - t2
                 tw = time.perf_counter()
-                to_write.put((hb, sid, res, buf, coff))
+                to_write.put((hb, sid, res, buf, coff, rb))
                 with lock:
                     t["wait_out"] += time.perf_counter() - tw
                 if done:
@@ -216,7 +229,7 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
             if item is None:
                 live -= 1
                 continue
-            hb, sid, res, buf, coff = item
+            hb, sid, res, buf, coff, rb = item
             t0 = time.perf_counter()
             try:
                 if not errors:
@@ -224,8 +237,10 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
             except Exception as e:                  # noqa: BLE001
                 errors.append(e)
             t["write"] += time.perf_counter() - t0
-            del hb, item
-            tokens.release()
+            k = hb.set_index
+            del hb, item, res, buf, coff
+            free_results.put(rb)
+            free_sets.put(k)
 
     threads = [threading.Thread(target=reader_thread, daemon=True), threading.Thread(target=writer_thread, daemon=True)]
     threads += [threading.Thread(target=device_thread, args=(w % n_dev,), daemon=True) for w in range(n_work)]

@@ -199,6 +199,11 @@ typedef struct {
   const int64_t* off;
 } c3_host_batch;
 
+/* host buffers for callers that assemble their own batches: page-locked when a GPU is present (DMA copies in
+ * c3_batch_stage / c3_batch_upload), plain memory otherwise.  The reference builds Python lists (C3POa.py:239-244). */
+int c3_host_alloc(int64_t bytes, void** out);
+void c3_host_free(void* p);
+
 typedef struct c3_reader c3_reader;
 /* mm.fastx_read(path, read_comment=False) (C3POa.py:201,239): FASTA or FASTQ, multi-line, plain or .gz.
  * n_sets = how many groups stay valid at once (the buffers of a group are reused n_sets calls later). */
@@ -210,6 +215,9 @@ void c3_reader_names_only(c3_reader* r, int names_only);
 /* next group: at most max_reads reads of length >= min_len (C3POa.py:202-204,240-241), stops early once max_bases
  * bases are held (0 = no limit).  out->n == 0 at end of file. */
 int c3_reader_next(c3_reader* r, int max_reads, int64_t max_bases, int min_len, c3_host_batch* out);
+/* the same into buffer set `set` (0 .. n_sets-1) named by the caller instead of round-robin: a pipeline whose consumers
+ * finish out of order (several GPUs) keeps a free list of sets and reuses one only after its group has been written */
+int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t max_bases, int min_len, c3_host_batch* out);
 
 /* file side effects of analyze_reads + determine_consensus for one group (C3POa.py:141-173,
  * bin/determine_consensus.py:57-77,108-114): appends the consensus FASTA records to cons_paths[splint_id[i]] and the

@@ -1,0 +1,53 @@
+"""bench.py launcher logic (CPU): `--gpus N` without WORLD_SIZE starts N child ranks, and fails loudly without N GPUs."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_worker_command_is_a_child_torchrun():
+    cmd = bench.worker_command(4, ["--gpus", "4", "--steps", "2"], port=29511)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-5] == os.path.join(ROOT, "bench.py") and cmd[-4:] == ["--gpus", "4", "--steps", "2"]
+    # a free port is picked when none is given
+    assert int(bench.worker_command(2, [])[bench.worker_command(2, []).index("--master-port") + 1]) > 0
+
+
+def test_launcher_refuses_more_gpus_than_visible():
+    with pytest.raises(SystemExit) as e:
+        bench.launch_workers(2, ["--gpus", "2"], have=1)
+    assert "only 1 GPU" in str(e.value)
+
+
+def test_per_config_defaults():
+    assert bench.parse_args([]).reads == 100000 and bench.parse_args([]).cfg == "cfg2"
+    assert bench.parse_args(["--cfg", "cfg3"]).reads == 125000
+    assert bench.parse_args(["--cfg", "cfg4"]).reads == 100000
+    assert bench.parse_args(["--cfg", "cfg4", "--reads", "5"]).reads == 5
+
+
+@pytest.mark.timeout(300)
+def test_gpus_2_on_a_box_without_two_gpus_fails_loudly():
+    """the way the driver runs it: `python3 bench.py --gpus 2` (no WORLD_SIZE).  Here no GPU is visible at all."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: covered by the driver's scaling run")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=280)
+    assert p.returncode != 0
+    assert "GPU(s) visible" in (p.stderr + p.stdout)
+
+
+def test_world_size_must_match_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--reads", "8"],
+                       capture_output=True, text=True, env=env, timeout=280)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)

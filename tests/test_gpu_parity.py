@@ -161,4 +161,10 @@ def test_full_batch_exact(O, cfg, n):
     t = h.timing()
     ocells = sum(r.cells_poa for r in ores)
     assert t["cells_poa"] == ocells
+    opol = sum(r.cells_polish for r in ores)
+    assert t["cells_polish"] == opol
+    # per-run figures: a second run of the same resident batch reports the same counts (no accumulation)
+    h.run()
+    t2 = h.timing()
+    assert (t2["cells_conk"], t2["cells_poa"], t2["cells_polish"]) == (t["cells_conk"], t["cells_poa"], t["cells_polish"])
     h.close()

@@ -1,0 +1,112 @@
+"""Host logic of the streamed CLI pipeline (c3poa_amd/stream.py) with SEVERAL workers, on CPU.
+
+The product pipeline (native reader -> worker threads -> native writer) runs unchanged; only the GPU handle is replaced by
+a stand-in that answers through the oracle (tests may use the oracle as the checker's engine) and sleeps for a random time,
+so batches complete OUT OF ORDER.  What is under test is the ownership of the reader's buffer sets and of the result
+buffers across worker threads (the `-n N` path of C3POa.py:236-256): every record of every group must come out exactly
+once, with its own name, subreads and qualities.
+"""
+import os
+import random
+import sys
+import time
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from c3poa_amd import _lib, stream, synth  # noqa: E402
+from c3poa_amd.seqio import fastx_read, revcomp  # noqa: E402
+
+
+class FakeHandle:
+    """stand-in for _lib.Handle: same methods the pipeline calls; results from the oracle; random latency"""
+    delays = random.Random(7)
+
+    def __init__(self, **cfg):
+        self.cfg = types.SimpleNamespace(conk_match=5)
+        self.md = cfg.get("mdistcutoff", 500)
+        self.cur = self.staged = None
+        self.last_timing = {"ms_pack": 0.0, "ms_total": 0.0}
+
+    def set_splints(self, splints):
+        self.splint = splints[0]
+
+    def _snap(self, hb, strands):
+        # copy out of the reader's buffers NOW, as the device upload does
+        return [hb.read(i) for i in range(hb.n)], strands.decode() if isinstance(strands, bytes) else strands, hb.n, hb.off
+
+    def upload_host(self, hb, strands, splint_ids):
+        self.cur = self._snap(hb, strands)
+        self.n, self.off = hb.n, hb.off
+
+    def stage_host(self, hb, strands, splint_ids):
+        self.staged = self._snap(hb, strands)
+
+    def commit(self):
+        self.cur, self.staged = self.staged, None
+        self.n, self.off = self.cur[2], self.cur[3]
+
+    def run(self):
+        time.sleep(self.delays.random() * 0.05)
+
+    def timing(self):
+        return self.last_timing
+
+    def results_raw(self, into=None):
+        from oracle import oracle_py as O
+        reads, st, n, off = self.cur
+        P = O.default_params(mdistcutoff=self.md)
+        ores, ocons = O.process_batch(self.splint, [(r[1], r[2]) for r in reads], list(st), params=P, threads=4)
+        res, buf, coff = into.fit(n, int(off[-1]) + 16)
+        res[:] = np.zeros(n, dtype=_lib.RESULT_DTYPE)
+        pos = 0
+        for i, (r, c) in enumerate(zip(ores, ocons)):
+            for f in ("status", "n_peaks", "n_sub", "has_front", "has_tail", "front_end", "tail_beg"):
+                res[i][f] = getattr(r, f)
+            res[i]["cons_len"] = len(c)
+            res[i]["sub_beg"][:r.n_sub] = r.sub_beg[:r.n_sub]
+            res[i]["sub_end"][:r.n_sub] = r.sub_end[:r.n_sub]
+            coff[i] = pos
+            buf[pos:pos + len(c)] = np.frombuffer(c.encode(), dtype=np.uint8)
+            pos += len(c)
+        coff[n] = pos
+        time.sleep(self.delays.random() * 0.03)
+        return res, buf, coff
+
+    def close(self):
+        pass
+
+
+def _run(tmp_path, tag, recs, n_dev, batch, monkeypatch):
+    out = str(tmp_path / tag) + "/"
+    os.makedirs(out)
+    fq = str(tmp_path / "reads.fastq")
+    if not os.path.exists(fq):
+        with open(fq, "w") as fh:
+            for r in recs:
+                fh.write("@%s\n%s\n+\n%s\n" % (r[0], r[1], r[2]))
+    monkeypatch.setattr(_lib, "Handle", FakeHandle)
+    monkeypatch.setenv("C3_GPU_BATCH_READS", str(batch))
+    args = types.SimpleNamespace(out_path=out, reads=fq, groupSize=1000, lencutoff=1000, mdistcutoff=500, zero=True,
+                                 compress_output=False)
+    sd = {"Splint1": [synth.SPLINT1, revcomp(synth.SPLINT1)]}
+    adapter = {r[0]: ["Splint1", r[3]] for r in recs}
+    n = stream.run(args, sd, adapter, {"Splint1"}, n_dev)
+    assert n == len(recs)
+    return (sorted(fastx_read(out + "Splint1/R2C2_Consensus.fasta")), sorted(fastx_read(out + "Splint1/R2C2_Subreads.fastq")))
+
+
+def test_three_workers_out_of_order_equal_one_worker(tmp_path, monkeypatch):
+    recs = list(synth.generate("cfg1", n_reads=60))
+    one = _run(tmp_path, "one", recs, 1, 1000, monkeypatch)
+    many = _run(tmp_path, "many", recs, 3, 4, monkeypatch)           # 15 batches over 3 workers
+    assert one == many
+    assert len(one[0]) == 60 and len({r[0] for r in one[1]}) == len(one[1])
+    # every subread record carries the bases of ITS read
+    byname = {r[0]: r for r in recs}
+    for name, seq, qual in many[1][::7]:
+        src = byname[name.rsplit("_", 1)[0]]
+        assert seq in src[1] and qual in src[2]
