@@ -477,10 +477,10 @@ static int run_poa(c3_handle* h) {
   if (cells > 0x7fffff00LL) cells = 0x7fffff00LL;
   const size_t N = (size_t)Ncap;
   const int NI = 26;      // int arrays of N (opn/opq count twice)
-  size_t per_slot = N * (NI * 4 + 8 + 5 + 32 + 4 * C3_JUMP_LEVELS) + N * K * 12 + (size_t)cells * 16;
+  size_t per_slot = N * (NI * 4 + 8 + 5 + 32 + 4 * C3_JUMP_LEVELS) + N * K * 12 + (size_t)cells * 17;
   const int slots = auto_slots(h, h->cfg.slots_poa, per_slot, nw, 24);
   HIPCHK(h->s_poa_i.ensure(sizeof(int) * N * NI * slots)); HIPCHK(h->s_poa_nk.ensure(sizeof(int) * N * K * 3 * slots));
-  HIPCHK(h->s_poa_cells.ensure((size_t)cells * 16 * slots)); HIPCHK(h->s_poa_b.ensure(N * 5 * slots)); HIPCHK(h->s_poa_sc.ensure(sizeof(long long) * N * slots));
+  HIPCHK(h->s_poa_cells.ensure((size_t)cells * 17 * slots)); HIPCHK(h->s_poa_b.ensure(N * 5 * slots)); HIPCHK(h->s_poa_sc.ensure(sizeof(long long) * N * slots));
   HIPCHK(h->s_poa_desc.ensure(sizeof(uint4) * 2 * N * slots));
   HIPCHK(h->s_poa_jump.ensure(sizeof(int) * C3_JUMP_LEVELS * N * slots));
   PoaArgs a; memset(&a, 0, sizeof(a));

@@ -16,7 +16,7 @@ struct PoaArgs {
   // per-slot scratch, one block per kind (the kernel derives every array from these bases: few live SGPRs):
   //   ibase: 23*Ncap ints  (n_in n_out grp order order2 index gfirst glast rem mpl mpr rbeg rend roff anchor col col2t nxt,
   //                          opn[2N] opq[2N] path[N])
-  //   ebase: 3*Ncap*K ints (in_from out_to out_w);  cellsb: 16*cells_cap bytes (H E1 E2 D);  bbase: 5*Ncap bytes (base rows2[4N])
+  //   ebase: 3*Ncap*K ints (in_from out_to out_w);  cellsb: 17*cells_cap bytes (H E1 E2 D + byte cells D8);  bbase: 5*Ncap bytes (base rows2[4N])
   int* ibase; int* ebase; char* cellsb; uint8_t* bbase; long long* score;
   int Ncap, K, Pcap, cells_cap;
   uint8_t* draft; int32_t* tpos; uint8_t* msa_dbg; const int64_t* msa_off; int* msa_len;

@@ -47,6 +47,25 @@ __device__ __forceinline__ int wave_shr1(int v, int carry) {
   return __builtin_amdgcn_update_dpp(carry, v, 0x138, 0xf, 0xf, false);
 }
 
+// value of lane+1; lane 63 receives `carry` (wave_shl:1)
+__device__ __forceinline__ int wave_shl1(int v, int carry) {
+  return __builtin_amdgcn_update_dpp(carry, v, 0x130, 0xf, 0xf, false);
+}
+
+// three independent inclusive max-scans, interleaved step by step: a DPP instruction reading a register written by the
+// previous VALU instruction needs two wait states, which the other two chains fill
+__device__ __forceinline__ void wave_scan_max3(int& a, int& b, int& c) {
+  const int ID = INT32_MIN;
+#define C3_SCAN_STEP(ctrl, rm) { \
+    const int ta = __builtin_amdgcn_update_dpp(ID, a, ctrl, rm, 0xf, false); \
+    const int tb = __builtin_amdgcn_update_dpp(ID, b, ctrl, rm, 0xf, false); \
+    const int tc = __builtin_amdgcn_update_dpp(ID, c, ctrl, rm, 0xf, false); \
+    a = max(a, ta); b = max(b, tb); c = max(c, tc); }
+  C3_SCAN_STEP(0x111, 0xf) C3_SCAN_STEP(0x112, 0xf) C3_SCAN_STEP(0x114, 0xf) C3_SCAN_STEP(0x118, 0xf)
+  C3_SCAN_STEP(0x142, 0xa) C3_SCAN_STEP(0x143, 0xc)
+#undef C3_SCAN_STEP
+}
+
 // inclusive max-scan over the 64 lanes (DPP row shifts + row broadcasts)
 __device__ __forceinline__ int wave_scan_max(int x) {
   const int ID = INT32_MIN;

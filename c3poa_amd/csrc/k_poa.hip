@@ -37,6 +37,7 @@ struct Ctx {
   __device__ __forceinline__ int32_t* E1() const { return (int32_t*)(C + 4 * (size_t)cells_cap); }
   __device__ __forceinline__ int32_t* E2() const { return (int32_t*)(C + 8 * (size_t)cells_cap); }
   __device__ __forceinline__ uint32_t* D() const { return (uint32_t*)(C + 12 * (size_t)cells_cap); }
+  __device__ __forceinline__ uint8_t* D8() const { return (uint8_t*)(C + 16 * (size_t)cells_cap); }     // 1-byte cells of the fast rows
   __device__ __forceinline__ uint8_t* base() const { return B8; }
   __device__ __forceinline__ uint8_t* rows2() const { return B8 + (size_t)Ncap; }
   __device__ __forceinline__ long long* score() const { return score_; }
@@ -113,6 +114,15 @@ __shared__ PoaLds L;     // file scope: accesses stay in the LDS address space (
 // direction word (device-internal): mp[0..7] | e1code[8..16] | e2code[17..25] | hts[26..27] | hs[28..29]
 // | f1x[30] | f2x[31];  e?code = 2*pred + ext;  hts: 0 M, 1 E1, 2 E2;  hs: 0 Ht, 1 F1, 2 F2
 
+// row offset as stored in rowm[3*idx+2]: rows with byte cells (fast rows) store ~offset
+__device__ __forceinline__ int ro_dec(int x) { return x < 0 ? ~x : x; }
+// byte cell of a fast row (single predecessor, ordinal 0) -> the 32-bit direction word of the general rows
+__device__ __forceinline__ unsigned dir_word_of_byte(unsigned b) {
+  const unsigned ext1 = (~b) & 1u, ext2 = ((~b) >> 1) & 1u;
+  const unsigned hts = 2u - ((b >> 2) & 3u), hs = 2u - ((b >> 4) & 3u);
+  return (ext1 << 8) | (ext2 << 17) | (hts << 26) | (hs << 28) | (((b >> 6) & 1u) << 30) | ((b >> 7) << 31);
+}
+
 __device__ void poa_build_desc(Ctx& c, int lane) {
   const int K = c.K, n = c.n;
   for (int idx = lane; idx < n; idx += 64) {
@@ -135,7 +145,8 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   const int K = c.K, n = c.n;
   const int mt9 = S9(P.poa_match), mm9 = S9(-P.poa_mismatch);
   const int e1_9 = S9(P.e1), e2_9 = S9(P.e2), o1_9 = S9(P.o1), o2_9 = S9(P.o2), oe1_9 = S9(P.o1 + P.e1), oe2_9 = S9(P.o2 + P.e2);
-  const int w = P.band_b + (int)(P.band_f * (double)Q);
+  const int w = wave_first(P.band_b + (int)(P.band_f * (double)Q));
+  const int le1 = e1_9 * lane, le2 = e2_9 * lane;                   // e*j = e*beg (scalar) + e*lane: no vector multiply per row
   // remaining length along the heaviest out-edge (first maximum in out-list order): list ranking by
   // pointer jumping, log2(n) parallel rounds instead of a serial reverse sweep
   {
@@ -177,6 +188,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   PH_MARK(0)
   int ncell = 0;
   int pv_idx = -9, pv_beg = 0, pv_end = -1, pv_left = 0, pv_right = 0, pv_inl = 0;   // previous row, kept in scalars
+  int pH = NEGS, pE1 = NEGS, pE2 = NEGS; bool pv_reg = false;                        // ... and its cells, lane = band column (rows of <= 64 cells)
   for (int ib = 0; ib < n; ib += 64) {
   uint4 dA = c.descA()[min(ib + lane, n - 1)], dB = c.descB()[min(ib + lane, n - 1)];
   asm volatile("" : "+v"(dA.x), "+v"(dA.y), "+v"(dA.z), "+v"(dB.x), "+v"(dB.y), "+v"(dB.z), "+v"(dB.w));   // wait here, not in the row loop
@@ -192,64 +204,69 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     const int p0 = __builtin_amdgcn_readlane(dB.x, li), p1 = __builtin_amdgcn_readlane(dB.y, li);
     const int p2 = __builtin_amdgcn_readlane(dB.z, li), p3 = __builtin_amdgcn_readlane(dB.w, li);
 #define PRED_IDX(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[v * K + (k)]])
-    // ---- FAST ROW: one predecessor = the previous row, still in the LDS ring, band fits one 64-lane chunk.
-    // Same arithmetic as the general path below, minus the predecessor loop, the tag bookkeeping
-    // (ordinal 0 everywhere) and every LDS metadata read (the previous row's band is in scalars).
-    if (nin == 1 && p0 == idx - 1 && pv_idx == idx - 1 && pv_inl && v != SRC) {
+    // ---- FAST ROW: one predecessor = the previous row, whose H/E1/E2 are still in this wave's REGISTERS (lane = band
+    // column), and the band moved right by at most two columns.  The predecessor cells arrive by DPP lane shifts (no LDS
+    // round trip on the dependent chain), the row maximum is taken from Ht in parallel with the two F scans (an F value
+    // is always strictly below some Ht to its left, so max H == max Ht and both are attained in the same columns), and
+    // every tie order is a tag in the low bits of the compared keys, so the direction cell is 1 byte of masked key bits:
+    //   bit0 E1 opened (0 = extended), bit1 E2 opened, bits2-3 Ht source (2 M, 1 E1, 0 E2), bits4-5 H source
+    //   (2 Ht, 1 F1, 0 F2), bit6 F1 extended, bit7 F2 extended.
+    if (qlds && nin == 1 && p0 == idx - 1 && pv_idx == idx - 1 && pv_reg && v != SRC) {
       const int qr = Q - remv;
       const int b = pv_beg, e = pv_end;
       const int mplv = e >= b ? pv_left + 1 : INT32_MAX / 2, mprv = e >= b ? pv_right + 1 : 0;
       int beg = max(max(0, min(mplv, qr) - w), b);
       int end = min(min(Q, max(mprv, qr) + w), e + 1);
       if (end < beg) end = beg - 1;
-      const int wd = end - beg + 1;
-      if (wd > 0 && wd <= 64) {
+      const int wd = end - beg + 1, sh = beg - b;
+      if (wd > 0 && wd <= 64 && sh <= 2) {
         if (ncell + wd > c.cells_cap) return -4;
-        const int slot = idx & (PR - 1), sl = (idx - 1) & (PR - 1);
+        const int slot = idx & (PR - 1);
         const int ro = ncell;
         ncell += wd;
-        const int j = beg + lane, o = j - b;
-        const bool act = j <= end;
-        // all LDS reads of the row are issued together on clamped (always valid) addresses and masked afterwards: inside
-        // their own `if`s each read gets its own s_waitcnt, three LDS round trips per row instead of one
-        const int oc = min(max(o, 0), PW - 1), om = min(max(o - 1, 0), PW - 1), jq = min(max(j - 1, 0), PQW * 16 - 1);
-        const int hd_ = L.H[sl][om], hp_ = L.H[sl][oc], e1_ = L.E1[sl][oc], e2_ = L.E2[sl][oc];
-        const unsigned qw_ = L.qpk[jq >> 4];
-        const bool inp = act && j <= e;
-        const int hd = (act && o >= 1) ? hd_ : NEGS, hp = inp ? hp_ : NEGS, e1p = inp ? e1_ : NEGS, e2p = inp ? e2_ : NEGS;
-        int qc = 7;
-        if (act && j > 0) qc = qlds ? (int)((qw_ >> ((jq & 15) * 2)) & 3) : c3_code_at(c.pk, qb + j - 1);
-        const int M9 = (j > 0) ? hd + ((vb == qc) ? mt9 : mm9) : NEGS;
-        const int a1 = hp - oe1_9, x1 = e1p - e1_9, a2 = hp - oe2_9, x2 = e2p - e2_9;
-        const int E1v = max(a1, x1), E2v = max(a2, x2);
-        const int k2 = max(max(M9 + 2, E1v + 1), E2v);
+        const int j = beg + lane;
+        const bool act = lane < wd;
+        // query base of column j (LDS copy; issued first, consumed after the shifts)
+        const int jq = max(j - 1, 0);
+        // (subreads longer than the LDS copy take the general row: a global load here would wait for every older store)
+        const unsigned qw_ = L.qpk[min(jq >> 4, PQW - 1)];
+        // previous row shifted to this row's columns: hp = H[i-1][j], hd = H[i-1][j-1]
+        int hd, hp, e1p, e2p;
+        if (sh == 1) { hd = pH; hp = wave_shl1(pH, NEGS); e1p = wave_shl1(pE1, NEGS); e2p = wave_shl1(pE2, NEGS); }
+        else if (sh == 0) { hd = wave_shr1(pH, NEGS); hp = pH; e1p = pE1; e2p = pE2; }
+        else { hd = wave_shl1(pH, NEGS); hp = wave_shl1(hd, NEGS); e1p = wave_shl1(wave_shl1(pE1, NEGS), NEGS); e2p = wave_shl1(wave_shl1(pE2, NEGS), NEGS); }
+        const int qc = (int)((qw_ >> ((jq & 15) * 2)) & 3);
+        const int M9 = hd + ((vb == qc) ? mt9 + 8 : mm9 + 8);                   // tag 2 in bits 2-3
+        const int E1t = max(hp - (oe1_9 - 1), e1p - e1_9);                     // bit 0 set: opened (open wins ties)
+        const int E2t = max(hp - (oe2_9 - 2), e2p - e2_9);                     // bit 1 set: opened
+        const int E1c = E1t & ~511, E2c = E2t & ~511;
+        const int k2 = max(max(M9, E1c + 4), E2c);
         const int ht9 = k2 & ~511;
-        unsigned d = ((unsigned)(x1 > a1) << 8) | ((unsigned)(x2 > a2) << 17) | ((unsigned)(2 - (k2 & 3)) << 26);
         const int htm = act ? ht9 : NEG2S;
-        const int s1 = wave_scan_max(htm + e1_9 * j), s2 = wave_scan_max(htm + e2_9 * j);
+        const int ej1 = le1 + e1_9 * beg, ej2 = le2 + e2_9 * beg;
+        int s1 = htm + ej1, s2 = htm + ej2, s3 = htm;
+        wave_scan_max3(s1, s2, s3);
         const int px1 = wave_shr1(s1, NEG2S), px2 = wave_shr1(s2, NEG2S);
         const int htl = wave_shr1(htm, NEGS);
-        int f1 = NEG2S, f2 = NEG2S; unsigned f1x = 0, f2x = 0;
-        if (lane != 0) {
-          f1 = px1 - o1_9 - e1_9 * j; f2 = px2 - o2_9 - e2_9 * j;
-          f1x = f1 != htl - oe1_9; f2x = f2 != htl - oe2_9;
-        }
-        const int k3 = max(max(ht9 + 2, f1 + 1), f2);
+        const int f1 = px1 - (o1_9 + ej1), f2 = px2 - (o2_9 + ej2);
+        const int k3 = max(max(ht9 + 32, f1 + 16), f2);
         const int h9 = k3 & ~511;
-        d |= ((unsigned)(2 - (k3 & 3)) << 28) | (f1x << 30) | (f2x << 31);
+        unsigned d = ((unsigned)E1t & 1u) | ((unsigned)E2t & 2u) | ((unsigned)k2 & 12u) | ((unsigned)k3 & 48u);
+        d |= (((unsigned)(htl - oe1_9 - f1)) >> 25) & 64u;                      // f1 > its "open" candidate: extended
+        d |= (((unsigned)(htl - oe2_9 - f2)) >> 24) & 128u;
+        pH = act ? h9 : NEGS; pE1 = act ? E1c : NEGS; pE2 = act ? E2c : NEGS;
         if (act) {
-          c.D()[ro + lane] = d;
-          L.H[slot][lane] = h9; L.E1[slot][lane] = E1v; L.E2[slot][lane] = E2v;
-          if (far) { c.H()[ro + lane] = h9; c.E1()[ro + lane] = E1v; c.E2()[ro + lane] = E2v; }
+          c.D8()[ro + lane] = (uint8_t)d;
+          L.H[slot][lane] = h9; L.E1[slot][lane] = E1c; L.E2[slot][lane] = E2c;
+          if (far) { c.H()[ro + lane] = h9; c.E1()[ro + lane] = E1c; c.E2()[ro + lane] = E2c; }
         }
-        const int hb = act ? h9 : INT32_MIN;
-        const int rb = wave_max(hb);
+        const int rb = __builtin_amdgcn_readlane(s3, 63);
         // first / last column holding the row maximum: columns are beg + lane, so one ballot replaces two reductions
-        const unsigned long long mxm = __ballot(hb == rb);
+        const unsigned long long mxm = __ballot(htm == rb);
         const int left = beg + __builtin_ctzll(mxm), right = beg + 63 - __builtin_clzll(mxm);
         if (lane == 0) {
           L.beg[slot] = beg; L.end[slot] = end; L.rl[slot] = left; L.rr[slot] = right; L.inl[slot] = 1;
-          { int* rm = c.rowm() + 3 * idx; rm[0] = beg; rm[1] = end; rm[2] = ro; }
+          { int* rm = c.rowm() + 3 * idx; rm[0] = beg; rm[1] = end; rm[2] = ~ro; }       // ~ro: byte cells
           if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
         }
         pv_idx = idx; pv_beg = beg; pv_end = end; pv_left = left; pv_right = right; pv_inl = 1;
@@ -278,6 +295,9 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       end = min(Q, max(mprv, qr) + w);
       beg = max(beg, minb); end = min(end, maxe);
     }
+    // the band comes out of LDS / global loads the compiler cannot see are uniform: pin it to scalars, or every
+    // loop-carried row descriptor (and the fast row's band arithmetic and branches) turns into vector code
+    beg = wave_first(beg); end = wave_first(end);
     if (end < beg) end = beg - 1;
     const int wd = end - beg + 1;
     if (ncell + wd > c.cells_cap) return -4;
@@ -288,6 +308,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     int best = INT32_MIN, bl = 0, br = 0;        // per-lane running row maximum
     int carry1 = NEG2S, carry2 = NEG2S;          // scan carries over previous chunks
     int prev_ht = NEGS;
+    int gH = NEGS, gE1 = NEGS, gE2 = NEGS;       // the row's cells (first chunk) for a fast successor
     for (int c0 = 0; c0 < wd; c0 += 64) {
       const int j = beg + c0 + lane;
       const bool act = j <= end;
@@ -307,7 +328,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
             int b = L.beg[sl], e = L.end[sl];                                  // see the note above: no pointer select
             asm volatile("" : "+v"(b), "+v"(e));
             if (idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1]; }
-            const int po = c.rowm()[3 * pi + 2];
+            const int po = ro_dec(c.rowm()[3 * pi + 2]);
             if (j > 0 && j - 1 >= b && j - 1 <= e) hd = c.H()[po + (j - 1 - b)];
             if (j >= b && j <= e) { hp = c.H()[po + (j - b)]; e1p = c.E1()[po + (j - b)]; e2p = c.E2()[po + (j - b)]; }
           }
@@ -340,6 +361,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       const int k3 = max(max(ht9 + 2, f1 + 1), f2);
       const int h9 = k3 & ~511;
       d |= ((unsigned)(2 - (k3 & 3)) << 28) | (f1x << 30) | (f2x << 31);
+      if (c0 == 0) { gH = act ? h9 : NEGS; gE1 = act ? E1v : NEGS; gE2 = act ? E2v : NEGS; }
       if (act) {
         const int ci = c0 + lane;
         c.D()[ro + ci] = d;
@@ -355,12 +377,14 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       left = wave_min(best == rb ? bl : INT32_MAX / 2);
       right = wave_max(best == rb ? br : -1);
     }
+    left = wave_first(left); right = wave_first(right);
     if (lane == 0) {
       L.beg[slot] = beg; L.end[slot] = end; L.rl[slot] = left; L.rr[slot] = right; L.inl[slot] = inl;
       { int* rm = c.rowm() + 3 * idx; rm[0] = beg; rm[1] = end; rm[2] = ro; }
       if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
     }
     pv_idx = idx; pv_beg = beg; pv_end = end; pv_left = left; pv_right = right; pv_inl = inl;
+    pH = gH; pE1 = gE1; pE2 = gE2; pv_reg = wd <= 64;
   }
   }
   WSYNC();
@@ -370,7 +394,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   int bi = -1, bs = INT32_MIN;
   for (int k = 0; k < c.n_in()[SNK]; ++k) {
     const int pi = c.index()[c.in_from()[SNK * K + k]];
-    const int hh = (Q < c.rowm()[3 * pi] || Q > c.rowm()[3 * pi + 1]) ? NEGS : c.H()[c.rowm()[3 * pi + 2] + (Q - c.rowm()[3 * pi])];
+    const int hh = (Q < c.rowm()[3 * pi] || Q > c.rowm()[3 * pi + 1]) ? NEGS : c.H()[ro_dec(c.rowm()[3 * pi + 2]) + (Q - c.rowm()[3 * pi])];
     if (hh > bs) { bs = hh; bi = pi; }
   }
   if (bi < 0 || bs <= NEGS / 2) return -1;
@@ -389,10 +413,11 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     while (!(i == 0 && j == 0)) {
       const int ik = i - lane, jk = j - lane;
       const int ic = max(ik, 0);
-      const int b = c.rowm()[3 * ic], e = c.rowm()[3 * ic + 1], ro = c.rowm()[3 * ic + 2];
+      const int b = c.rowm()[3 * ic], e = c.rowm()[3 * ic + 1], roe = c.rowm()[3 * ic + 2];
       const uint4 A = c.descA()[ic], B = c.descB()[ic];
       const bool inb = ik >= 0 && jk >= b && jk <= e;
-      const unsigned d = inb ? c.D()[ro + (jk - b)] : 0u;
+      unsigned d = 0u;
+      if (inb) d = roe < 0 ? dir_word_of_byte(c.D8()[~roe + (jk - b)]) : c.D()[roe + (jk - b)];
       int m = 0;
       if (st == 0 && i > 0 && j > 0) {
         const int mp = d & 0xff;
@@ -546,7 +571,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
   Ctx c;
   const size_t N = (size_t)a.Ncap;
   c.I = a.ibase + (size_t)slot * 23 * N; c.E = a.ebase + (size_t)slot * 3 * N * a.K;
-  c.C = a.cellsb + (size_t)slot * 16 * (size_t)a.cells_cap; c.B8 = a.bbase + (size_t)slot * 5 * N;
+  c.C = a.cellsb + (size_t)slot * 17 * (size_t)a.cells_cap; c.B8 = a.bbase + (size_t)slot * 5 * N;
   c.score_ = a.score + (size_t)slot * N; c.desc_ = a.desc + (size_t)slot * 2 * N; c.jump_ = a.jump + (size_t)slot * C3_JUMP_LEVELS * N;
   c.K = a.K; c.Ncap = a.Ncap; c.cells_cap = a.cells_cap;
   PH_DECL
@@ -580,7 +605,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
       g_blocks(c, lane);
       int poff = 0;
       for (int s = 0; s < ns && !fail; ++s) {
-        const int qb = info->sub_beg[s], Q = info->sub_end[s] - qb;
+        const int qb = wave_first(info->sub_beg[s]), Q = wave_first(info->sub_end[s]) - qb;
         if (s > 0) { if (poa_align(c, a.p, qb, Q, lane, &cells PHP) < 0) { fail = 1; break; } }
         if (poa_fuse(c, s == 0, qb, Q, c.path() + poff, lane PHP) < 0) { fail = 1; break; }
         poff += Q;
