@@ -116,7 +116,8 @@ struct c3_handle {
   int n = 0; int64_t total = 0, words = 0, maxL = 0; std::vector<int64_t> off, woff;
   DBuf d_ascii, d_pk, d_woff, d_qual, d_off, d_strand, d_sid, d_info, d_track, d_draft, d_tpos, d_cons, d_counter, d_gather, d_gather_off;
   DBuf d_raw, d_nraw, d_sum, d_work, d_bufA, d_bufB, d_cand, d_cst, d_msa, d_msa_off, d_msa_len;
-  DBuf s_poa_i, s_poa_nk, s_poa_cells, s_poa_b, s_poa_sc, s_poa_desc, s_poa_jump;      // POA scratch
+  DBuf s_poa_i, s_poa_nk, s_poa_cells, s_poa_b, s_poa_sc, s_poa_desc, s_poa_jump, s_poa_path, d_overflow;      // POA scratch
+  int n_poa_redo = 0;        // reads of the last run that needed the full-size second POA pass
   DBuf s_eH, s_eD, s_lw, d_wrec, d_wlay, d_wbase, d_wout;       // prep / windows
   DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc;
   DBuf s_zero_d, d_zinfo, d_zflag, d_zwork; std::vector<int> zwork;  // window scratch
@@ -187,7 +188,7 @@ extern "C" void c3_destroy(c3_handle* h) {
   DBuf* all[] = {&h->d_sp_codes, &h->d_sp_len, &h->d_ascii, &h->d_pk, &h->d_woff, &h->d_qual, &h->d_off, &h->d_strand, &h->d_sid,
                  &h->d_info, &h->d_track, &h->d_draft, &h->d_tpos, &h->d_cons, &h->d_counter, &h->d_raw, &h->d_nraw, &h->d_sum,
                  &h->d_work, &h->d_bufA, &h->d_bufB, &h->d_cand, &h->d_cst, &h->d_msa, &h->d_msa_off, &h->d_msa_len,
-                 &h->s_poa_i, &h->s_poa_nk, &h->s_poa_cells, &h->s_poa_b, &h->s_poa_sc, &h->s_poa_desc, &h->s_poa_jump, &h->s_eH, &h->s_eD, &h->s_lw, &h->d_wrec,
+                 &h->s_poa_i, &h->s_poa_nk, &h->s_poa_cells, &h->s_poa_b, &h->s_poa_sc, &h->s_poa_desc, &h->s_poa_jump, &h->s_poa_path, &h->d_overflow, &h->s_eH, &h->s_eD, &h->s_lw, &h->d_wrec,
                  &h->d_wlay, &h->d_wbase, &h->d_wout, &h->s_win_i, &h->s_win_nk, &h->s_win_h, &h->s_win_d, &h->s_win_b, &h->s_win_sc, &h->s_win_desc, &h->s_zero_d, &h->d_zinfo, &h->d_zflag, &h->d_zwork, &h->d_gather, &h->d_gather_off};
   for (DBuf* b : all) b->release();
   { DBuf* sh[] = {&h->st.d_ascii, &h->st.d_pk, &h->st.d_woff, &h->st.d_qual, &h->st.d_off, &h->st.d_strand, &h->st.d_sid}; for (DBuf* b : sh) b->release(); }
@@ -462,6 +463,39 @@ static int fetch_summary(c3_handle* h) {
   return 0;
 }
 
+// one launch of k_poa over `nw` reads of `d_work` with the given capacities
+static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, int Pcap, long long cells, int* d_overflow, int waves_per_cu) {
+  const size_t N = (size_t)Ncap;
+  const int NI = 18;      // int arrays of N (c3_args.h)
+  cells = (cells + 15) & ~15LL;                   // every per-slot arena (18 bytes per cell) starts 16-byte aligned
+  const size_t per_slot = N * (NI * 4 + 8 + 5 + 32 + 4 * C3_JUMP_LEVELS) + N * K * 12 + (size_t)cells * 18 + (size_t)Pcap * 4;
+  const int slots = auto_slots(h, h->cfg.slots_poa, per_slot, nw, waves_per_cu);
+  HIPCHK(h->s_poa_i.ensure(sizeof(int) * N * NI * slots)); HIPCHK(h->s_poa_nk.ensure(sizeof(int) * N * K * 3 * slots));
+  HIPCHK(h->s_poa_cells.ensure((size_t)cells * 18 * slots + 256)); HIPCHK(h->s_poa_b.ensure(N * 5 * slots)); HIPCHK(h->s_poa_sc.ensure(sizeof(long long) * N * slots));
+  HIPCHK(h->s_poa_desc.ensure(sizeof(uint4) * 2 * N * slots));
+  HIPCHK(h->s_poa_jump.ensure(sizeof(int) * C3_JUMP_LEVELS * N * slots));
+  HIPCHK(h->s_poa_path.ensure(sizeof(int) * (size_t)Pcap * slots));
+  PoaArgs a; memset(&a, 0, sizeof(a));
+  a.b = dev_batch(h); a.info = h->d_info.as<C3Info>(); a.p = dev_params(h->cfg);
+  a.counter = h->d_counter.as<int>(); a.work = d_work; a.n_work = nw;
+  a.ibase = h->s_poa_i.as<int>(); a.ebase = h->s_poa_nk.as<int>(); a.cellsb = h->s_poa_cells.as<char>();
+  a.bbase = h->s_poa_b.as<uint8_t>(); a.score = h->s_poa_sc.as<long long>();
+  a.Ncap = Ncap; a.K = K; a.Pcap = Pcap; a.cells_cap = (int)cells; a.desc = h->s_poa_desc.as<uint4>(); a.jump = h->s_poa_jump.as<int>();
+  a.pbase = h->s_poa_path.as<int>(); a.overflow = d_overflow;
+  a.draft = h->d_draft.as<uint8_t>(); a.tpos = h->d_tpos.as<int32_t>();
+  a.msa_dbg = nullptr; a.msa_off = nullptr; a.msa_len = nullptr;
+  if (h->debug_msa) { a.msa_dbg = h->d_msa.as<uint8_t>(); a.msa_off = h->d_msa_off.as<int64_t>(); a.msa_len = h->d_msa_len.as<int>(); }
+  a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
+  DBG("poa: nw=%d Ncap=%d K=%d cells=%lld slots=%d (%.1f MB per slot)%s\n", nw, Ncap, K, cells, slots, per_slot / 1048576.0, d_overflow ? "" : " [full-size pass]");
+  c3k_launch_poa(&a, slots, h->stream);
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// K3 over the work list.  The per-slot scratch (graph arrays, DP cells) is sized for the TYPICAL alignment of the batch --
+// small slots mean more resident waves, and the DP kernels live on resident waves -- and the few reads that overflow it
+// (ragged subread lengths widen the adaptive band; long insertions add nodes) are queued by the kernel and redone by a
+// second launch with worst-case scratch, so no read is ever lost to the smaller first-pass capacity.
 static int run_poa(c3_handle* h) {
   const int nw = (int)h->work.size();
   HIPCHK(h->d_draft.ensure((size_t)h->total + 64)); HIPCHK(h->d_tpos.ensure(sizeof(int32_t) * (size_t)h->total + 64));
@@ -470,27 +504,17 @@ static int run_poa(c3_handle* h) {
   if (nw == 0) return 0;
   int max_sum = 0, max_ns = 0, max_q = 0;
   for (int i : h->work) { max_sum = std::max(max_sum, h->sum[i].sum_sub); max_ns = std::max(max_ns, h->sum[i].n_sub); max_q = std::max(max_q, h->sum[i].max_sub); }
-  const int Ncap = max_sum + 8, K = max_ns + 1, Pcap = max_sum + 8;
+  const int Ncap_full = max_sum + 8, K = max_ns + 1, Pcap = max_sum + 8;
   const int w = h->cfg.poa_band_b + (int)(h->cfg.poa_band_f * max_q);
-  long long cells = (long long)(2 * max_q + 2) * (2 * w + 1 + max_q / 5);
-  if (max_ns < 2) cells = 64;
-  if (cells > 0x7fffff00LL) cells = 0x7fffff00LL;
-  const size_t N = (size_t)Ncap;
-  const int NI = 26;      // int arrays of N (opn/opq count twice)
-  size_t per_slot = N * (NI * 4 + 8 + 5 + 32 + 4 * C3_JUMP_LEVELS) + N * K * 12 + (size_t)cells * 17;
-  const int slots = auto_slots(h, h->cfg.slots_poa, per_slot, nw, 24);
-  HIPCHK(h->s_poa_i.ensure(sizeof(int) * N * NI * slots)); HIPCHK(h->s_poa_nk.ensure(sizeof(int) * N * K * 3 * slots));
-  HIPCHK(h->s_poa_cells.ensure((size_t)cells * 17 * slots)); HIPCHK(h->s_poa_b.ensure(N * 5 * slots)); HIPCHK(h->s_poa_sc.ensure(sizeof(long long) * N * slots));
-  HIPCHK(h->s_poa_desc.ensure(sizeof(uint4) * 2 * N * slots));
-  HIPCHK(h->s_poa_jump.ensure(sizeof(int) * C3_JUMP_LEVELS * N * slots));
-  PoaArgs a; memset(&a, 0, sizeof(a));
-  a.b = dev_batch(h); a.info = h->d_info.as<C3Info>(); a.p = dev_params(h->cfg);
-  a.counter = h->d_counter.as<int>(); a.work = h->d_work.as<int>(); a.n_work = nw;
-  a.ibase = h->s_poa_i.as<int>(); a.ebase = h->s_poa_nk.as<int>(); a.cellsb = h->s_poa_cells.as<char>();
-  a.bbase = h->s_poa_b.as<uint8_t>(); a.score = h->s_poa_sc.as<long long>();
-  a.Ncap = Ncap; a.K = K; a.Pcap = Pcap; a.cells_cap = (int)cells; a.desc = h->s_poa_desc.as<uint4>(); a.jump = h->s_poa_jump.as<int>();
-  a.draft = h->d_draft.as<uint8_t>(); a.tpos = h->d_tpos.as<int32_t>();
-  a.msa_dbg = nullptr; a.msa_off = nullptr; a.msa_len = nullptr;
+  long long cells_full = (long long)(2 * max_q + 2) * (2 * w + 1 + max_q / 5);
+  if (max_ns < 2) cells_full = 64;
+  if (cells_full > 0x7fffff00LL) cells_full = 0x7fffff00LL;
+  // typical need: every further subread adds ~12 % nodes (mismatch siblings + insertions) to a graph of max_q nodes; a row
+  // holds 2w+1 cells plus the drift between the row's nominal column and the argmax of its predecessors
+  const double nodes_typ = (double)max_q * (1.0 + 0.15 * std::max(0, max_ns - 1));
+  int Ncap = (int)std::min<double>(Ncap_full, 1.3 * nodes_typ + 256);
+  long long cells = std::min<long long>(cells_full, (long long)(1.5 * nodes_typ * (2 * w + 12)) + 4096);
+  if (const char* e_ = getenv("C3_DEBUG_POA_SMALL")) { Ncap = std::min(Ncap_full, std::max(64, atoi(e_))); cells = std::min<long long>(cells_full, 16LL * Ncap); }   // test hook: forces the second pass
   if (h->debug_msa) {
     std::vector<int64_t> mo(h->n + 1, 0);
     for (int i = 0; i < h->n; ++i) mo[i + 1] = mo[i] + (int64_t)h->sum[i].n_sub * (h->sum[i].sum_sub + 2);
@@ -498,13 +522,24 @@ static int run_poa(c3_handle* h) {
     HIPCHK(hipMemcpyAsync(h->d_msa_off.p, mo.data(), sizeof(int64_t) * (h->n + 1), hipMemcpyHostToDevice, h->stream));
     HIPCHK(hipMemsetAsync(h->d_msa_len.p, 0, sizeof(int) * h->n, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
-    a.msa_dbg = h->d_msa.as<uint8_t>(); a.msa_off = h->d_msa_off.as<int64_t>(); a.msa_len = h->d_msa_len.as<int>();
   }
+  HIPCHK(h->d_overflow.ensure(sizeof(int) * (size_t)nw));
   HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));                       // work queue only: [2..3] already holds the zero-repeat cells
-  HIPCHK(hipMemsetAsync(h->d_counter.as<char>() + 64, 0, 192, h->stream));
-  a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
-  c3k_launch_poa(&a, slots, h->stream);
-  HIPCHK(hipGetLastError());
+  HIPCHK(hipMemsetAsync(h->d_counter.as<char>() + 16, 0, 240, h->stream));       // [4] overflow count, phase counters
+  const bool two_pass = Ncap < Ncap_full || cells < cells_full;
+  int rc = launch_poa(h, h->d_work.as<int>(), nw, Ncap, K, Pcap, cells, two_pass ? h->d_overflow.as<int>() : nullptr, 24);
+  if (rc) return rc;
+  h->n_poa_redo = 0;
+  if (two_pass) {
+    int cnt[8];
+    HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 32, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    if (cnt[4] > 0) {
+      h->n_poa_redo = cnt[4];
+      HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
+      if ((rc = launch_poa(h, h->d_overflow.as<int>(), cnt[4], Ncap_full, K, Pcap, cells_full, nullptr, 24))) return rc;
+    }
+  }
   if (!h->zwork.empty()) {             // zero-repeat rescue, second half: stitch left + overlap consensus + right
     ZeroArgs z; fill_zero_args(h, z, (int)h->zwork.size());
     c3k_launch_zero_finish(&z, std::min((int)h->zwork.size(), 512), h->stream);
@@ -636,6 +671,7 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
       HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 64, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       if (!h->work.empty()) h->tm.cells_poa = *(long long*)(cnt + 2);
+      h->tm.n_poa_redo = h->n_poa_redo;
       DBG("run: poa done\n");
       HIPCHK(hipEventElapsedTime(&ms, t3, t4)); h->tm.ms_poa = ms;
     }

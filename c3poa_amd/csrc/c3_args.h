@@ -14,13 +14,14 @@ struct PeaksArgs {
 struct PoaArgs {
   C3Batch b; C3Info* info; C3Params p; int* counter; const int* work; int n_work;
   // per-slot scratch, one block per kind (the kernel derives every array from these bases: few live SGPRs):
-  //   ibase: 23*Ncap ints  (n_in n_out grp order order2 index gfirst glast rem mpl mpr rbeg rend roff anchor col col2t nxt,
-  //                          opn[2N] opq[2N] path[N])
-  //   ebase: 3*Ncap*K ints (in_from out_to out_w);  cellsb: 17*cells_cap bytes (H E1 E2 D + byte cells D8);  bbase: 5*Ncap bytes (base rows2[4N])
+  //   ibase: 18*Ncap ints  (n_in n_out grp order order2 index gfirst glast rem mpl mpr rowm[3N] anchor col col2t nxt)
+  //   ebase: 3*Ncap*K ints (in_from out_to out_w);  cellsb: 18*cells_cap bytes (H E1 E2, 32-bit cells D, direction bytes D8, predecessor bytes P8);  bbase: 5*Ncap bytes (base rows2[4N])
   int* ibase; int* ebase; char* cellsb; uint8_t* bbase; long long* score;
   int Ncap, K, Pcap, cells_cap;
   uint8_t* draft; int32_t* tpos; uint8_t* msa_dbg; const int64_t* msa_off; int* msa_len;
   unsigned long long* phases; uint4* desc; int* jump;
+  int* pbase;               // [slots][Pcap] node of every fused base
+  int* overflow;            // first pass: reads whose scratch overflowed (count in counter[4]); nullptr in the final pass
 };
 struct WLayer { int qbeg, len, begin, end; };
 struct WinRec { int rid, w, n_layers, blen, tgs, out_len, polished, pad_; };

@@ -15,6 +15,7 @@
 #include "c3_args.h"
 
 #define WSYNC() __syncthreads()
+#define C3_POA_NI 18       // int arrays of Ncap per slot in Ctx::I
 #define SRC 0
 #define SNK 1
 
@@ -22,13 +23,13 @@
 // Per-slot scratch of k_poa.  Only a few base pointers are kept live; every array is base + constant multiple of Ncap
 // (or Ncap*K, cells_cap), which keeps the uniform state in SGPRs instead of spilling it into VGPR lanes.
 struct Ctx {
-  int* I; int* E; char* C; uint8_t* B8; long long* score_; uint4* desc_; int* jump_;
+  int* I; int* E; char* C; uint8_t* B8; long long* score_; uint4* desc_; int* jump_; int* path_;
   int K, n, Ncap, cells_cap;
   const uint32_t* pk;        // packed read
 #define CTX_I(name, k) __device__ __forceinline__ int* name() const { return I + (size_t)(k) * Ncap; }
   CTX_I(n_in, 0) CTX_I(n_out, 1) CTX_I(grp, 2) CTX_I(order, 3) CTX_I(order2, 4) CTX_I(index, 5) CTX_I(gfirst, 6) CTX_I(glast, 7)
   CTX_I(rem, 8) CTX_I(mpl, 9) CTX_I(mpr, 10) CTX_I(rowm, 11) /* 3 ints per row: band begin, band end, cell offset (blocks 11..13) */ CTX_I(anchor, 14) CTX_I(col, 15)
-  CTX_I(col2t, 16) CTX_I(nxt, 17) CTX_I(opn, 18) CTX_I(opq, 20) CTX_I(path, 22)
+  CTX_I(col2t, 16) CTX_I(nxt, 17)
 #undef CTX_I
   __device__ __forceinline__ int* in_from() const { return E; }
   __device__ __forceinline__ int* out_to() const { return E + (size_t)Ncap * K; }
@@ -37,13 +38,15 @@ struct Ctx {
   __device__ __forceinline__ int32_t* E1() const { return (int32_t*)(C + 4 * (size_t)cells_cap); }
   __device__ __forceinline__ int32_t* E2() const { return (int32_t*)(C + 8 * (size_t)cells_cap); }
   __device__ __forceinline__ uint32_t* D() const { return (uint32_t*)(C + 12 * (size_t)cells_cap); }
-  __device__ __forceinline__ uint8_t* D8() const { return (uint8_t*)(C + 16 * (size_t)cells_cap); }     // 1-byte cells of the fast rows
+  __device__ __forceinline__ uint8_t* D8() const { return (uint8_t*)(C + 16 * (size_t)cells_cap); }     // direction bytes (rows of <= 4 predecessors)
+  __device__ __forceinline__ uint8_t* P8() const { return (uint8_t*)(C + 17 * (size_t)cells_cap); }     // predecessor bytes (rows of 2..4 predecessors)
   __device__ __forceinline__ uint8_t* base() const { return B8; }
   __device__ __forceinline__ uint8_t* rows2() const { return B8 + (size_t)Ncap; }
   __device__ __forceinline__ long long* score() const { return score_; }
   __device__ __forceinline__ uint4* descA() const { return desc_; }
   __device__ __forceinline__ uint4* descB() const { return desc_ + (size_t)Ncap; }
   __device__ __forceinline__ int* jump() const { return jump_; }
+  __device__ __forceinline__ int* path() const { return path_; }     // node of every base fused so far: Pcap = sum of the subread lengths
 };
 
 __device__ __forceinline__ void g_add_edge(Ctx& c, int u, int v, int w) {
@@ -102,7 +105,7 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 #define PW 128      // ring slot width (cells)
 #define PR 4        // ring rows
 #define PQW 112     // packed query words kept in LDS (1792 bases); longer subreads read the packed read
-struct PoaLds { int H[PR][PW], E1[PR][PW], E2[PR][PW]; int beg[PR], end[PR], rl[PR], rr[PR], inl[PR]; unsigned qpk[PQW]; };
+struct PoaLds { int H[PR][PW], E1[PR][PW], E2[PR][PW]; int4 meta[PR] /* band begin, end, leftmost / rightmost argmax */; unsigned qpk[PQW]; };
 __shared__ PoaLds L;     // file scope: accesses stay in the LDS address space (ds_*, lgkmcnt only)
 
 // scores are carried as score*512 (+ a 9-bit tag while candidates compete): one v_max per candidate
@@ -114,16 +117,7 @@ __shared__ PoaLds L;     // file scope: accesses stay in the LDS address space (
 // direction word (device-internal): mp[0..7] | e1code[8..16] | e2code[17..25] | hts[26..27] | hs[28..29]
 // | f1x[30] | f2x[31];  e?code = 2*pred + ext;  hts: 0 M, 1 E1, 2 E2;  hs: 0 Ht, 1 F1, 2 F2
 
-// row offset as stored in rowm[3*idx+2]: rows with byte cells (fast rows) store ~offset
-__device__ __forceinline__ int ro_dec(int x) { return x < 0 ? ~x : x; }
-// byte cell of a fast row (single predecessor, ordinal 0) -> the 32-bit direction word of the general rows
-__device__ __forceinline__ unsigned dir_word_of_byte(unsigned b) {
-  const unsigned ext1 = (~b) & 1u, ext2 = ((~b) >> 1) & 1u;
-  const unsigned hts = 2u - ((b >> 2) & 3u), hs = 2u - ((b >> 4) & 3u);
-  return (ext1 << 8) | (ext2 << 17) | (hts << 26) | (hs << 28) | (((b >> 6) & 1u) << 30) | ((b >> 7) << 31);
-}
-
-__device__ void poa_build_desc(Ctx& c, int lane) {
+__device__ void poa_build_desc(Ctx& c, int lane, int Q, bool qlds) {
   const int K = c.K, n = c.n;
   for (int idx = lane; idx < n; idx += 64) {
     const int v = c.order()[idx];
@@ -132,7 +126,10 @@ __device__ void poa_build_desc(Ctx& c, int lane) {
     for (int k = 0; k < nin && k < 4; ++k) p[k] = (unsigned)c.index()[c.in_from()[v * K + k]];
     unsigned far = 0;
     for (int k = 0; k < c.n_out()[v]; ++k) { const int t = c.out_to()[v * K + k]; if (t == SNK || c.index()[t] - idx > PR - 1) far = 1; }
-    uint4 A; A.x = (unsigned)v; A.y = (unsigned)c.rem()[v]; A.z = (unsigned)c.base()[v] | ((unsigned)min(nin, 255) << 8) | (far << 16) | ((unsigned)(nin > 4) << 17); A.w = 0;
+    uint4 A; A.x = (unsigned)v; A.y = (unsigned)c.rem()[v]; A.z = (unsigned)c.base()[v] | ((unsigned)min(nin, 255) << 8) | (far << 16) | ((unsigned)(nin > 4) << 17);
+    // bit 18: candidate for the fast row (one predecessor, the row above; query in LDS); bit 19: the sink (no DP row)
+    A.z |= ((unsigned)(qlds && nin == 1 && (int)p[0] == idx - 1 && v != SRC && v != SNK) << 18) | ((unsigned)(v == SNK) << 19);
+    A.w = (unsigned)(Q - c.rem()[v]);                    // qr: the query column this node would sit on by distance to the sink
     uint4 B; B.x = p[0]; B.y = p[1]; B.z = p[2]; B.w = p[3];
     c.descA()[idx] = A; c.descB()[idx] = B;
   }
@@ -146,7 +143,8 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   const int mt9 = S9(P.poa_match), mm9 = S9(-P.poa_mismatch);
   const int e1_9 = S9(P.e1), e2_9 = S9(P.e2), o1_9 = S9(P.o1), o2_9 = S9(P.o2), oe1_9 = S9(P.o1 + P.e1), oe2_9 = S9(P.o2 + P.e2);
   const int w = wave_first(P.band_b + (int)(P.band_f * (double)Q));
-  const int le1 = e1_9 * lane, le2 = e2_9 * lane;                   // e*j = e*beg (scalar) + e*lane: no vector multiply per row
+  const int le1 = e1_9 * lane, le2 = e2_9 * lane;                   // the F scans run in lane coordinates: e*(j-beg) = e*lane
+  const int lo1 = le1 + o1_9, lo2 = le2 + o2_9;
   // remaining length along the heaviest out-edge (first maximum in out-list order): list ranking by
   // pointer jumping, log2(n) parallel rounds instead of a serial reverse sweep
   {
@@ -173,10 +171,10 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     WSYNC();
     if (dB != c.rem()) { for (int v = lane; v < n; v += 64) c.rem()[v] = dB[v]; WSYNC(); }
   }
-  poa_build_desc(c, lane);
+  const bool qlds = Q <= PQW * 16;
+  poa_build_desc(c, lane, Q, qlds);
   // the subread, 2-bit packed and re-aligned to its first base, goes to LDS: the row loop must not
   // touch global memory for it (a vector load would wait for every older row store)
-  const bool qlds = Q <= PQW * 16;
   if (qlds) {
     for (int i = lane; i * 16 < Q; i += 64) {
       const long long b0 = (long long)qb + 16 * i;
@@ -186,55 +184,59 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   }
   WSYNC();
   PH_MARK(0)
-  int ncell = 0;
-  int pv_idx = -9, pv_beg = 0, pv_end = -1, pv_left = 0, pv_right = 0, pv_inl = 0;   // previous row, kept in scalars
-  int pH = NEGS, pE1 = NEGS, pE2 = NEGS; bool pv_reg = false;                        // ... and its cells, lane = band column (rows of <= 64 cells)
+  // Row loop.  The scalar ALU is ONE per CU (measured: 0.96 scalar instructions per cycle per CU against 1.5-1.7 vector
+  // instructions; DPP forms at half the vector rate), so uniform per-row values -- the previous row's band and argmax span, the
+  // cell counter -- live in VECTOR registers (every lane holds the same number) and the band arithmetic runs on the vector
+  // ALU; the scalar unit only sees the loop, one descriptor test and two branches per row.
+  int u_beg = 0, u_end = -1, u_left = 0, u_right = 0, u_ncell = 0;                    // previous row / cells used so far
+  int pH = NEGS, pE1 = NEGS, pE2 = NEGS;                                              // its cells, lane = band column
+  bool pv_ok = false;                                                                  // ... valid: the row above, <= 64 cells
+  const int lane4 = lane * 4;
+#define UNI(x) asm volatile("" : "+v"(x))       /* keep a uniform value in a vector register (no instruction) */
+#ifdef C3_PHASE_PROF
+  unsigned long long row_t0 = __builtin_readcyclecounter();
+#endif
   for (int ib = 0; ib < n; ib += 64) {
   uint4 dA = c.descA()[min(ib + lane, n - 1)], dB = c.descB()[min(ib + lane, n - 1)];
-  asm volatile("" : "+v"(dA.x), "+v"(dA.y), "+v"(dA.z), "+v"(dB.x), "+v"(dB.y), "+v"(dB.z), "+v"(dB.w));   // wait here, not in the row loop
+  asm volatile("" : "+v"(dA.x), "+v"(dA.y), "+v"(dA.z), "+v"(dA.w), "+v"(dB.x), "+v"(dB.y), "+v"(dB.z), "+v"(dB.w));   // wait here, not in the row loop
   const int cnt = min(64, n - ib);
   for (int li = 0; li < cnt; ++li) {
     const int idx = ib + li;
-    const int v = __builtin_amdgcn_readlane(dA.x, li);
-    if (v == SNK) continue;
-    const int remv = __builtin_amdgcn_readlane(dA.y, li);
     const int fl = __builtin_amdgcn_readlane(dA.z, li);
-    const int vb = fl & 0xff, nin = (fl >> 8) & 0xff;
-    const bool far = (fl >> 16) & 1, ovf = (fl >> 17) & 1;
-    const int p0 = __builtin_amdgcn_readlane(dB.x, li), p1 = __builtin_amdgcn_readlane(dB.y, li);
-    const int p2 = __builtin_amdgcn_readlane(dB.z, li), p3 = __builtin_amdgcn_readlane(dB.w, li);
-#define PRED_IDX(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[v * K + (k)]])
+    if ((fl >> 19) & 1) { pv_ok = false; continue; }                                  // the sink has no row
+    const int qr = __builtin_amdgcn_readlane(dA.w, li);
+    const int vb = fl & 0xff;
+    const bool far = (fl >> 16) & 1;
     // ---- FAST ROW: one predecessor = the previous row, whose H/E1/E2 are still in this wave's REGISTERS (lane = band
-    // column), and the band moved right by at most two columns.  The predecessor cells arrive by DPP lane shifts (no LDS
-    // round trip on the dependent chain), the row maximum is taken from Ht in parallel with the two F scans (an F value
-    // is always strictly below some Ht to its left, so max H == max Ht and both are attained in the same columns), and
-    // every tie order is a tag in the low bits of the compared keys, so the direction cell is 1 byte of masked key bits:
-    //   bit0 E1 opened (0 = extended), bit1 E2 opened, bits2-3 Ht source (2 M, 1 E1, 0 E2), bits4-5 H source
-    //   (2 Ht, 1 F1, 0 F2), bit6 F1 extended, bit7 F2 extended.
-    if (qlds && nin == 1 && p0 == idx - 1 && pv_idx == idx - 1 && pv_reg && v != SRC) {
-      const int qr = Q - remv;
-      const int b = pv_beg, e = pv_end;
-      const int mplv = e >= b ? pv_left + 1 : INT32_MAX / 2, mprv = e >= b ? pv_right + 1 : 0;
-      int beg = max(max(0, min(mplv, qr) - w), b);
-      int end = min(min(Q, max(mprv, qr) + w), e + 1);
-      if (end < beg) end = beg - 1;
-      const int wd = end - beg + 1, sh = beg - b;
-      if (wd > 0 && wd <= 64 && sh <= 2) {
-        if (ncell + wd > c.cells_cap) return -4;
+    // column).  The predecessor cells arrive by lane permutes (no LDS round trip through memory on the dependent chain),
+    // the row maximum is taken from Ht in parallel with the two F scans (an F value is always strictly below some Ht to
+    // its left, so max H == max Ht and both are attained in the same columns), and every tie order is a tag in the low
+    // bits of the compared keys, so the direction cell is 1 byte of masked key bits
+    // (DIRECTION BYTE, all rows): bit0 E1 opened (0 = extended), bit1 E2 opened, bits2-3 Ht source (2 M, 1 E1, 0 E2),
+    // bits4-5 H source (2 Ht, 1 F1, 0 F2), bit6 F1 extended, bit7 F2 extended.
+    if (((fl >> 18) & 1) && pv_ok) {
+      UNI(u_beg); UNI(u_end); UNI(u_left); UNI(u_right); UNI(u_ncell);
+      const bool nonempty = u_end >= u_beg;
+      const int mplv = nonempty ? u_left + 1 : INT32_MAX / 2, mprv = nonempty ? u_right + 1 : 0;
+      const int beg = max(max(0, min(mplv, qr) - w), u_beg);
+      int end = min(min(Q, max(mprv, qr) + w), u_end + 1);
+      end = max(end, beg - 1);
+      const int wd = end - beg + 1, sh = beg - u_beg;
+      // (64 cells of head room instead of wd: the stores below are not masked)
+      if (__builtin_amdgcn_ballot_w64((unsigned)(wd - 1) < 64u && sh < 64 && u_ncell + 64 <= c.cells_cap) != 0) {
         const int slot = idx & (PR - 1);
-        const int ro = ncell;
-        ncell += wd;
+        const int ro = u_ncell;
         const int j = beg + lane;
         const bool act = lane < wd;
-        // query base of column j (LDS copy; issued first, consumed after the shifts)
+        // query base of column j (LDS copy; issued first, consumed after the permutes)
         const int jq = max(j - 1, 0);
-        // (subreads longer than the LDS copy take the general row: a global load here would wait for every older store)
         const unsigned qw_ = L.qpk[min(jq >> 4, PQW - 1)];
-        // previous row shifted to this row's columns: hp = H[i-1][j], hd = H[i-1][j-1]
-        int hd, hp, e1p, e2p;
-        if (sh == 1) { hd = pH; hp = wave_shl1(pH, NEGS); e1p = wave_shl1(pE1, NEGS); e2p = wave_shl1(pE2, NEGS); }
-        else if (sh == 0) { hd = wave_shr1(pH, NEGS); hp = pH; e1p = pE1; e2p = pE2; }
-        else { hd = wave_shl1(pH, NEGS); hp = wave_shl1(hd, NEGS); e1p = wave_shl1(wave_shl1(pE1, NEGS), NEGS); e2p = wave_shl1(wave_shl1(pE2, NEGS), NEGS); }
+        // previous row moved to this row's columns: hp = H[i-1][j] sits sh lanes to the right, hd = H[i-1][j-1] one less
+        const int a_p = lane4 + sh * 4, a_d = a_p - 4;
+        const int hd_ = __builtin_amdgcn_ds_bpermute(a_d, pH), hp_ = __builtin_amdgcn_ds_bpermute(a_p, pH);
+        const int e1_ = __builtin_amdgcn_ds_bpermute(a_p, pE1), e2_ = __builtin_amdgcn_ds_bpermute(a_p, pE2);
+        const bool vp = j <= u_end, vd = a_d >= 0;                              // (j - 1 <= u_end always: end <= u_end + 1)
+        const int hd = vd ? hd_ : NEGS, hp = vp ? hp_ : NEGS, e1p = vp ? e1_ : NEGS, e2p = vp ? e2_ : NEGS;
         const int qc = (int)((qw_ >> ((jq & 15) * 2)) & 3);
         const int M9 = hd + ((vb == qc) ? mt9 + 8 : mm9 + 8);                   // tag 2 in bits 2-3
         const int E1t = max(hp - (oe1_9 - 1), e1p - e1_9);                     // bit 0 set: opened (open wins ties)
@@ -243,51 +245,81 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         const int k2 = max(max(M9, E1c + 4), E2c);
         const int ht9 = k2 & ~511;
         const int htm = act ? ht9 : NEG2S;
-        const int ej1 = le1 + e1_9 * beg, ej2 = le2 + e2_9 * beg;
-        int s1 = htm + ej1, s2 = htm + ej2, s3 = htm;
+        // F[j] = max_{k<j} Ht[k] - o - e*(j-k): scanned in lane coordinates (the e*beg term cancels)
+        int s1 = htm + le1, s2 = htm + le2, s3 = htm;
         wave_scan_max3(s1, s2, s3);
         const int px1 = wave_shr1(s1, NEG2S), px2 = wave_shr1(s2, NEG2S);
         const int htl = wave_shr1(htm, NEGS);
-        const int f1 = px1 - (o1_9 + ej1), f2 = px2 - (o2_9 + ej2);
+        const int f1 = px1 - lo1, f2 = px2 - lo2;
         const int k3 = max(max(ht9 + 32, f1 + 16), f2);
         const int h9 = k3 & ~511;
         unsigned d = ((unsigned)E1t & 1u) | ((unsigned)E2t & 2u) | ((unsigned)k2 & 12u) | ((unsigned)k3 & 48u);
         d |= (((unsigned)(htl - oe1_9 - f1)) >> 25) & 64u;                      // f1 > its "open" candidate: extended
         d |= (((unsigned)(htl - oe2_9 - f2)) >> 24) & 128u;
         pH = act ? h9 : NEGS; pE1 = act ? E1c : NEGS; pE2 = act ? E2c : NEGS;
-        if (act) {
-          c.D8()[ro + lane] = (uint8_t)d;
-          L.H[slot][lane] = h9; L.E1[slot][lane] = E1c; L.E2[slot][lane] = E2c;
-          if (far) { c.H()[ro + lane] = h9; c.E1()[ro + lane] = E1c; c.E2()[ro + lane] = E2c; }
-        }
+        // unmasked stores: lanes past the band write cells that the next rows overwrite / that no reader ever selects
+        c.D8()[(unsigned)(ro + lane)] = (uint8_t)d;
+        L.H[slot][lane] = h9; L.E1[slot][lane] = E1c; L.E2[slot][lane] = E2c;
         const int rb = __builtin_amdgcn_readlane(s3, 63);
         // first / last column holding the row maximum: columns are beg + lane, so one ballot replaces two reductions
         const unsigned long long mxm = __ballot(htm == rb);
-        const int left = beg + __builtin_ctzll(mxm), right = beg + 63 - __builtin_clzll(mxm);
+        const int left = beg + __builtin_ctzll(mxm), right = beg + (63 - __builtin_clzll(mxm));
         if (lane == 0) {
-          L.beg[slot] = beg; L.end[slot] = end; L.rl[slot] = left; L.rr[slot] = right; L.inl[slot] = 1;
-          { int* rm = c.rowm() + 3 * idx; rm[0] = beg; rm[1] = end; rm[2] = ~ro; }       // ~ro: byte cells
-          if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
+          L.meta[slot] = make_int4(beg, end, left, right);
+          int off = 3 * idx; UNI(off);
+          int* rm = c.rowm() + off; rm[0] = beg; rm[1] = end; rm[2] = ro;                 // type 0: byte cells, one predecessor
         }
-        pv_idx = idx; pv_beg = beg; pv_end = end; pv_left = left; pv_right = right; pv_inl = 1;
+        if (far) {
+          if (act) { c.H()[ro + lane] = h9; c.E1()[ro + lane] = E1c; c.E2()[ro + lane] = E2c; }
+          if (lane == 0) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
+        }
+        u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ro + wd;
+#ifdef C3_PHASE_PROF
+        { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[8] += t_ - row_t0; row_t0 = t_; }
+#endif
         continue;
       }
     }
-    // ---- adaptive band: gather the hints of the predecessors (abPOA scatters them to the successors)
+    const int v = __builtin_amdgcn_readlane(dA.x, li);
+    const int nin = (fl >> 8) & 0xff;
+    const bool ovf = (fl >> 17) & 1;
+    const int p0 = __builtin_amdgcn_readlane(dB.x, li), p1 = __builtin_amdgcn_readlane(dB.y, li);
+    const int p2 = __builtin_amdgcn_readlane(dB.z, li), p3 = __builtin_amdgcn_readlane(dB.w, li);
+#define PRED_IDX(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[v * K + (k)]])
+    int ncell = wave_first(u_ncell);
+    // ---- GENERAL ROW.  Adaptive band: gather the hints of the predecessors (abPOA scatters them to the successors).  The
+    // ring metadata of the first four predecessors is fetched in ONE LDS round trip (one 16-byte read each, issued
+    // together) and pinned to scalars; predecessors that left the ring (or a fifth, sixth ... one) take global loads.
     int beg, end;
-    const int qr = Q - remv;
+    int pb_[4] = {0, 0, 0, 0}, pe_[4] = {-1, -1, -1, -1};          // band of predecessor k (k < 4)
+    bool ring_[4] = {false, false, false, false};                    // ... and whether its cells are in the LDS ring
     if (v == SRC) { beg = 0; end = min(Q, max(qr, 0) + w); }
     else {
       int mplv = INT32_MAX / 2, mprv = 0, minb = INT32_MAX, maxe = INT32_MIN;
-      for (int k = 0; k < nin; ++k) {
+      int4 m_[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) m_[k] = L.meta[(k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3) & (PR - 1)];
+      asm volatile("" : "+v"(m_[0].x), "+v"(m_[1].x), "+v"(m_[2].x), "+v"(m_[3].x));     // the LDS loads happen HERE, together
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (k < nin) {
+          const int pi = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
+          int b = m_[k].x, e = m_[k].y, l = m_[k].z, r = m_[k].w;
+          // (written as an override, not as if/else: a select between an LDS and a global POINTER becomes a flat load)
+          if (idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1] & 0x0fffffff; l = c.mpl()[pi]; r = c.mpr()[pi]; }
+          b = wave_first(b); e = wave_first(e); l = wave_first(l); r = wave_first(r);
+          pb_[k] = b; pe_[k] = e; ring_[k] = idx - pi < PR && e - b + 1 <= PW;
+          minb = min(minb, b); maxe = max(maxe, e + 1);
+          if (e >= b) { mplv = min(mplv, l + 1); mprv = max(mprv, r + 1); }
+        }
+      }
+      for (int k = 4; k < nin; ++k) {
         const int pi = PRED_IDX(k);
-        // LDS reads are unconditional (the slot index is always valid) and the rare out-of-ring predecessor overrides
-        // them: written as if/else, the compiler selects between an LDS and a global POINTER and emits a flat load,
-        // whose vmcnt wait drains every outstanding row store
         const int sl = pi & (PR - 1);
-        int b = L.beg[sl], e = L.end[sl], l = L.rl[sl], r = L.rr[sl];
-        asm volatile("" : "+v"(b), "+v"(e), "+v"(l), "+v"(r));                     // the LDS loads happen HERE
-        if (idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1]; l = c.mpl()[pi]; r = c.mpr()[pi]; }
+        int4 m = L.meta[sl];
+        asm volatile("" : "+v"(m.x), "+v"(m.y), "+v"(m.z), "+v"(m.w));
+        int b = m.x, e = m.y, l = m.z, r = m.w;
+        if (idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1] & 0x0fffffff; l = c.mpl()[pi]; r = c.mpr()[pi]; }
         minb = min(minb, b); maxe = max(maxe, e + 1);
         if (e >= b) { mplv = min(mplv, l + 1); mprv = max(mprv, r + 1); }
       }
@@ -302,8 +334,9 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     const int wd = end - beg + 1;
     if (ncell + wd > c.cells_cap) return -4;
     const int slot = idx & (PR - 1);
-    const bool inl = wd <= PW, toglobal = far || !inl;
+    const bool inl = wd <= PW, toglobal = far || !inl;             // wd is scalar (beg / end pinned above)
     const int ro = ncell;
+    const int ty = ovf ? 2 : (nin >= 2 ? 1 : 0);                   // cell format: byte / byte + predecessor byte / 32-bit word
     ncell += wd;
     int best = INT32_MIN, bl = 0, br = 0;        // per-lane running row maximum
     int carry1 = NEG2S, carry2 = NEG2S;          // scan carries over previous chunks
@@ -312,23 +345,51 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     for (int c0 = 0; c0 < wd; c0 += 64) {
       const int j = beg + c0 + lane;
       const bool act = j <= end;
-      int ht9, E1v, E2v; unsigned d = 0;
-      if (v == SRC) { ht9 = (j == 0) ? 0 : NEGS; E1v = E2v = NEGS; }
+      int ht9, E1v, E2v; unsigned d = 0, pby = 0, dw = 0;
+      if (v == SRC) { ht9 = (j == 0) ? 0 : NEGS; E1v = E2v = NEGS; d = 8; }
       else {
         int kM = INT32_MIN, kE1 = INT32_MIN, kE2 = INT32_MIN;
-        for (int k = 0; k < nin; ++k) {
+        // ring predecessors: unconditional reads on clamped addresses, all issued before the first use, masked afterwards
+        int hd_[4], hp_[4], e1_[4], e2_[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int sl = (k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3) & (PR - 1);
+          const int o = j - pb_[k];
+          const int oc = min(max(o, 0), PW - 1), om = min(max(o - 1, 0), PW - 1);
+          hd_[k] = L.H[sl][om]; hp_[k] = L.H[sl][oc]; e1_[k] = L.E1[sl][oc]; e2_[k] = L.E2[sl][oc];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (k < nin) {
+            const int pi = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
+            const int b = pb_[k], e = pe_[k];
+            const bool vd = j > 0 && j - 1 >= b && j - 1 <= e, vp = j >= b && j <= e;
+            int hd = NEGS, hp = NEGS, e1p = NEGS, e2p = NEGS;
+            if (ring_[k]) {
+              hd = vd ? hd_[k] : NEGS; hp = vp ? hp_[k] : NEGS; e1p = vp ? e1_[k] : NEGS; e2p = vp ? e2_[k] : NEGS;
+            } else {
+              const int po = c.rowm()[3 * pi + 2];
+              if (vd) hd = c.H()[po + (j - 1 - b)];
+              if (vp) { hp = c.H()[po + (j - b)]; e1p = c.E1()[po + (j - b)]; e2p = c.E2()[po + (j - b)]; }
+            }
+            kM = max(kM, hd + (511 - k));
+            kE1 = max(kE1, max(hp - oe1_9 + (511 - 2 * k), e1p - e1_9 + (510 - 2 * k)));
+            kE2 = max(kE2, max(hp - oe2_9 + (511 - 2 * k), e2p - e2_9 + (510 - 2 * k)));
+          }
+        }
+        for (int k = 4; k < nin; ++k) {
           const int pi = PRED_IDX(k);
           int hd = NEGS, hp = NEGS, e1p = NEGS, e2p = NEGS;
           const int sl = pi & (PR - 1);
-          if (idx - pi < PR && L.inl[sl]) {
-            const int b = L.beg[sl], e = L.end[sl];
+          int4 m = L.meta[sl];
+          asm volatile("" : "+v"(m.x), "+v"(m.y));
+          int b = m.x, e = m.y;
+          if (idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1] & 0x0fffffff; }
+          if (idx - pi < PR && e - b + 1 <= PW) {
             if (j > 0 && j - 1 >= b && j - 1 <= e) hd = L.H[sl][j - 1 - b];
             if (j >= b && j <= e) { hp = L.H[sl][j - b]; e1p = L.E1[sl][j - b]; e2p = L.E2[sl][j - b]; }
           } else {
-            int b = L.beg[sl], e = L.end[sl];                                  // see the note above: no pointer select
-            asm volatile("" : "+v"(b), "+v"(e));
-            if (idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1]; }
-            const int po = ro_dec(c.rowm()[3 * pi + 2]);
+            const int po = c.rowm()[3 * pi + 2];
             if (j > 0 && j - 1 >= b && j - 1 <= e) hd = c.H()[po + (j - 1 - b)];
             if (j >= b && j <= e) { hp = c.H()[po + (j - b)]; e1p = c.E1()[po + (j - b)]; e2p = c.E2()[po + (j - b)]; }
           }
@@ -342,113 +403,170 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         E1v = kE1 & ~511; E2v = kE2 & ~511;
         const int k2 = max(max(M9 + 2, E1v + 1), E2v);
         ht9 = k2 & ~511;
-        d = (unsigned)(511 - (kM & 511)) | ((unsigned)(511 - (kE1 & 511)) << 8) | ((unsigned)(511 - (kE2 & 511)) << 17)
-            | ((unsigned)(2 - (k2 & 3)) << 26);
+        const unsigned mp = 511u - ((unsigned)kM & 511u), c1 = 511u - ((unsigned)kE1 & 511u), c2 = 511u - ((unsigned)kE2 & 511u);
+        d = ((~c1) & 1u) | (((~c2) & 1u) << 1) | (((unsigned)k2 & 3u) << 2);
+        pby = mp | ((c1 >> 1) << 2) | ((c2 >> 1) << 4);
+        dw = mp | (c1 << 8) | (c2 << 17) | ((unsigned)(2 - (k2 & 3)) << 26);             // word format (> 4 predecessors)
       }
       // horizontal states: F[j] = max_{beg<=k<j} ht[k] - o - e*(j-k)
       const int htm = act ? ht9 : NEG2S;
-      const int s1 = wave_scan_max(htm + e1_9 * j), s2 = wave_scan_max(htm + e2_9 * j);
+      const int cl1 = le1 + e1_9 * c0, cl2 = le2 + e2_9 * c0;                           // e * (column - beg)
+      int s1 = htm + cl1, s2 = htm + cl2, s3 = htm;
+      wave_scan_max3(s1, s2, s3);
       const int px1 = max(wave_shr1(s1, NEG2S), carry1), px2 = max(wave_shr1(s2, NEG2S), carry2);
       const int htl = wave_shr1(htm, prev_ht);
       int f1, f2; unsigned f1x = 0, f2x = 0;
       if (j == beg) { f1 = f2 = NEG2S; }
       else {
-        f1 = px1 - o1_9 - e1_9 * j; f2 = px2 - o2_9 - e2_9 * j;
+        f1 = px1 - o1_9 - cl1; f2 = px2 - o2_9 - cl2;
         f1x = f1 != htl - oe1_9; f2x = f2 != htl - oe2_9;
       }
       carry1 = max(carry1, wave_bcast(s1, 63)); carry2 = max(carry2, wave_bcast(s2, 63));
       prev_ht = wave_bcast(htm, 63);
       const int k3 = max(max(ht9 + 2, f1 + 1), f2);
       const int h9 = k3 & ~511;
-      d |= ((unsigned)(2 - (k3 & 3)) << 28) | (f1x << 30) | (f2x << 31);
+      d |= (((unsigned)k3 & 3u) << 4) | (f1x << 6) | (f2x << 7);
+      dw |= ((unsigned)(2 - (k3 & 3)) << 28) | (f1x << 30) | (f2x << 31);
       if (c0 == 0) { gH = act ? h9 : NEGS; gE1 = act ? E1v : NEGS; gE2 = act ? E2v : NEGS; }
       if (act) {
         const int ci = c0 + lane;
-        c.D()[ro + ci] = d;
+        if (ty == 2) c.D()[ro + ci] = dw;
+        else { c.D8()[(unsigned)(ro + ci)] = (uint8_t)d; if (ty == 1) c.P8()[(unsigned)(ro + ci)] = (uint8_t)pby; }
         if (inl) { L.H[slot][ci] = h9; L.E1[slot][ci] = E1v; L.E2[slot][ci] = E2v; }
         if (toglobal) { c.H()[ro + ci] = h9; c.E1()[ro + ci] = E1v; c.E2()[ro + ci] = E2v; }
-        if (h9 > best) { best = h9; bl = br = j; } else if (h9 == best) br = j;
       }
+      // row maximum == maximum of Ht, attained in the same columns (see the fast row)
+      const int cmx = wave_bcast(s3, 63);
+      if (cmx > best) { best = cmx; const unsigned long long mm = __ballot(htm == cmx); bl = beg + c0 + __builtin_ctzll(mm); br = beg + c0 + 63 - __builtin_clzll(mm); }
+      else if (cmx == best) { const unsigned long long mm = __ballot(htm == cmx); if (mm) br = beg + c0 + 63 - __builtin_clzll(mm); }
     }
-    // row maximum: leftmost / rightmost argmax -> band hints read by the successors
-    int left = 0, right = 0;
-    if (wd > 0) {
-      const int rb = wave_max(best);
-      left = wave_min(best == rb ? bl : INT32_MAX / 2);
-      right = wave_max(best == rb ? br : -1);
-    }
-    left = wave_first(left); right = wave_first(right);
+    // leftmost / rightmost argmax -> band hints read by the successors
+    const int left = wd > 0 ? bl : 0, right = wd > 0 ? br : 0;
     if (lane == 0) {
-      L.beg[slot] = beg; L.end[slot] = end; L.rl[slot] = left; L.rr[slot] = right; L.inl[slot] = inl;
-      { int* rm = c.rowm() + 3 * idx; rm[0] = beg; rm[1] = end; rm[2] = ro; }
+      L.meta[slot] = make_int4(beg, end, left, right);
+      { int* rm = c.rowm() + 3 * idx; rm[0] = beg; rm[1] = end | (ty << 28); rm[2] = ro; }
       if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
     }
-    pv_idx = idx; pv_beg = beg; pv_end = end; pv_left = left; pv_right = right; pv_inl = inl;
-    pH = gH; pE1 = gE1; pE2 = gE2; pv_reg = wd <= 64;
+    u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ncell;
+#ifdef C3_PHASE_PROF
+    { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[11] += t_ - row_t0; row_t0 = t_; }
+#endif
+    pH = gH; pE1 = gE1; pE2 = gE2; pv_ok = wd <= 64;
   }
   }
   WSYNC();
-  *cells += ncell;
+  *cells += wave_first(u_ncell);
   PH_MARK(1)
   // ---- end cell: best predecessor of the sink at column Q (first maximum in in-edge order)
   int bi = -1, bs = INT32_MIN;
   for (int k = 0; k < c.n_in()[SNK]; ++k) {
     const int pi = c.index()[c.in_from()[SNK * K + k]];
-    const int hh = (Q < c.rowm()[3 * pi] || Q > c.rowm()[3 * pi + 1]) ? NEGS : c.H()[ro_dec(c.rowm()[3 * pi + 2]) + (Q - c.rowm()[3 * pi])];
+    const int pb = c.rowm()[3 * pi], pe = c.rowm()[3 * pi + 1] & 0x0fffffff;
+    const int hh = (Q < pb || Q > pe) ? NEGS : c.H()[c.rowm()[3 * pi + 2] + (Q - pb)];
     if (hh > bs) { bs = hh; bi = pi; }
   }
   if (bi < 0 || bs <= NEGS / 2) return -1;
   // ---- traceback.  vq[q] = graph node aligned to base q (-1 = insertion); deletions leave no trace.
-  // In state H the wave speculates 64 steps down the diagonal at once (lane k fetches the cell k steps
-  // back and checks "match move from the previous row"); the cell that breaks the run is resolved by
-  // the scalar state machine below.
-  // Every round fetches, in two dependent load levels, the cells (i-k, j-k) for all 64 lanes (row metadata and both
-  // descriptors first, then the direction word); lane 0 is always the current cell.  The breaking cell is then
-  // resolved from lane m's registers by the scalar state machine below, which only goes back to memory when the
-  // cell changes -- one round per break instead of a chain of dependent scalar loads per state transition.
+  // The walk needs, per row it crosses, the row record (band, cell offset, format), the node and its first four
+  // predecessor rows, and the direction cell(s) around the column where the path crosses the row.  All of that is fetched
+  // 64 ROWS AT A TIME: lane k owns row it-k, loads its records (coalesced) and a 32-byte window of its direction bytes
+  // (and predecessor bytes) centred on the diagonal through the current cell, and parks the windows in LDS (the DP ring is
+  // free by now).  Inside such a block every step is an LDS read: in state H the wave checks 64 cells down the diagonal at
+  // once (lane k: "match move from the previous row"?), consumes the run, and resolves the cell that breaks it with the
+  // scalar state machine from that lane's registers.  One memory round trip per 64 rows instead of one per break.
   int* vq = c.mpl();
   int rc = 0;
   {
+    uint8_t* WD = (uint8_t*)&L.H[0][0];          // [64][32] direction-byte windows
+    uint8_t* WP = (uint8_t*)&L.E1[0][0];         // [64][32] predecessor-byte windows
     int i = bi, j = Q, st = 0;   // st: 0 H, 1 Ht, 2 E1, 3 E2, 4 F1, 5 F2
-    while (!(i == 0 && j == 0)) {
-      const int ik = i - lane, jk = j - lane;
-      const int ic = max(ik, 0);
-      const int b = c.rowm()[3 * ic], e = c.rowm()[3 * ic + 1], roe = c.rowm()[3 * ic + 2];
+    while (!(i == 0 && j == 0) && rc == 0) {
+      const int it = i, jt = j;
+      const int rk = it - lane;
+      const int ic = max(rk, 0);
+      const int b = c.rowm()[3 * ic], et = c.rowm()[3 * ic + 1], ro = c.rowm()[3 * ic + 2];
       const uint4 A = c.descA()[ic], B = c.descB()[ic];
-      const bool inb = ik >= 0 && jk >= b && jk <= e;
-      unsigned d = 0u;
-      if (inb) d = roe < 0 ? dir_word_of_byte(c.D8()[~roe + (jk - b)]) : c.D()[roe + (jk - b)];
-      int m = 0;
-      if (st == 0 && i > 0 && j > 0) {
-        const int mp = d & 0xff;
-        bool ok = ik >= 1 && jk >= 1 && inb && ((d >> 26) & 15) == 0 && mp < 4 && !((A.z >> 17) & 1);
-        const int pi = mp == 0 ? (int)B.x : mp == 1 ? (int)B.y : mp == 2 ? (int)B.z : (int)B.w;
-        ok = ok && pi == ik - 1;
-        const unsigned long long bal = __ballot(ok);
-        m = (~bal) ? __builtin_ctzll(~bal) : 64;
-        if (lane < m) vq[jk - 1] = (int)A.x;
-        i -= m; j -= m;
-        if (m == 64 || (i == 0 && j == 0)) continue;
+      const int e = et & 0x0fffffff, ty = (int)((unsigned)et >> 28);
+      const bool adj = rk >= 1 && ((A.z >> 8) & 0xff) == 1 && (int)B.x == rk - 1;       // one predecessor, the row above
+      // window of 32 cells, 4-byte aligned in the arena, around column jt - lane (clamped into the slot's arena)
+      int a0 = ro + (jt - lane - 12 - b);
+      a0 = min(max(a0, 0), c.cells_cap - 32) & ~3;
+      const int w0 = a0 - ro + b;                                                          // column of window byte 0
+      {
+        uint4 x0, x1;
+        const uint32_t* src = (const uint32_t*)(c.D8() + a0);
+        x0 = make_uint4(src[0], src[1], src[2], src[3]); x1 = make_uint4(src[4], src[5], src[6], src[7]);
+        uint4 y0 = make_uint4(0, 0, 0, 0), y1 = y0;
+        if (ty == 1) { const uint32_t* sp = (const uint32_t*)(c.P8() + a0); y0 = make_uint4(sp[0], sp[1], sp[2], sp[3]); y1 = make_uint4(sp[4], sp[5], sp[6], sp[7]); }
+        uint4* wd_ = (uint4*)(WD + lane * 32); wd_[0] = x0; wd_[1] = x1;
+        uint4* wp_ = (uint4*)(WP + lane * 32); wp_[0] = y0; wp_[1] = y1;
       }
-      // the current cell (i, j) sits in lane m
-      if (!wave_bcast((int)inb, m)) { rc = -2; break; }
-      const unsigned d0 = (unsigned)wave_bcast((int)d, m);
-      const int v = wave_bcast((int)A.x, m);
-      const int p0 = wave_bcast((int)B.x, m), p1 = wave_bcast((int)B.y, m), p2 = wave_bcast((int)B.z, m), p3 = wave_bcast((int)B.w, m);
-#define TB_PRED(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[v * K + (k)]])
-      for (bool same = true; same;) {
-        if (st == 0) { const int hs = (d0 >> 28) & 3; st = hs == 0 ? 1 : (hs == 1 ? 4 : 5); }
-        else if (st == 1) {
-          const int hts = (d0 >> 26) & 3;
-          if (hts == 0) { if (lane == 0) vq[j - 1] = v; const int k = d0 & 0xff; i = TB_PRED(k); --j; st = 0; same = false; }
-          else st = hts == 1 ? 2 : 3;
+      WSYNC();
+      // ---- steps inside the block
+      for (;;) {
+        const int s = it - i;                                  // lane s holds the current row
+        const int jk = j - (lane - s);                         // lane k >= s looks at cell (it-k, j-(k-s))
+        const bool inb = rk >= 0 && lane >= s && jk >= b && jk <= e;
+        const int wo = jk - w0;
+        const bool hit = inb && wo >= 0 && wo < 32 && ty != 2;
+        const int wa = lane * 32 + min(max(wo, 0), 31);
+        unsigned d = WD[wa], pq = WP[wa];
+        int m = 0;
+        if (st == 0 && i > 0 && j > 0) {
+          // H <- Ht <- M through the single, adjacent predecessor: bits 2-3 == 2 and bits 4-5 == 2
+          const bool ok = hit && adj && jk >= 1 && ((d >> 2) & 15u) == 10u;
+          const unsigned long long bal = __ballot(ok) >> s;
+          m = (~bal) ? __builtin_ctzll(~bal) : 64;
+          m = min(m, 64 - s);
+          if (lane >= s && lane < s + m) vq[jk - 1] = (int)A.x;
+          i -= m; j -= m;
+          if (i == 0 && j == 0) break;
+          if (s + m >= 64) break;                              // block used up: fetch the next 64 rows
         }
-        else if (st == 2) { const int ec = (d0 >> 8) & 0x1ff; const int k = ec >> 1; i = TB_PRED(k); st = (ec & 1) ? 2 : 0; same = false; }
-        else if (st == 3) { const int ec = (d0 >> 17) & 0x1ff; const int k = ec >> 1; i = TB_PRED(k); st = (ec & 1) ? 3 : 0; same = false; }
-        else if (st == 4) { if (lane == 0) vq[j - 1] = -1; st = ((d0 >> 30) & 1) ? 4 : 1; --j; same = false; }
-        else { if (lane == 0) vq[j - 1] = -1; st = ((d0 >> 31) & 1) ? 5 : 1; --j; same = false; }
-      }
+        // the current cell (i, j) sits in lane cl
+        const int cl = it - i;
+        if (!wave_bcast((int)inb, cl)) { rc = -2; break; }
+        const int v = wave_bcast((int)A.x, cl);
+        const int cty = wave_bcast(ty, cl);
+        const int p0 = wave_bcast((int)B.x, cl), p1 = wave_bcast((int)B.y, cl), p2 = wave_bcast((int)B.z, cl), p3 = wave_bcast((int)B.w, cl);
+        unsigned mp, c1, c2, hts, hs, f1x, f2x;
+        if (cty == 2 || !wave_bcast((int)hit, cl)) {
+          // outside the window (the path drifted off the diagonal of this block) or a row of 32-bit words: direct loads
+          const int cb = wave_bcast(b, cl), cro = wave_bcast(ro, cl);
+          if (cty == 2) {
+            const unsigned wv = c.D()[cro + (j - cb)];
+            mp = wv & 0xff; c1 = (wv >> 8) & 0x1ff; c2 = (wv >> 17) & 0x1ff; hts = (wv >> 26) & 3; hs = (wv >> 28) & 3; f1x = (wv >> 30) & 1; f2x = wv >> 31;
+          } else {
+            const unsigned db = c.D8()[(unsigned)(cro + (j - cb))];
+            const unsigned pb = cty == 1 ? c.P8()[(unsigned)(cro + (j - cb))] : 0u;
+            mp = pb & 3; c1 = (((pb >> 2) & 3) << 1) | ((~db) & 1u); c2 = (((pb >> 4) & 3) << 1) | (((~db) >> 1) & 1u);
+            hts = 2u - ((db >> 2) & 3u); hs = 2u - ((db >> 4) & 3u); f1x = (db >> 6) & 1; f2x = db >> 7;
+          }
+        } else {
+          const unsigned db = (unsigned)wave_bcast((int)d, cl), pb = (unsigned)wave_bcast((int)pq, cl);
+          mp = pb & 3; c1 = (((pb >> 2) & 3) << 1) | ((~db) & 1u); c2 = (((pb >> 4) & 3) << 1) | (((~db) >> 1) & 1u);
+          hts = 2u - ((db >> 2) & 3u); hs = 2u - ((db >> 4) & 3u); f1x = (db >> 6) & 1; f2x = db >> 7;
+        }
+#define TB_PRED(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[v * K + (k)]])
+        for (bool same = true; same;) {
+          if (st == 0) { st = hs == 0 ? 1 : (hs == 1 ? 4 : 5); }
+          else if (st == 1) {
+            if (hts == 0) { if (lane == 0) vq[j - 1] = v; const int k = (int)mp; i = TB_PRED(k); --j; st = 0; same = false; }
+            else st = hts == 1 ? 2 : 3;
+          }
+          else if (st == 2) { const int k = (int)(c1 >> 1); i = TB_PRED(k); st = (c1 & 1) ? 2 : 0; same = false; }
+          else if (st == 3) { const int k = (int)(c2 >> 1); i = TB_PRED(k); st = (c2 & 1) ? 3 : 0; same = false; }
+          else if (st == 4) { if (lane == 0) vq[j - 1] = -1; st = f1x ? 4 : 1; --j; same = false; }
+          else { if (lane == 0) vq[j - 1] = -1; st = f2x ? 5 : 1; --j; same = false; }
+        }
 #undef TB_PRED
+        if (i == 0 && j == 0) break;
+        if (i < 0 || j < 0) { rc = -2; break; }
+        // leave the block when the row is no longer in it, or when the path has drifted too far from the block's diagonal
+        const int drift = (jt - j) - (it - i);
+        if (it - i >= 64 || drift > 8 || drift < -8) break;
+      }
+      WSYNC();
     }
   }
   WSYNC();
@@ -570,8 +688,8 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
   const int slot = blockIdx.x;
   Ctx c;
   const size_t N = (size_t)a.Ncap;
-  c.I = a.ibase + (size_t)slot * 23 * N; c.E = a.ebase + (size_t)slot * 3 * N * a.K;
-  c.C = a.cellsb + (size_t)slot * 17 * (size_t)a.cells_cap; c.B8 = a.bbase + (size_t)slot * 5 * N;
+  c.I = a.ibase + (size_t)slot * C3_POA_NI * N; c.path_ = a.pbase + (size_t)slot * a.Pcap; c.E = a.ebase + (size_t)slot * 3 * N * a.K;
+  c.C = a.cellsb + (size_t)slot * 18 * (size_t)a.cells_cap; c.B8 = a.bbase + (size_t)slot * 5 * N;
   c.score_ = a.score + (size_t)slot * N; c.desc_ = a.desc + (size_t)slot * 2 * N; c.jump_ = a.jump + (size_t)slot * C3_JUMP_LEVELS * N;
   c.K = a.K; c.Ncap = a.Ncap; c.cells_cap = a.cells_cap;
   PH_DECL
@@ -606,8 +724,8 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
       int poff = 0;
       for (int s = 0; s < ns && !fail; ++s) {
         const int qb = wave_first(info->sub_beg[s]), Q = wave_first(info->sub_end[s]) - qb;
-        if (s > 0) { if (poa_align(c, a.p, qb, Q, lane, &cells PHP) < 0) { fail = 1; break; } }
-        if (poa_fuse(c, s == 0, qb, Q, c.path() + poff, lane PHP) < 0) { fail = 1; break; }
+        if (s > 0) { const int rc = poa_align(c, a.p, qb, Q, lane, &cells PHP); if (rc < 0) { fail = rc == -4 ? 2 : 1; break; } }
+        if (poa_fuse(c, s == 0, qb, Q, c.path() + poff, lane PHP) < 0) { fail = 2; break; }                 // node capacity
         poff += Q;
       }
       PH_MARK(9)
@@ -755,7 +873,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
                 draft[pp] = c.base()[node]; c.col2t()[c.col()[node]] = pp;
               }
             }
-            if (C < 0) { fail = 1; C = 0; }
+            if (C < 0) { fail = 2; C = 0; }
             WSYNC();
           }
 
@@ -772,11 +890,17 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
     }
     WSYNC();
     PH_MARK(7)
+    // fail == 2: the scratch of this slot was too small (cells / nodes).  The first pass runs with scratch sized for the
+    // TYPICAL alignment (more resident waves); such reads are queued and redone by a second launch with worst-case scratch
+    const bool redo = fail == 2 && a.overflow != nullptr;
     if (lane == 0) {
-      info->draft_len = C;
-      if (fail) { info->status = C3_ST_LIMIT; info->draft_len = 0; }
-      else if (C == 0) info->status = C3_ST_NO_CONSENSUS;
-      atomicAdd((unsigned long long*)(a.counter + 2), (unsigned long long)cells);
+      if (redo) a.overflow[atomicAdd(a.counter + 4, 1)] = rid;
+      else {
+        info->draft_len = C;
+        if (fail) { info->status = C3_ST_LIMIT; info->draft_len = 0; }
+        else if (C == 0) info->status = C3_ST_NO_CONSENSUS;
+        atomicAdd((unsigned long long*)(a.counter + 2), (unsigned long long)cells);
+      }
     }
     WSYNC();
   }

@@ -77,6 +77,7 @@ typedef struct {
   float ms_pack, ms_conk, ms_peaks, ms_poa, ms_prep, ms_window, ms_stitch, ms_total;
   int64_t n_reads, n_bases, n_windows;
   int64_t cells_conk, cells_poa, cells_polish;
+  int64_t n_poa_redo;      /* reads whose POA scratch (sized for the typical alignment) overflowed and were redone full-size */
 } c3_timing;
 
 typedef struct c3_handle c3_handle;

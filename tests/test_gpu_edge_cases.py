@@ -464,3 +464,26 @@ def test_scan_then_assign_equals_upload_with_known_strands():
     h.run()
     assert h.results()[1] == want and sum(1 for c in want if c) >= 25
     h.close()
+
+
+def test_poa_second_pass_redoes_overflowing_reads(O, monkeypatch):
+    """the first POA pass runs with scratch sized for the typical alignment; reads that overflow it are redone by a second
+    launch with worst-case scratch -- same results, nobody ends in C3_ST_LIMIT"""
+    from c3poa_amd import _lib
+    recs = list(synth.generate("cfg3", n_reads=40))
+    h = _lib.Handle()
+    h.set_splints([synth.SPLINT1])
+    h.upload([r[1] for r in recs], [r[2] for r in recs], [r[3] for r in recs])
+    h.run()
+    res0, cons0 = h.results()
+    assert h.timing()["n_poa_redo"] == 0
+    monkeypatch.setenv("C3_DEBUG_POA_SMALL", "6000")          # alignments of > 96000 cells (or 6000 nodes) overflow the first pass
+    h.run()
+    res1, cons1 = h.results()
+    t = h.timing()
+    assert 0 < t["n_poa_redo"] < len(recs)
+    assert cons1 == cons0 and np.array_equal(res1["status"], res0["status"])
+    ores, ocons = O.process_batch(synth.SPLINT1, [(r[1], r[2]) for r in recs], [r[3] for r in recs], threads=8)
+    assert cons1 == ocons
+    assert t["cells_poa"] == sum(r.cells_poa for r in ores)
+    h.close()

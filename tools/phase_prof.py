@@ -27,4 +27,4 @@ for which, kn in ((0, "k_poa"), (1, "k_window")):
     out = (C.c_uint64 * 12)()
     h.lib.c3_debug_phases(h.h, which, out)
     tot = float(sum(out)) or 1.0
-    print(kn, " ".join("%s=%.1f%%" % (names[which][i], 100 * out[i] / tot) for i in range(10) if out[i]), "| raw[9..11] =", out[9], out[10], out[11])
+    print(kn, " ".join("%s=%.1f%%" % (names[which][i], 100 * out[i] / tot) for i in range(10) if out[i]), "| raw[8..11] =", out[8], out[9], out[10], out[11])

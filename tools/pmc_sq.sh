@@ -1,0 +1,28 @@
+#!/bin/bash
+# SQ counters per kernel (two passes of <= 8 SQ counters, kernel trace only): tools/pmc_sq.sh N [cfg]
+# What binds the DP kernels: VALU issue, SALU issue, waiting on memory / LDS, or instruction fetch?
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+N=${1:-32768}; CFG=${2:-cfg2}; R=gpurun_out/pmcsq_$CFG; rm -rf $R; mkdir -p $R
+export C3_REPS=1
+P1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SMEM"
+P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS"
+i=0
+for P in "$P1" "$P2"; do
+  i=$((i+1))
+  timeout 300 rocprofv3 --kernel-trace --pmc $P -d $R/p$i -o b -- python3 tools/phase_prof.py $N $CFG > $R/p$i.log 2>&1
+done
+python3 - <<PY
+import sqlite3, glob
+from collections import defaultdict
+val = defaultdict(dict); dur = {}
+for f in glob.glob("$R/p*/*results.db"):
+    db = sqlite3.connect(f)
+    for kn, cn, v, st, en in db.execute("select kernel_name, counter_name, value, start, end from counters_collection"):
+        n = kn.split("(")[0].replace("void ", "")
+        val[n][cn] = val[n].get(cn, 0.0) + float(v); dur[n] = max(dur.get(n, 0), en - st)
+for n, d in sorted(val.items(), key=lambda t: -dur.get(t[0], 0)):
+    if not n.startswith("k_") or dur[n] < 1e6: continue
+    wc = d.get("SQ_WAVE_CYCLES", 1.0)
+    print("%-10s %.1f ms" % (n, dur[n] / 1e6), " ".join("%s=%.3g" % (k.replace("SQ_", ""), v) for k, v in sorted(d.items())))
+    print("           per wave-cycle: " + " ".join("%s=%.3f" % (k.replace("SQ_", ""), d[k] / wc) for k in sorted(d) if k != "SQ_WAVE_CYCLES"))
+PY
