@@ -16,6 +16,7 @@
 //   k_stitch  one wave per read: window consensi concatenated into the final sequence.
 #include "c3_dev.h"
 #include "c3_args.h"
+#include <algorithm>
 
 #define WSYNC() __syncthreads()
 
@@ -781,50 +782,92 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
         const int gbs = wave_max(bs);
         const int gbr = wave_min(bs == gbs ? br : INT32_MAX / 2);
         PH_MARK(4)
-        // ---- traceback, wave-speculative: lane k fetches the cell k steps down the diagonal; the run of
-        // "diagonal from the previous row" cells is consumed in one go, then the cell that breaks it.
-        // rq[q] = DP row aligned to query base q, 0 = insertion.
+        // ---- traceback.  rq[q] = DP row aligned to query base q, 0 = insertion.
+        // 64 ROWS AT A TIME: lane k owns row rt-k, loads its descriptor and a 16-byte window of its direction cells around
+        // the column where the diagonal through the current cell crosses that row (32-64 cells of a 2-bit row, 12-16 of a
+        // byte row) and parks the window in LDS (the consensus arrays are not live yet).  Inside the block every step is an
+        // LDS read: the wave checks 64 cells down the diagonal at once ("diagonal move from the row above"?), consumes the
+        // run, and resolves the cell that breaks it.  One memory round trip per 64 rows instead of one per break -- and
+        // the traceback no longer fetches about as many bytes as the fill wrote.
         int* rq = c.opq(); int* tq = c.opn();
         {
+          unsigned* WD = (unsigned*)(mabits + ((a.Ncap + 64) >> 6) + 1);       // [64][4] dwords, behind the row-type bitmasks
+          const int cdiv = cpl ? (65536 + cpl - 1) / cpl : 0;                   // j / cpl == (j * cdiv) >> 16 for j < 2^13
           int r = (gbs == INT32_MIN) ? 0 : gbr, j = Q;
           while (r > 0 || j > 0) {
             if (r == 0) { for (int q = lane; q < j; q += 64) rq[q] = 0; break; }
             if (j == 0) break;                                   // only vertical moves remain
-            const int rk = r - lane, jk = j - lane;
-            const bool val = rk >= 1 && jk >= 0;
-            int d = 0, prow = -1;
-            if (val) {
-              const int rb = rk - 1;
-              const bool two = (m2bits[rb >> 6] >> (rb & 63)) & 1;
-              if (two) {
-                // 2-bit row: no descriptor needed on the common path (LDS says whether the predecessor is row rk-1)
-                const unsigned w = ((const unsigned*)(c.D + (size_t)rk * RS))[jk / cpl];
-                d = 63 + 64 * (int)((w >> (2 * (jk % cpl))) & 3u);
-                prow = ((mabits[rb >> 6] >> (rb & 63)) & 1) ? rk - 1 : -3;
-              } else {
-                // both loads are issued together (one dependent level per round, not two)
-                const uint4 de = c.rdesc[rk];
-                d = c.D[(size_t)rk * RS + win_idx(jk, cpl)];
+            const int rt = r, jt = j;
+            const int rk = rt - lane;
+            const bool rowv = rk >= 1;
+            const int rb = max(rk, 1) - 1;
+            const bool two = rowv && ((m2bits[rb >> 6] >> (rb & 63)) & 1);
+            const bool adj = two && ((mabits[rb >> 6] >> (rb & 63)) & 1);
+            const uint4 de = c.rdesc[max(rk, 1)];
+            // byte offset of cell `col` inside a D row: two-bit rows keep one dword per lane (lane = col / cpl), byte rows
+            // ds_ bytes per lane; the window starts 4-byte aligned a little left of the expected column
+            const int ce = max(jt - lane, 0);
+            const int le = cpl ? (ce * cdiv) >> 16 : 0;
+            int wb;                                                             // window start (byte offset in the row)
+            if (two) wb = max(le - 1, 0) * 4;
+            else wb = max((cpl ? le * (((cpl + 3) & ~3)) + (ce - le * cpl) : ce) - 6, 0) & ~3;
+            wb = min(wb, max(RS - 16, 0));
+            {
+              const unsigned* src = (const unsigned*)(c.D + (size_t)max(rk, 1) * RS + wb);
+              uint4 x = make_uint4(0, 0, 0, 0);
+              if (rowv) x = make_uint4(src[0], src[1], src[2], src[3]);
+              *(uint4*)(WD + lane * 4) = x;
+            }
+            WSYNC();
+            for (;;) {
+              const int s = rt - r;                               // lane s holds the current row
+              const int jk = j - (lane - s);
+              const bool val = rowv && lane >= s && jk >= 0;
+              const int jc = max(jk, 0);
+              const int lq = cpl ? (jc * cdiv) >> 16 : 0, cw = jc - lq * cpl;
+              const int bo = (two ? lq * 4 : (cpl ? lq * ((cpl + 3) & ~3) + cw : jc)) - wb;       // byte offset in the window
+              const bool hit = val && bo >= 0 && bo < 16;
+              const unsigned wv = WD[lane * 4 + (min(max(bo, 0), 15) >> 2)];
+              int d, prow = -1;
+              if (two) { d = 63 + 64 * (int)((wv >> (2 * cw)) & 3u); prow = adj ? rk - 1 : -3; }
+              else {
+                d = (int)((wv >> (8 * (bo & 3))) & 0xffu);
                 if (win_d_type(d) != 2) prow = ((de.x >> 16) & 1) ? -2 : win_pred_row(c, de, rk, win_d_pred(d));
               }
-            }
-            const bool diag1 = val && jk >= 1 && win_d_type(d) == 0 && prow == rk - 1;
-            const unsigned long long bal = __ballot(diag1);
-            const int m = (~bal) ? __builtin_ctzll(~bal) : 64;  // length of the diagonal run
-            if (lane < m) rq[jk - 1] = rk;
-            r -= m; j -= m;
-            if (m < 64 && r > 0 && j >= 0) {
-              // the breaking cell sits in lane m
-              const int db = wave_bcast(d, m);
-              int pb = wave_bcast(prow, m);
+              const bool diag1 = hit && jk >= 1 && win_d_type(d) == 0 && prow == rk - 1;
+              const unsigned long long bal = __ballot(diag1) >> s;
+              const int m = (~bal) ? __builtin_ctzll(~bal) : 64;  // length of the diagonal run
+              if (lane >= s && lane < s + m) rq[jk - 1] = rk;
+              r -= m; j -= m;
+              if (s + m >= 64 || r <= 0 || j <= 0) break;
+              // the breaking cell (r, j) sits in lane cl
+              const int cl = rt - r;
+              int db, pb;
+              if (wave_bcast((int)hit, cl)) { db = wave_bcast(d, cl); pb = wave_bcast(prow, cl); }
+              else {
+                // outside the window (the path drifted off this block's diagonal): direct loads of the one cell
+                const bool two0 = (m2bits[(r - 1) >> 6] >> ((r - 1) & 63)) & 1;
+                if (two0) {
+                  const unsigned w0 = ((const unsigned*)(c.D + (size_t)r * RS))[j / cpl];
+                  db = 63 + 64 * (int)((w0 >> (2 * (j % cpl))) & 3u);
+                  pb = ((mabits[(r - 1) >> 6] >> ((r - 1) & 63)) & 1) ? r - 1 : -3;
+                } else {
+                  db = c.D[(size_t)r * RS + win_idx(j, cpl)];
+                  pb = -2;
+                }
+              }
               const int ty = win_d_type(db);
               if (ty == 2) { if (lane == 0) rq[j - 1] = 0; --j; }
               else {
-                if (pb <= -2) pb = win_pred_row(c, c.rdesc[r], r, win_d_pred(db));   // >4 predecessors, or a 2-bit row whose predecessor is not r-1 (uniform slow path)
+                if (pb <= -2) pb = win_pred_row(c, c.rdesc[r], r, win_d_pred(db));   // > 4 predecessors, a 2-bit row whose predecessor is not r-1, or a window miss
                 if (ty == 0) { if (lane == 0) rq[j - 1] = r; --j; }
                 r = pb;
               }
+              if (r <= 0 || j <= 0) break;
+              const int drift = (jt - j) - (rt - r);
+              if (rt - r >= 64 || drift > 5 || drift < -5) break;
             }
+            WSYNC();
           }
         }
         WSYNC();
@@ -940,7 +983,8 @@ __global__ __launch_bounds__(64) void k_stitch(StitchArgs a) {
 
 extern "C" void c3k_launch_prep(const PrepArgs* a, int slots, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(slots), dim3(64), 0, s, *a); }
 extern "C" void c3k_launch_window(const WinArgs* a, int slots, hipStream_t s) {
-  const size_t lds = (size_t)a->Lcap * 6 + 16;
+  // consensus sweep arrays (Lcap scores + predecessors) share the LDS with the row-type bitmasks + traceback windows
+  const size_t lds = std::max<size_t>((size_t)a->Lcap * 6 + 16, (size_t)16 * (((a->Ncap + 64) >> 6) + 1) + 1024 + 64);
   hipLaunchKernelGGL(k_window, dim3(slots), dim3(64), lds, s, *a);
 }
 extern "C" void c3k_launch_stitch(const StitchArgs* a, int grid, hipStream_t s) { hipLaunchKernelGGL(k_stitch, dim3(grid), dim3(64), 0, s, *a); }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 output that a gpurun call merged into gpurun_out/ into the summaries kept under profiles/.
 
-  python tools/collect_profiles.py TAG STATS_DIR FETCH_DIR WRITE_DIR [BENCH_JSON]
+  python tools/collect_profiles.py TAG STATS_DIR FETCH_DIR WRITE_DIR [BENCH_JSON] [WORKLOAD e.g. cfg4_100k]
 
 STATS_DIR : `rocprofv3 --kernel-trace --stats -d STATS_DIR -o s -- python3 bench.py --steps 1 --warmup 0 --no-cpu`
 FETCH_DIR : `rocprofv3 --kernel-trace --pmc FETCH_SIZE -d FETCH_DIR -o b -- python3 bench.py ...` (own pass)
@@ -30,9 +30,10 @@ def counter_sum(d, name):
 
 def main():
     tag, stats_dir, fdir, wdir = sys.argv[1:5]
+    wl = sys.argv[6] if len(sys.argv) > 6 else "cfg2_100k"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     prof = os.path.join(root, "profiles")
-    dst = os.path.join(prof, "%s_kernel_stats_bench_cfg2_100k.csv" % tag)
+    dst = os.path.join(prof, "%s_kernel_stats_bench_%s.csv" % (tag, wl))
     csvs = glob.glob(os.path.join(stats_dir, "*kernel_stats.csv"))
     if csvs:
         shutil.copy(csvs[0], dst)
@@ -48,20 +49,20 @@ def main():
     st = dst
     fetch, write = counter_sum(fdir, "FETCH_SIZE"), counter_sum(wdir, "WRITE_SIZE")
     out = {"note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on `python3 bench.py --steps 1 "
-                   "--warmup 0 --no-cpu` (cfg2, 100000 reads); KB per launch as reported, averaged over launches. "
+                   "--warmup 0 --no-cpu` (%s); KB per launch as reported, averaged over launches. " % wl +
                    "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (FETCH_SIZE reports 1/2 of dword loads on this device, "
                    "calibrated with tools/pmc_calibrate.py; WRITE_SIZE exact).",
            "calibration": {"source": "tools/pmc_calibrate.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this pool (round 1)",
                            "bytes_read": 1073741824, "bytes_written": 1073741824, "FETCH_SIZE_KB": 524307.25, "WRITE_SIZE_KB": 1048576.0},
-           "workload": "cfg2: 100000 reads/GPU/step", "kernels": {}}
+           "workload": wl, "kernels": {}}
     for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, 0) + write.get(k, 0))):
         if not k.startswith("k_"):
             continue
         out["kernels"][k] = {"FETCH_SIZE_KB": fetch.get(k, 0.0), "WRITE_SIZE_KB": write.get(k, 0.0),
                              "hbm_bytes_per_launch": (2 * fetch.get(k, 0.0) + write.get(k, 0.0)) * 1024}
-    json.dump(out, open(os.path.join(prof, "%s_pmc_traffic_cfg2_100k.json" % tag), "w"), indent=1)
+    json.dump(out, open(os.path.join(prof, "%s_pmc_traffic_%s.json" % (tag, wl)), "w"), indent=1)
     if len(sys.argv) > 5:
-        shutil.copy(sys.argv[5], os.path.join(prof, "%s_bench_under_rocprof.json" % tag))
+        shutil.copy(sys.argv[5], os.path.join(prof, "%s_bench_under_rocprof_%s.json" % (tag, wl)))
     print(open(st).read())
     print(json.dumps(out["kernels"], indent=1))
 
