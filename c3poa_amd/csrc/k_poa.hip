@@ -15,6 +15,9 @@
 #include "c3_args.h"
 
 #define WSYNC() __syncthreads()
+// adjacency slot k of node v.  Slot-major (all first edges, then all second edges, ...): nearly every node has one or two
+// edges, so the arrays a wave actually touches are contiguous runs of Ncap ints instead of one 64-byte line per node
+#define EI(v, k) ((size_t)(k) * (size_t)c.Ncap + (size_t)(v))
 #define C3_POA_NI 18       // int arrays of Ncap per slot in Ctx::I
 #define SRC 0
 #define SNK 1
@@ -52,10 +55,10 @@ struct Ctx {
 __device__ __forceinline__ void g_add_edge(Ctx& c, int u, int v, int w) {
   const int K = c.K;
   for (int k = 0; k < c.n_out()[u]; ++k)
-    if (c.out_to()[u * K + k] == v) { c.out_w()[u * K + k] += w; return; }
+    if (c.out_to()[EI(u, k)] == v) { c.out_w()[EI(u, k)] += w; return; }
   int no = c.n_out()[u], ni = c.n_in()[v];
-  c.out_to()[u * K + no] = v; c.out_w()[u * K + no] = w; c.n_out()[u] = no + 1;
-  c.in_from()[v * K + ni] = u; c.n_in()[v] = ni + 1;
+  c.out_to()[EI(u, no)] = v; c.out_w()[EI(u, no)] = w; c.n_out()[u] = no + 1;
+  c.in_from()[EI(v, ni)] = u; c.n_in()[v] = ni + 1;
 }
 
 // block extents from order/grp (parallel)
@@ -123,9 +126,9 @@ __device__ void poa_build_desc(Ctx& c, int lane, int Q, bool qlds) {
     const int v = c.order()[idx];
     const int nin = c.n_in()[v];
     unsigned p[4] = {0, 0, 0, 0};
-    for (int k = 0; k < nin && k < 4; ++k) p[k] = (unsigned)c.index()[c.in_from()[v * K + k]];
+    for (int k = 0; k < nin && k < 4; ++k) p[k] = (unsigned)c.index()[c.in_from()[EI(v, k)]];
     unsigned far = 0;
-    for (int k = 0; k < c.n_out()[v]; ++k) { const int t = c.out_to()[v * K + k]; if (t == SNK || c.index()[t] - idx > PR - 1) far = 1; }
+    for (int k = 0; k < c.n_out()[v]; ++k) { const int t = c.out_to()[EI(v, k)]; if (t == SNK || c.index()[t] - idx > PR - 1) far = 1; }
     uint4 A; A.x = (unsigned)v; A.y = (unsigned)c.rem()[v]; A.z = (unsigned)c.base()[v] | ((unsigned)min(nin, 255) << 8) | (far << 16) | ((unsigned)(nin > 4) << 17);
     // bit 18: candidate for the fast row (one predecessor, the row above; query in LDS); bit 19: the sink (no DP row)
     A.z |= ((unsigned)(qlds && nin == 1 && (int)p[0] == idx - 1 && v != SRC && v != SNK) << 18) | ((unsigned)(v == SNK) << 19);
@@ -151,7 +154,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     int *dA = c.rem(), *nA = c.nxt(), *dB = c.col(), *nB = c.col2t();
     for (int v = lane; v < n; v += 64) {
       int bw = INT32_MIN, bt = SNK;
-      for (int k = 0; k < c.n_out()[v]; ++k) { int ww = c.out_w()[v * K + k]; if (ww > bw) { bw = ww; bt = c.out_to()[v * K + k]; } }
+      for (int k = 0; k < c.n_out()[v]; ++k) { int ww = c.out_w()[EI(v, k)]; if (ww > bw) { bw = ww; bt = c.out_to()[EI(v, k)]; } }
       if (v == SNK) bt = SNK;
       nA[v] = bt; dA[v] = (v == SNK) ? 0 : 1;
     }
@@ -285,7 +288,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     const bool ovf = (fl >> 17) & 1;
     const int p0 = __builtin_amdgcn_readlane(dB.x, li), p1 = __builtin_amdgcn_readlane(dB.y, li);
     const int p2 = __builtin_amdgcn_readlane(dB.z, li), p3 = __builtin_amdgcn_readlane(dB.w, li);
-#define PRED_IDX(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[v * K + (k)]])
+#define PRED_IDX(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[EI(v, (k))]])
     int ncell = wave_first(u_ncell);
     // ---- GENERAL ROW.  Adaptive band: gather the hints of the predecessors (abPOA scatters them to the successors).  The
     // ring metadata of the first four predecessors is fetched in ONE LDS round trip (one 16-byte read each, issued
@@ -460,7 +463,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   // ---- end cell: best predecessor of the sink at column Q (first maximum in in-edge order)
   int bi = -1, bs = INT32_MIN;
   for (int k = 0; k < c.n_in()[SNK]; ++k) {
-    const int pi = c.index()[c.in_from()[SNK * K + k]];
+    const int pi = c.index()[c.in_from()[EI(SNK, k)]];
     const int pb = c.rowm()[3 * pi], pe = c.rowm()[3 * pi + 1] & 0x0fffffff;
     const int hh = (Q < pb || Q > pe) ? NEGS : c.H()[c.rowm()[3 * pi + 2] + (Q - pb)];
     if (hh > bs) { bs = hh; bi = pi; }
@@ -547,7 +550,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
           mp = pb & 3; c1 = (((pb >> 2) & 3) << 1) | ((~db) & 1u); c2 = (((pb >> 4) & 3) << 1) | (((~db) >> 1) & 1u);
           hts = 2u - ((db >> 2) & 3u); hs = 2u - ((db >> 4) & 3u); f1x = (db >> 6) & 1; f2x = db >> 7;
         }
-#define TB_PRED(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[v * K + (k)]])
+#define TB_PRED(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[EI(v, (k))]])
         for (bool same = true; same;) {
           if (st == 0) { st = hs == 0 ? 1 : (hs == 1 ? 4 : 5); }
           else if (st == 1) {
@@ -615,12 +618,12 @@ __device__ int poa_fuse(Ctx& c, bool first, int qb, int Q, int* path, int lane P
     const int u = q == 0 ? SRC : path[q - 1], v = q == Q ? SNK : path[q];
     const int no = c.n_out()[u];
     int hit = -1;
-    for (int k = 0; k < no; ++k) if (c.out_to()[u * K + k] == v) { hit = k; break; }
-    if (hit >= 0) c.out_w()[u * K + hit] += 1;
+    for (int k = 0; k < no; ++k) if (c.out_to()[EI(u, k)] == v) { hit = k; break; }
+    if (hit >= 0) c.out_w()[EI(u, hit)] += 1;
     else {
       const int ni = c.n_in()[v];
-      c.out_to()[u * K + no] = v; c.out_w()[u * K + no] = 1; c.n_out()[u] = no + 1;
-      c.in_from()[v * K + ni] = u; c.n_in()[v] = ni + 1;
+      c.out_to()[EI(u, no)] = v; c.out_w()[EI(u, no)] = 1; c.n_out()[u] = no + 1;
+      c.in_from()[EI(v, ni)] = u; c.n_in()[v] = ni + 1;
     }
   }
   WSYNC();
@@ -797,8 +800,8 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
               const int no = c.n_out()[v];
               int bw = INT32_MIN, bt = SNK, cm = 0;
               for (int k = 0; k < no; ++k) {
-                const int ww = c.out_w()[v * K + k];
-                if (ww > bw) { bw = ww; bt = c.out_to()[v * K + k]; cm = 1; } else if (ww == bw) ++cm;
+                const int ww = c.out_w()[EI(v, k)];
+                if (ww > bw) { bw = ww; bt = c.out_to()[EI(v, k)]; cm = 1; } else if (ww == bw) ++cm;
               }
               const bool term = (v == SNK) || cm >= 2 || no == 0;
               c.nxt()[v] = bt; tief[v] = (v != SNK && cm >= 2) ? 1 : 0;
@@ -829,7 +832,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
                 // lane k evaluates out-edge k: weight, target, score of the target
                 int ww = INT32_MIN, tt = SNK, st = 0;
                 if (lane < min(no, 64)) {
-                  ww = c.out_w()[vv * K + lane]; tt = c.out_to()[vv * K + lane];
+                  ww = c.out_w()[EI(vv, lane)]; tt = c.out_to()[EI(vv, lane)];
                   const int tm = nxA[tt];
                   st = (tm == tt) ? score[tt] : ssA[tt] + score[tm];
                 }
@@ -838,7 +841,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
                   int wk, tk, sk;
                   if (k < 64) { wk = wave_bcast(ww, k); tk = wave_bcast(tt, k); sk = wave_bcast(st, k); }
                   else {                                     // more than 64 out-edges: uniform loads
-                    wk = c.out_w()[vv * K + k]; tk = c.out_to()[vv * K + k];
+                    wk = c.out_w()[EI(vv, k)]; tk = c.out_to()[EI(vv, k)];
                     const int tm = nxA[tk];
                     sk = (tm == tk) ? score[tk] : ssA[tk] + score[tm];
                   }

@@ -19,6 +19,9 @@
 #include <algorithm>
 
 #define WSYNC() __syncthreads()
+// adjacency slot k of node v.  Slot-major (all first edges, then all second edges, ...): nearly every node has one or two
+// edges, so the arrays a wave actually touches are contiguous runs of Ncap ints instead of one 64-byte line per node
+#define EI(v, k) ((size_t)(k) * (size_t)c.Ncap + (size_t)(v))
 
 
 
@@ -335,14 +338,14 @@ __device__ void win_build_desc(WCtx& c, int R, int lane, unsigned long long* m2,
       unsigned p[4] = {0, 0, 0, 0};
       int np = 0;
       for (int k = 0; k < nin; ++k) {
-        const int pr = c.rowof()[c.in_from()[v * K + k]];
+        const int pr = c.rowof()[c.in_from()[EI(v, k)]];
         if (pr < 0) continue;
         if (np < 4) p[np] = (unsigned)pr;
         ++np;
       }
       unsigned needh = 0, has = 0;
       for (int k = 0; k < c.n_out()[v]; ++k) {
-        const int sr = c.rowof()[c.out_to()[v * K + k]];
+        const int sr = c.rowof()[c.out_to()[EI(v, k)]];
         if (sr >= 0) { has = 1; if (sr != r + 1 && sr != r + 2) needh = 1; }     // rows r-1 and r-2 stay in registers
       }
       unsigned ovf = np > 4;
@@ -366,7 +369,7 @@ __device__ int win_pred_row(const WCtx& c, const uint4& de, int r, int t) {
   if (!((de.x >> 16) & 1)) return (t == 0) ? (de.y & 0xffff) : (t == 1) ? (de.y >> 16) : (t == 2) ? (de.z & 0xffff) : (de.z >> 16);
   const int v = c.rows()[r];
   int seen = 0;
-  for (int k = 0; k < c.n_in()[v]; ++k) { int pr = c.rowof()[c.in_from()[v * c.K + k]]; if (pr >= 0) { if (seen == t) return pr; ++seen; } }
+  for (int k = 0; k < c.n_in()[v]; ++k) { int pr = c.rowof()[c.in_from()[EI(v, k)]]; if (pr >= 0) { if (seen == t) return pr; ++seen; } }
   return 0;
 }
 
@@ -379,12 +382,15 @@ __device__ int win_pred_row(const WCtx& c, const uint4& de, int r, int t) {
 // t, 64..127 vertical from predecessor t-64, 128 horizontal.  One v_max per candidate then
 // implements "highest score, first candidate in (diag preds, vert preds, horizontal) order" exactly.
 // The D byte of a cell is its tag.
+#ifndef C3_WIN_RING
+#define C3_WIN_RING 1
+#endif
 #define W_TAG_H 127           /* 255 - 128 */
 __device__ __forceinline__ int win_d_type(int tag) { return (255 - tag) >> 6; }       // 0 diag 1 vert 2 horiz
 __device__ __forceinline__ int win_d_pred(int tag) { return (255 - tag) & 63; }
 
 template <int CPL>
-__device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane, unsigned long long* dbg) {
+__device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane, unsigned long long* dbg, unsigned* ring) {
   const int RS = 64 * CPL, K = c.K;
   const int mt8 = P.pol_match * 256, mm8 = P.pol_mismatch * 256, g8 = P.pol_gap * 256;
   constexpr int DS = (CPL + 3) & ~3, RSD = 64 * DS;                        // D row: natural column order, DS bytes per lane
@@ -398,12 +404,17 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
     qc[cc] = (j >= 1 && j <= Q) ? c3_code_at(pk, qbeg + j - 1) : 7;
     hcur[cc] = j * g8;                                                      // virtual row 0
     gj8[cc] = (j <= Q) ? g8 * j : (1 << 28);                                // columns past Q drop out of the scan
-    if (j <= Q) c.H[cc * 64 + lane] = j * g8;
+    if (j <= Q) ((short*)c.H)[cc * 64 + lane] = (short)(j * P.pol_gap);        // H rows are kept as 16-bit scores
   }
   // gfx9 has ONE in-order vmcnt for loads and stores: consuming any load waits for every older
   // store.  So the row loop carries no vector loads on its common path -- descriptors come 64 rows at
   // a time (one per lane) and are broadcast with v_readlane; only rows with a non-adjacent
   // predecessor touch memory.
+  // LDS ring of the last four rows that a far successor will need (16-bit scores, two columns per dword): a far
+  // predecessor is usually a handful of rows back, and an LDS hit spares the row loop a global load -- which on gfx9
+  // waits for every older direction / H store (one in-order vmcnt)
+  int rt0 = -1, rt1 = -1, rt2 = -1, rt3 = -1, rnext = 0;
+  constexpr int RW = (CPL + 1) / 2 * 64;                                    // dwords per ring slot
   for (int rb = 1; rb <= R; rb += 64) {
   uint4 dblk = c.rdesc[min(rb + lane, R)];
   // pin the wait for this load HERE (the asm "uses" the registers), not inside the row loop
@@ -427,7 +438,7 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
       else {                                                                 // >4 predecessors: walk the in-edges
         const int v = c.rows()[r];
         prow = -1;
-        while (kedge < c.n_in()[v]) { int pr = c.rowof()[c.in_from()[v * K + kedge]]; ++kedge; if (pr >= 0) { prow = pr; break; } }
+        while (kedge < c.n_in()[v]) { int pr = c.rowof()[c.in_from()[EI(v, kedge)]]; ++kedge; if (pr >= 0) { prow = pr; break; } }
         if (prow < 0) break;
       }
 #ifdef C3_PHASE_PROF
@@ -442,10 +453,24 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
       } else if (prow == r - 2) {                                            // the usual "skip one sibling" edge
 #pragma unroll
         for (int cc = 0; cc < CPL; ++cc) hp[cc] = hp2[cc];
-      } else {
-        const int32_t* hp_ = c.H + (size_t)prow * RS;
+      } else if (prow == 0) {                                                // the virtual start row: H[0][j] = j * gap
 #pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) hp[cc] = hp_[cc * 64 + lane];
+        for (int cc = 0; cc < CPL; ++cc) hp[cc] = gj8[cc];                   // (columns past Q hold a large value there: never used)
+      } else {
+        const int sl = !C3_WIN_RING ? -1 : prow == rt0 ? 0 : prow == rt1 ? 1 : prow == rt2 ? 2 : prow == rt3 ? 3 : -1;
+        if (sl >= 0) {
+          const unsigned* rp = ring + sl * RW;
+#pragma unroll
+          for (int m = 0; m < (CPL + 1) / 2; ++m) {
+            const unsigned x = rp[m * 64 + lane];
+            hp[2 * m] = ((int)(x << 16)) >> 8;
+            if (2 * m + 1 < CPL) hp[2 * m + 1] = ((int)x >> 8) & ~0xff;
+          }
+        } else {
+          const short* hp_ = (const short*)c.H + (size_t)prow * RS;
+#pragma unroll
+          for (int cc = 0; cc < CPL; ++cc) hp[cc] = ((int)hp_[cc * 64 + lane]) << 8;
+        }
       }
       const int hleft = wave_shr1(hp[CPL - 1], NEG8);                        // column lane*CPL-1 of the predecessor
 #pragma unroll
@@ -461,7 +486,7 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
     for (int cc = 0; cc < CPL; ++cc) { y[cc] = (key[cc] & ~0xff) - gj8[cc]; run = max(run, y[cc]); }
     const int s = wave_scan_max(run);
     int ex = wave_shr1(s, NEG8);                                             // max over all previous lanes
-    int32_t* hrow = c.H + (size_t)r * RS;
+    short* hrow = (short*)c.H + (size_t)r * RS;
     if (two) {
       // single-predecessor row: the tag is 255 (diag), 191 (vert) or 127 (horiz) -> 2 bits per cell, one dword per
       // lane, 256 contiguous bytes per row instead of 64*DS
@@ -474,7 +499,10 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
         hcur[cc] = k2 & ~0xff;
         w2 |= (((unsigned)k2 >> 6) & 3u) << (2 * cc);
       }
-      if (lane * CPL <= Q) ((unsigned*)(c.D + (size_t)r * RSD))[lane] = w2;
+      if (lane * CPL <= Q) {
+        if (CPL <= 8) ((unsigned short*)(c.D + (size_t)r * RSD))[lane] = (unsigned short)w2;       // 16 bits hold 8 cells: 128 bytes per row
+        else ((unsigned*)(c.D + (size_t)r * RSD))[lane] = w2;
+      }
     } else {
       unsigned dpk[DS / 4];
 #pragma unroll
@@ -495,7 +523,19 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
     }
     if (needh) {
 #pragma unroll
-      for (int cc = 0; cc < CPL; ++cc) if (lane * CPL + cc <= Q) hrow[cc * 64 + lane] = hcur[cc];
+      for (int cc = 0; cc < CPL; ++cc) if (lane * CPL + cc <= Q) hrow[cc * 64 + lane] = (short)(hcur[cc] >> 8);
+      if (C3_WIN_RING) {
+      const int sl = rnext;
+      rnext = (rnext + 1) & 3;
+      rt0 = sl == 0 ? r : rt0; rt1 = sl == 1 ? r : rt1; rt2 = sl == 2 ? r : rt2; rt3 = sl == 3 ? r : rt3;
+      unsigned* wp = ring + sl * RW;
+#pragma unroll
+      for (int m = 0; m < (CPL + 1) / 2; ++m) {
+        const unsigned lo = ((unsigned)(hcur[2 * m] >> 8)) & 0xffffu;
+        const unsigned hi = (2 * m + 1 < CPL) ? ((unsigned)(hcur[2 * m + 1] >> 8)) << 16 : 0u;
+        wp[m * 64 + lane] = lo | hi;
+      }
+      }
     }
     if (isend) {
 #pragma unroll
@@ -528,7 +568,7 @@ __device__ int win_rows_lin(WCtx& c, const C3Params& P, const uint32_t* pk, int 
       int bd = INT32_MIN, dd = 0, bv = INT32_MIN, dv = 0, np = 0;
       for (int k = 0; k <= nin; ++k) {
         int prow;
-        if (k < nin) { prow = c.rowof()[c.in_from()[v * K + k]]; if (prow < 0) continue; ++np; }
+        if (k < nin) { prow = c.rowof()[c.in_from()[EI(v, k)]]; if (prow < 0) continue; ++np; }
         else { if (np > 0) break; prow = 0; }
         const int tt = min(np > 0 ? np - 1 : 0, 63);
         const int32_t* hp_ = c.H + (size_t)prow * RS;
@@ -559,19 +599,20 @@ __device__ int win_rows_lin(WCtx& c, const C3Params& P, const uint32_t* pk, int 
 __device__ __forceinline__ int win_idx(int j, int cpl) { return cpl ? (j / cpl) * ((cpl + 3) & ~3) + j % cpl : j; }
 
 __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane, int* cpl_out, int* rs_out, unsigned long long* dbg,
-                                 unsigned long long* m2, unsigned long long* ma) {
+                                 unsigned long long* m2, unsigned long long* ma, unsigned* ring) {
   const int need = (Q + 1 + 63) / 64;
   int cpl;
-  if (need <= 2) cpl = 2; else if (need <= 4) cpl = 4; else if (need <= 6) cpl = 6; else if (need <= 8) cpl = 8;
+  if (5 * (R + Q + 2) >= 32000) cpl = 0;            // 16-bit H rows of the register-blocked rows: |score| <= 5 * (R + Q)
+  else if (need <= 2) cpl = 2; else if (need <= 4) cpl = 4; else if (need <= 6) cpl = 6; else if (need <= 8) cpl = 8;
   else if (need <= 10) cpl = 10; else cpl = 0;
   *cpl_out = cpl; *rs_out = cpl ? 64 * ((cpl + 3) & ~3) : need * 64;    // D row stride in bytes
   win_build_desc(c, R, lane, m2, ma, cpl != 0);
   switch (cpl) {
-    case 2: return win_rows<2>(c, P, pk, qbeg, Q, R, lane, dbg);
-    case 4: return win_rows<4>(c, P, pk, qbeg, Q, R, lane, dbg);
-    case 6: return win_rows<6>(c, P, pk, qbeg, Q, R, lane, dbg);
-    case 8: return win_rows<8>(c, P, pk, qbeg, Q, R, lane, dbg);
-    case 10: return win_rows<10>(c, P, pk, qbeg, Q, R, lane, dbg);
+    case 2: return win_rows<2>(c, P, pk, qbeg, Q, R, lane, dbg, ring);
+    case 4: return win_rows<4>(c, P, pk, qbeg, Q, R, lane, dbg, ring);
+    case 6: return win_rows<6>(c, P, pk, qbeg, Q, R, lane, dbg, ring);
+    case 8: return win_rows<8>(c, P, pk, qbeg, Q, R, lane, dbg, ring);
+    case 10: return win_rows<10>(c, P, pk, qbeg, Q, R, lane, dbg, ring);
     default: return win_rows_lin(c, P, pk, qbeg, Q, R, lane);
   }
 }
@@ -592,8 +633,8 @@ __device__ __forceinline__ int win_consensus(WCtx& c, int* s_score, unsigned sho
     int v = 0, nin = 0, u0 = 0, w0 = 0, u1 = 0, w1 = 0;
     if (i < n) {
       v = c.order()[i]; nin = c.n_in()[v];
-      if (nin > 0) { u0 = c.in_from()[v * K]; w0 = c.in_w()[v * K]; }
-      if (nin > 1) { u1 = c.in_from()[v * K + 1]; w1 = c.in_w()[v * K + 1]; }
+      if (nin > 0) { u0 = c.in_from()[EI(v, 0)]; w0 = c.in_w()[EI(v, 0)]; }
+      if (nin > 1) { u1 = c.in_from()[EI(v, 1)]; w1 = c.in_w()[EI(v, 1)]; }
     }
     const int cnt = min(64, n - i0);
     for (int t = 0; t < cnt; ++t) {
@@ -603,7 +644,7 @@ __device__ __forceinline__ int win_consensus(WCtx& c, int* s_score, unsigned sho
         int u, w;
         if (k == 0) { u = wave_bcast(u0, t); w = wave_bcast(w0, t); }
         else if (k == 1) { u = wave_bcast(u1, t); w = wave_bcast(w1, t); }
-        else { u = c.in_from()[vv * K + k]; w = c.in_w()[vv * K + k]; }
+        else { u = c.in_from()[EI(vv, k)]; w = c.in_w()[EI(vv, k)]; }
         if (sc < w || (sc == w && s_score[pr] <= s_score[u])) { sc = w; pr = u; }
       }
       if (pr != -1) sc += s_score[pr];
@@ -621,15 +662,15 @@ __device__ __forceinline__ int win_consensus(WCtx& c, int* s_score, unsigned sho
       while (c.n_out()[max_id] > 0) {
         const int v = max_id;
         for (int k = 0; k < c.n_out()[v]; ++k) {
-          const int t2 = c.out_to()[v * K + k];
-          for (int e = 0; e < c.n_in()[t2]; ++e) { int u = c.in_from()[t2 * K + e]; if (u != v) c.score[u] = -1; }
+          const int t2 = c.out_to()[EI(v, k)];
+          for (int e = 0; e < c.n_in()[t2]; ++e) { int u = c.in_from()[EI(t2, e)]; if (u != v) c.score[u] = -1; }
         }
         long long ms = 0; int mid = -1;
         for (int i = c.index()[v] + 1; i < n; ++i) {
           const int x = c.order()[i];
           c.score[x] = -1; c.pred()[x] = -1;
           for (int k = 0; k < c.n_in()[x]; ++k) {
-            const int u = c.in_from()[x * K + k]; const long long w = c.in_w()[x * K + k];
+            const int u = c.in_from()[EI(x, k)]; const long long w = c.in_w()[EI(x, k)];
             if (c.score[u] == -1) continue;
             if (c.score[x] < w || (c.score[x] == w && c.score[c.pred()[x]] <= c.score[u])) { c.score[x] = w; c.pred()[x] = u; }
           }
@@ -706,8 +747,8 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
       for (int i = lane; i < blen; i += 64) {
         c.base()[i] = bb[i]; c.grp()[i] = i; c.order()[i] = i; c.index()[i] = i; c.ncov()[i] = 1;
         c.n_in()[i] = i > 0; c.n_out()[i] = i + 1 < blen;
-        if (i > 0) { c.in_from()[i * c.K] = i - 1; c.in_w()[i * c.K] = 0; }
-        if (i + 1 < blen) { c.out_to()[i * c.K] = i + 1; c.out_w()[i * c.K] = 0; }
+        if (i > 0) { c.in_from()[EI(i, 0)] = i - 1; c.in_w()[EI(i, 0)] = 0; }
+        if (i + 1 < blen) { c.out_to()[EI(i, 0)] = i + 1; c.out_w()[EI(i, 0)] = 0; }
       }
       c.n = blen;
       WSYNC();
@@ -742,7 +783,7 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
             for (int v = lane; v < c.n; v += 64) {
               if (!c.mask()[v]) continue;
               int seed = v == l.end;
-              for (int k = 0; k < c.n_out()[v] && !seed; ++k) seed = c.mask()[c.out_to()[v * K + k]];
+              for (int k = 0; k < c.n_out()[v] && !seed; ++k) seed = c.mask()[c.out_to()[EI(v, k)]];
               if (seed) gseed[c.grp()[v]] = 1;
             }
             WSYNC();
@@ -770,7 +811,7 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
         PH_MARK(2)
         int cpl = 0, RS = 0;
         unsigned long long dbg_[3] = {0, 0, 0};
-        if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits) < 0) { fail = 1; break; }
+        if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, (unsigned*)(mabits + ((a.Ncap + 64) >> 6) + 1)) < 0) { fail = 1; break; }
 #ifdef C3_PHASE_PROF
         ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1]; ph_acc_[9] += dbg_[2];
 #endif
@@ -793,6 +834,7 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
         {
           unsigned* WD = (unsigned*)(mabits + ((a.Ncap + 64) >> 6) + 1);       // [64][4] dwords, behind the row-type bitmasks
           const int cdiv = cpl ? (65536 + cpl - 1) / cpl : 0;                   // j / cpl == (j * cdiv) >> 16 for j < 2^13
+          const int tb = cpl <= 8 ? 2 : 4;                                       // bytes per lane of a 2-bit row
           int r = (gbs == INT32_MIN) ? 0 : gbr, j = Q;
           while (r > 0 || j > 0) {
             if (r == 0) { for (int q = lane; q < j; q += 64) rq[q] = 0; break; }
@@ -809,7 +851,7 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
             const int ce = max(jt - lane, 0);
             const int le = cpl ? (ce * cdiv) >> 16 : 0;
             int wb;                                                             // window start (byte offset in the row)
-            if (two) wb = max(le - 1, 0) * 4;
+            if (two) wb = (max(le - 2, 0) * tb) & ~3;
             else wb = max((cpl ? le * (((cpl + 3) & ~3)) + (ce - le * cpl) : ce) - 6, 0) & ~3;
             wb = min(wb, max(RS - 16, 0));
             {
@@ -825,11 +867,11 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
               const bool val = rowv && lane >= s && jk >= 0;
               const int jc = max(jk, 0);
               const int lq = cpl ? (jc * cdiv) >> 16 : 0, cw = jc - lq * cpl;
-              const int bo = (two ? lq * 4 : (cpl ? lq * ((cpl + 3) & ~3) + cw : jc)) - wb;       // byte offset in the window
-              const bool hit = val && bo >= 0 && bo < 16;
+              const int bo = (two ? lq * tb : (cpl ? lq * ((cpl + 3) & ~3) + cw : jc)) - wb;      // byte offset in the window
+              const bool hit = val && bo >= 0 && bo + (two ? tb : 1) <= 16;
               const unsigned wv = WD[lane * 4 + (min(max(bo, 0), 15) >> 2)];
               int d, prow = -1;
-              if (two) { d = 63 + 64 * (int)((wv >> (2 * cw)) & 3u); prow = adj ? rk - 1 : -3; }
+              if (two) { const unsigned cellw = tb == 2 ? (wv >> (8 * (bo & 2))) & 0xffffu : wv; d = 63 + 64 * (int)((cellw >> (2 * cw)) & 3u); prow = adj ? rk - 1 : -3; }
               else {
                 d = (int)((wv >> (8 * (bo & 3))) & 0xffu);
                 if (win_d_type(d) != 2) prow = ((de.x >> 16) & 1) ? -2 : win_pred_row(c, de, rk, win_d_pred(d));
@@ -848,7 +890,7 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
                 // outside the window (the path drifted off this block's diagonal): direct loads of the one cell
                 const bool two0 = (m2bits[(r - 1) >> 6] >> ((r - 1) & 63)) & 1;
                 if (two0) {
-                  const unsigned w0 = ((const unsigned*)(c.D + (size_t)r * RS))[j / cpl];
+                  const unsigned w0 = tb == 2 ? (unsigned)((const unsigned short*)(c.D + (size_t)r * RS))[j / cpl] : ((const unsigned*)(c.D + (size_t)r * RS))[j / cpl];
                   db = 63 + 64 * (int)((w0 >> (2 * (j % cpl))) & 3u);
                   pb = ((mabits[(r - 1) >> 6] >> ((r - 1) & 63)) & 1) ? r - 1 : -3;
                 } else {
@@ -917,14 +959,14 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
           const int w = ((int)qual[l.qbeg + q - 1] - 33) + ((int)qual[l.qbeg + q] - 33);
           const int no = c.n_out()[u];
           int hit = -1;
-          for (int k = 0; k < no; ++k) if (c.out_to()[u * K + k] == v) { hit = k; break; }
+          for (int k = 0; k < no; ++k) if (c.out_to()[EI(u, k)] == v) { hit = k; break; }
           if (hit >= 0) {
-            c.out_w()[u * K + hit] += w;
-            for (int t2 = 0; t2 < c.n_in()[v]; ++t2) if (c.in_from()[v * K + t2] == u) { c.in_w()[v * K + t2] += w; break; }
+            c.out_w()[EI(u, hit)] += w;
+            for (int t2 = 0; t2 < c.n_in()[v]; ++t2) if (c.in_from()[EI(v, t2)] == u) { c.in_w()[EI(v, t2)] += w; break; }
           } else {
             const int ni = c.n_in()[v];
-            c.out_to()[u * K + no] = v; c.out_w()[u * K + no] = w; c.n_out()[u] = no + 1;
-            c.in_from()[v * K + ni] = u; c.in_w()[v * K + ni] = w; c.n_in()[v] = ni + 1;
+            c.out_to()[EI(u, no)] = v; c.out_w()[EI(u, no)] = w; c.n_out()[u] = no + 1;
+            c.in_from()[EI(v, ni)] = u; c.in_w()[EI(v, ni)] = w; c.n_in()[v] = ni + 1;
           }
         }
         WSYNC();
@@ -984,7 +1026,7 @@ __global__ __launch_bounds__(64) void k_stitch(StitchArgs a) {
 extern "C" void c3k_launch_prep(const PrepArgs* a, int slots, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(slots), dim3(64), 0, s, *a); }
 extern "C" void c3k_launch_window(const WinArgs* a, int slots, hipStream_t s) {
   // consensus sweep arrays (Lcap scores + predecessors) share the LDS with the row-type bitmasks + traceback windows
-  const size_t lds = std::max<size_t>((size_t)a->Lcap * 6 + 16, (size_t)16 * (((a->Ncap + 64) >> 6) + 1) + 1024 + 64);
+  const size_t lds = std::max<size_t>((size_t)a->Lcap * 6 + 16, (size_t)16 * (((a->Ncap + 64) >> 6) + 1) + 4 * 5 * 64 * 4 + 64);       // bitmasks + H ring (the traceback windows reuse the ring)
   hipLaunchKernelGGL(k_window, dim3(slots), dim3(64), lds, s, *a);
 }
 extern "C" void c3k_launch_stitch(const StitchArgs* a, int grid, hipStream_t s) { hipLaunchKernelGGL(k_stitch, dim3(grid), dim3(64), 0, s, *a); }

@@ -108,6 +108,9 @@ int c3o_poa_msa(const char* const* seqs, const int* lens, int n, const c3o_param
                 char* cons, int cons_cap, int* cons_len,
                 char* msa, int64_t msa_cap, int* msa_len, int64_t* cells);
 
+/* end-cell DP scores of the alignments of the last c3o_poa_msa call on this thread (checker hook); returns their number */
+int c3o_poa_last_scores(int32_t* out, int cap);
+
 /* bin/consensus.py pairwise_consensus: rows have msa_len chars */
 int c3o_pairwise_consensus(const char* rowA, const char* rowB, int msa_len,
                            const char* subA, int lenA, const char* qualA,

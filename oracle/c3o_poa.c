@@ -17,6 +17,12 @@
 #include <limits.h>
 #include "c3o_mem.h"
 
+/* DP score of the end cell of every sequence-to-graph alignment of the last c3o_poa_msa call on this thread: lets an
+ * independent brute-force aligner (tests/test_independent_checkers.py) check optimality without sharing any code */
+static __thread int32_t g_scores[256];
+static __thread int g_nscores = 0;
+int c3o_poa_last_scores(int32_t* out, int cap) { int n = g_nscores < cap ? g_nscores : cap; for (int i = 0; i < n; ++i) out[i] = g_scores[i]; return g_nscores; }
+
 #define SRC 0
 #define SNK 1
 
@@ -189,6 +195,7 @@ static int poa_align(const c3o_graph* g, const uint8_t* q, int Q, const c3o_para
     int32_t h = rd(&m, m.H, pi, Q);
     if (h > bs) { bs = h; bi = pi; }
   }
+  if (g_nscores < 256) g_scores[g_nscores++] = bs;       /* checker hook: see c3o_poa_last_scores */
   int rc = 0;
   if (bi < 0 || bs <= C3O_NEG / 2) rc = -1;
   else {
@@ -331,6 +338,7 @@ static int c3o_poa_msa_impl(const char* const* seqs, const int* lens, int n, con
   if (cons_len) *cons_len = 0;
   if (msa_len) *msa_len = 0;
   if (n <= 0) return 0;                       /* msa([]) -> empty result */
+  g_nscores = 0;
   c3o_poa_state st;
   int rc = c3o_poa_build(seqs, lens, n, P, &st, &cl);
   if (cells) *cells += cl;

@@ -177,6 +177,13 @@ def poa_msa(seqs, out_cons=True, out_msa=True, params=None):
     return c, m, cells.value
 
 
+def poa_last_scores():
+    """end-cell DP scores of the sequence-to-graph alignments of the last poa_msa call (one per sequence after the first)"""
+    out = (C.c_int32 * 256)()
+    n = lib().c3o_poa_last_scores(out, 256)
+    return [int(out[i]) for i in range(min(n, 256))]
+
+
 def normalize_len(row, qual):
     r, q = _b(row), _b(qual)
     out = C.create_string_buffer(len(r) + 8)
