@@ -499,10 +499,8 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
         hcur[cc] = k2 & ~0xff;
         w2 |= (((unsigned)k2 >> 6) & 3u) << (2 * cc);
       }
-      if (lane * CPL <= Q) {
-        if (CPL <= 8) ((unsigned short*)(c.D + (size_t)r * RSD))[lane] = (unsigned short)w2;       // 16 bits hold 8 cells: 128 bytes per row
-        else ((unsigned*)(c.D + (size_t)r * RSD))[lane] = w2;
-      }
+      if (CPL <= 8) ((unsigned short*)(c.D + (size_t)r * RSD))[lane] = (unsigned short)w2;         // 16 bits hold 8 cells: 128 bytes per row
+      else ((unsigned*)(c.D + (size_t)r * RSD))[lane] = w2;
     } else {
       unsigned dpk[DS / 4];
 #pragma unroll
@@ -516,14 +514,12 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
         dpk[cc / 4] |= (unsigned)(k2 & 0xff) << (8 * (cc & 3));
       }
       unsigned* drow = (unsigned*)(c.D + (size_t)r * RSD) + lane * (DS / 4);
-      if (lane * CPL <= Q) {
 #pragma unroll
-        for (int w = 0; w < DS / 4; ++w) drow[w] = dpk[w];
-      }
+      for (int w = 0; w < DS / 4; ++w) drow[w] = dpk[w];
     }
     if (needh) {
 #pragma unroll
-      for (int cc = 0; cc < CPL; ++cc) if (lane * CPL + cc <= Q) hrow[cc * 64 + lane] = (short)(hcur[cc] >> 8);
+      for (int cc = 0; cc < CPL; ++cc) hrow[cc * 64 + lane] = (short)(hcur[cc] >> 8);      // (columns past Q: inside the row, never read)
       if (C3_WIN_RING) {
       const int sl = rnext;
       rnext = (rnext + 1) & 3;
