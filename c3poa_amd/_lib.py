@@ -19,7 +19,7 @@ EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_create", "c
            "c3_batch_upload", "c3_batch_stage", "c3_batch_commit", "c3_batch_assign", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_timing",
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
            "c3_call_peaks", "c3_poa_msa", "c3_pairwise_consensus", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
-           "c3_reader_open", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_reader_next_set", "c3_write_group",
+           "c3_reader_open", "c3_reader_open_range", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_reader_next_set", "c3_write_group",
            "c3_scan_adapters", "c3_match_index", "c3_match_index_batch",
            "c3_assign_open", "c3_assign_close", "c3_assign_batch", "c3_assign_seen", "c3_write_splint_psl",
            "c3_host_alloc", "c3_host_free"]
@@ -111,6 +111,7 @@ def load():
     lib.c3_host_free.argtypes = [vp]
     lib.c3_host_free.restype = None
     lib.c3_reader_open.argtypes = [cp, C.c_int, C.POINTER(vp)]
+    lib.c3_reader_open_range.argtypes = [cp, C.c_int, C.c_int64, C.c_int64, C.POINTER(vp)]
     lib.c3_reader_close.argtypes = [vp]
     lib.c3_reader_close.restype = None
     lib.c3_reader_error.argtypes = [vp]
@@ -488,10 +489,15 @@ class HostBatch:
 class Reader:
     """native streaming FASTA/FASTQ(.gz) reader (c3_reader_*): mm.fastx_read replacement that yields SoA groups"""
 
-    def __init__(self, path, n_sets=3, names_only=False):
+    def __init__(self, path, n_sets=3, names_only=False, byte_range=None):
+        """byte_range = (beg, end): only the records that START inside [beg, end) (plain files; c3_reader_open_range)"""
         self.lib = load()
         self.r = C.c_void_p()
-        if self.lib.c3_reader_open(_b(str(path)), n_sets, C.byref(self.r)) != 0:
+        if byte_range is None:
+            rc = self.lib.c3_reader_open(_b(str(path)), n_sets, C.byref(self.r))
+        else:
+            rc = self.lib.c3_reader_open_range(_b(str(path)), n_sets, int(byte_range[0]), int(byte_range[1]), C.byref(self.r))
+        if rc != 0:
             raise OSError("cannot open %s" % path)
         if names_only:
             self.lib.c3_reader_names_only(self.r, 1)

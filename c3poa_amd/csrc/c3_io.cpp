@@ -71,13 +71,15 @@ struct c3_reader {
   int64_t n_records = 0;
   bool names_only = false;
   size_t file_bytes = 0, hint_bases = 0;
+  int64_t buf_off = 0;          // file offset of buf[0] (plain files)
+  int64_t range_end = -1;       // byte range readers stop at the first record that starts at or after this offset
 };
 
 namespace {
 
 bool refill(c3_reader* r) {
   if (r->eof) return false;
-  if (r->beg > 0) { memmove(r->buf.data(), r->buf.data() + r->beg, r->end - r->beg); r->end -= r->beg; r->beg = 0; }
+  if (r->beg > 0) { memmove(r->buf.data(), r->buf.data() + r->beg, r->end - r->beg); r->end -= r->beg; r->buf_off += (int64_t)r->beg; r->beg = 0; }
   if (r->end == r->buf.size()) r->buf.resize(r->buf.size() * 2);
   size_t room = r->buf.size() - r->end;
   long got = r->gz ? (long)gzread(r->gz, r->buf.data() + r->end, (unsigned)std::min<size_t>(room, 1u << 30))
@@ -153,6 +155,74 @@ extern "C" int c3_reader_open(const char* path, int n_sets, c3_reader** out) {
   return C3_E_OK;
 }
 
+namespace {
+
+// Is `p` (a line start inside [buf, buf+n)) the header of a record?  FASTA: '>' is unambiguous.  FASTQ: '@' also opens
+// quality lines, so the 4-line shape is checked: '@' line, sequence, '+' line, quality of the same length as the sequence.
+// Returns 1 yes, 0 no, -1 cannot tell (window too short).
+int record_starts_at(const char* buf, size_t n, size_t p, bool fastq) {
+  if (p >= n) return -1;
+  if (!fastq) return buf[p] == '>' ? 1 : 0;            // ('>' is also a quality character: the file's first byte decides)
+  if (buf[p] != '@') return 0;
+  size_t ls[5]; ls[0] = p;
+  for (int k = 1; k < 5; ++k) {
+    const char* nl = (const char*)memchr(buf + ls[k - 1], '\n', n - ls[k - 1]);
+    if (!nl) return -1;
+    ls[k] = (size_t)(nl - buf) + 1;
+    if (k < 4 && ls[k] >= n) return -1;
+  }
+  if (buf[ls[2]] != '+') return 0;
+  auto len = [&](int k) { size_t l = ls[k + 1] - ls[k] - 1; if (l && buf[ls[k] + l - 1] == '\r') --l; return l; };
+  return len(1) == len(3) && len(1) > 0 ? 1 : 0;
+}
+
+}  // namespace
+
+// Reader over the byte range [beg, end) of a plain (not gzip) FASTA / 4-line FASTQ file: starts at the first record that
+// begins at or after `beg`, stops before the first record that begins at or after `end` -- ranges that tile the file read
+// every record exactly once.  Lets every GPU worker parse its own contiguous part of the input (the reference hands 1000-read
+// groups to a process pool, C3POa.py:236-256).  end < 0 = end of file.
+extern "C" int c3_reader_open_range(const char* path, int n_sets, int64_t beg, int64_t end, c3_reader** out) {
+  if (!path || !out || beg < 0) return C3_E_ARG;
+  size_t n = strlen(path);
+  if (n > 3 && strcmp(path + n - 3, ".gz") == 0) return C3_E_ARG;              // a gzip stream cannot be entered in the middle
+  int rc = c3_reader_open(path, n_sets, out);
+  if (rc != C3_E_OK) return rc;
+  c3_reader* r = *out;
+  r->range_end = end;
+  if (beg == 0) return C3_E_OK;
+  int c0 = fgetc(r->fp);
+  const bool fastq = c0 == '@';
+  // resync: scan forward from beg-1 (so a record starting exactly at beg is found) for a line start that opens a record
+  std::vector<char> win((size_t)8 << 20);
+  int64_t at = beg - 1;
+  for (;;) {
+    if (fseek(r->fp, (long)at, SEEK_SET) != 0) { c3_reader_close(r); *out = nullptr; return C3_E_ARG; }
+    const size_t got = fread(win.data(), 1, win.size(), r->fp);
+    if (got == 0) { r->eof = true; r->buf_off = at; return C3_E_OK; }            // nothing left: an empty range
+    size_t p = 0; bool found = false, grow = false;
+    while (p < got) {
+      const char* nl = (const char*)memchr(win.data() + p, '\n', got - p);
+      if (!nl) break;
+      p = (size_t)(nl - win.data()) + 1;
+      if (p >= got) break;
+      const int st = record_starts_at(win.data(), got, p, fastq);
+      if (st == 1) { found = true; break; }
+      if (st < 0) { grow = got == win.size(); break; }
+    }
+    if (found) {
+      at += (int64_t)p;
+      if (fseek(r->fp, (long)at, SEEK_SET) != 0) { c3_reader_close(r); *out = nullptr; return C3_E_ARG; }
+      r->buf_off = at;
+      if (end >= 0 && at >= end) r->eof = true;                                    // the range holds no record start
+      return C3_E_OK;
+    }
+    if (grow && win.size() < ((size_t)1 << 30)) { win.resize(win.size() * 4); continue; }     // a record longer than the window
+    if (got < win.size()) { r->eof = true; r->buf_off = at; return C3_E_OK; }      // reached the end of the file without a record
+    at += (int64_t)got - 1;                                                         // no line start decided: keep scanning
+  }
+}
+
 extern "C" void c3_reader_close(c3_reader* r) {
   if (!r) return;
   if (r->gz) gzclose(r->gz);
@@ -191,6 +261,7 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
     if (!next_line(r, &p, &l)) break;
     if (l == 0) continue;
     if (p[0] != '>' && p[0] != '@') return fail(r, "not FASTA/FASTQ: record does not start with '>' or '@'");
+    if (r->range_end >= 0 && r->buf_off + (int64_t)(p - r->buf.data()) >= r->range_end) { r->eof = true; r->beg = r->end; break; }   // next range's record
     // name = header up to the first blank (read_comment=False)
     size_t nl = 1; while (nl < l && p[nl] != ' ' && p[nl] != '\t') ++nl;
     if (!s.names.reserve(nn + nl, nn)) return C3_E_NOMEM;

@@ -24,6 +24,8 @@ from . import _lib
 GPU_BATCH_READS = 131072         # enough reads to fill 256 CUs many times over (bench.py runs 100 000 per step)
 HANDLES_PER_GPU = 1              # measured: two handles per GPU make the persistent kernels fight for CUs (0.55x)
 GPU_BATCH_BASES = 1 << 30        # bound on host/device memory per batch
+READERS_PER_GPU = 2              # byte-range readers (parser threads) per GPU worker
+MIN_RANGE_BYTES = 256 << 20      # no point in cutting small inputs
 
 
 def count_reads(path, lencutoff, assigner):
@@ -89,60 +91,110 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
     gpu_batch = int(os.environ.get("C3_GPU_BATCH_READS", "0"))
     batch_reads = gpu_batch if gpu_batch > 0 else max(int(args.groupSize), GPU_BATCH_READS)
     n_work = n_dev * int(os.environ.get("C3_HANDLES_PER_GPU", HANDLES_PER_GPU))
-    n_sets = 2 * n_work + 3
-    rd = _lib.Reader(args.reads, n_sets=n_sets)
-    # Ownership of the host buffers is explicit: the reader fills buffer set k only after taking k from this free list,
-    # and the writer puts k back once the group has been written (device threads finish out of order, so a counting
-    # semaphore over round-robin sets would let the reader overwrite a set a lagging device still holds).  Result buffers
-    # follow the same rule: one object per batch in flight, returned by the writer.
-    free_sets = queue.Queue()
-    for k in range(n_sets):
-        free_sets.put(k)
+    # ---- the input is cut into contiguous BYTE RANGES, one native reader (thread) per range, READERS_PER_GPU ranges per
+    # worker: every GPU parses its own part of the file ("contiguous file ranges per GPU"), and one parser
+    # thread (~1.7 GB/s of FASTQ) no longer caps the node.  Range k writes its records to part files that are concatenated in
+    # range order at the end, so the output is byte-identical to a single sequential pass whatever the number of workers.
+    size = os.path.getsize(args.reads)
+    splittable = not str(args.reads).endswith(".gz") and size > 0
+    per_gpu = max(1, int(os.environ.get("C3_READERS_PER_GPU", READERS_PER_GPU)))
+    min_range = int(os.environ.get("C3_MIN_RANGE_BYTES", MIN_RANGE_BYTES))
+    n_ranges = max(1, min(n_work * per_gpu, size // max(min_range, 1))) if splittable else 1
+    n_ranges = max(n_ranges, 1)
+    cuts = [size * k // n_ranges for k in range(n_ranges)] + [-1]
+
+    def part(path, k):
+        return path if k == 0 else "%s.part%03d" % (path, k)
+    cons_parts = [[part(p_, k) for p_ in cons_paths] for k in range(n_ranges)]
+    sub_parts = [[part(p_, k) for p_ in sub_paths] for k in range(n_ranges)]
+    psl_parts = [part(finder_psl + ".part", k) for k in range(n_ranges)] if fused else None
+    for k in range(1, n_ranges):
+        for p_ in cons_parts[k] + sub_parts[k] + ([psl_parts[k]] if fused else []):
+            if os.path.dirname(p_) and os.path.isdir(os.path.dirname(p_)):
+                open(p_, "w").close()
+    # Ownership of the host buffers is explicit: a reader fills buffer set j only after taking j from its free list, and the
+    # writer puts j back once the group has been written (device threads finish out of order, so a counting semaphore over
+    # round-robin sets would let a reader overwrite a set a lagging device still holds).  Result buffers follow the same
+    # rule: one object per batch in flight, returned by the writer.
+    N_SETS = 5
+    readers = [_lib.Reader(args.reads, n_sets=N_SETS, byte_range=(cuts[k], cuts[k + 1])) if n_ranges > 1
+               else _lib.Reader(args.reads, n_sets=N_SETS) for k in range(n_ranges)]
+    free_sets = [queue.Queue() for _ in range(n_ranges)]
+    for fs in free_sets:
+        for j in range(N_SETS):
+            fs.put(j)
     free_results = queue.Queue()
-    for _k in range(2 * n_work + 2):
+    for _k in range(3 * n_work + 2):
         free_results.put(_lib.ResultBuffers())
-    parsed, to_write = queue.Queue(maxsize=n_work), queue.Queue(maxsize=n_work)
+    parsed = [queue.Queue(maxsize=1) for _ in range(n_ranges)]
+    to_write = [queue.Queue(maxsize=2) for _ in range(n_work)]
     t = dict(parse=0.0, assign=0.0, upload=0.0, upload_dev=0.0, run=0.0, run_dev=0.0, fetch=0.0, write=0.0, wait_in=0.0, wait_out=0.0,
-             setup=0.0, close=0.0, scan=0.0, reads=0, batches=0, short=0, assigned=0)
+             setup=0.0, close=0.0, scan=0.0, merge=0.0, reads=0, batches=0, short=0, assigned=0, ranges=n_ranges)
     seen = set()
     errors, lock = [], threading.Lock()
 
-    def reader_thread():                            # parse + splint/strand lookup, ahead of the GPUs
+    def reader_thread(k):                           # parse + splint/strand lookup of range k, ahead of its GPU
+        rd = readers[k]
         try:
             while not errors:
-                ks = free_sets.get()
+                ks = free_sets[k].get()
                 t0 = time.perf_counter()
                 hb = rd.next(batch_reads, args.lencutoff, GPU_BATCH_BASES, set_index=ks)
                 t1 = time.perf_counter()
                 if hb.n == 0:
-                    t["short"] += hb.n_short
-                    free_sets.put(ks)
+                    with lock:
+                        t["short"] += hb.n_short
+                    free_sets[k].put(ks)
                     break
                 if fused:
-                    sid, st, k = np.zeros(hb.n, dtype=np.int16), b"?" * hb.n, 0
+                    sid, st, na = np.zeros(hb.n, dtype=np.int16), b"?" * hb.n, 0
                 else:
-                    sid, st, k = assigner.batch(hb)
-                t["parse"] += t1 - t0; t["assign"] += time.perf_counter() - t1
-                t["reads"] += hb.n; t["batches"] += 1; t["short"] += hb.n_short; t["assigned"] += k
-                parsed.put((hb, sid, st))
+                    sid, st, na = assigner.batch(hb)
+                with lock:
+                    t["parse"] += t1 - t0; t["assign"] += time.perf_counter() - t1
+                    t["reads"] += hb.n; t["batches"] += 1; t["short"] += hb.n_short; t["assigned"] += na
+                hb.range_index = k
+                parsed[k].put((hb, sid, st))
         except Exception as e:                      # noqa: BLE001 -- re-raised by the caller's thread
             errors.append(e)
-        for _ in range(n_work):
-            parsed.put(None)
+        parsed[k].put(None)
 
-    def device_thread(dev):                         # one per GPU: c3_batch_run sizes its stages on the host, so it blocks
-        saw_end = [False]                           # this thread's end-of-input sentinel has been taken from the queue
+    def device_thread(w):                           # one per GPU: c3_batch_run sizes its stages on the host, so it blocks
+        dev = w % n_dev
+        mine = [k for k in range(n_ranges) if k % n_work == w]      # the ranges this worker serves, round-robin
+        live = list(mine)
+        rr = [0]
 
         def take(block=True):
+            """next parsed batch of one of this worker's ranges (round-robin); None when all of them are exhausted"""
             tw = time.perf_counter()
             try:
-                item = parsed.get() if block else parsed.get_nowait()
+                while live:
+                    for step in range(len(live)):
+                        k = live[(rr[0] + step) % len(live)]
+                        try:
+                            item = parsed[k].get_nowait()
+                        except queue.Empty:
+                            continue
+                        if item is None:
+                            live.remove(k)
+                            break                                       # list changed: rescan
+                        rr[0] = (live.index(k) + 1) % len(live)
+                        return item
+                    else:
+                        if not block:
+                            raise queue.Empty
+                        k = live[rr[0] % len(live)]
+                        item = parsed[k].get()
+                        if item is None:
+                            live.remove(k)
+                            continue
+                        rr[0] = (live.index(k) + 1) % len(live)
+                        return item
+                return None
             finally:
                 with lock:
                     t["wait_in"] += time.perf_counter() - tw
-            if item is None:
-                saw_end[0] = True
-            return item
 
         try:
             ts = time.perf_counter()
@@ -150,7 +202,7 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
             h.set_splints([splint_dict[n][0] for n in splint_names])
             with lock:
                 t["setup"] += time.perf_counter() - ts
-            # software pipeline on one handle: while batch i runs, batch i+1 (if the reader already has it) is copied
+            # software pipeline on one handle: while batch i runs, batch i+1 (if a reader already has it) is copied
             # and 2-bit packed on the handle's second stream (c3_batch_stage); c3_batch_commit makes it resident once
             # the results of batch i have been fetched
             cur = take()
@@ -167,8 +219,8 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                     tab, sid, st = h.scan_splints()
                     h.assign(sid, st)
                     with lock:
-                        k = _lib.write_splint_psl(hb, tab, sid, st, splint_names, sp_lens, h.cfg.conk_match, finder_psl + ".part")
-                        t["assigned"] += k; t["scan"] += time.perf_counter() - ts
+                        na = _lib.write_splint_psl(hb, tab, sid, st, splint_names, sp_lens, h.cfg.conk_match, psl_parts[hb.range_index])
+                        t["assigned"] += na; t["scan"] += time.perf_counter() - ts
                         seen.update(splint_names[x] for x in np.unique(sid[sid >= 0]))
                 nxt, staged = None, False
                 try:
@@ -186,8 +238,8 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                 t1 = time.perf_counter()
                 h.run()
                 t2 = time.perf_counter()
-                up_dev = h.timing()["ms_pack"] * 1e-3
-                run_dev = h.timing()["ms_total"] * 1e-3
+                up_dev = h.last_timing["ms_pack"] * 1e-3
+                run_dev = h.last_timing["ms_total"] * 1e-3
                 rb = free_results.get()
                 res, buf, coff = h.results_raw(into=rb)
                 t3 = time.perf_counter()
@@ -195,12 +247,12 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                     t["upload_dev"] += up_dev; t["run_dev"] += run_dev
                     t["run"] += t2 - t1; t["fetch"] += t3 - t2
                 tw = time.perf_counter()
-                to_write.put((hb, sid, res, buf, coff, rb))
+                to_write[w].put((hb, sid, res, buf, coff, rb))
                 with lock:
                     t["wait_out"] += time.perf_counter() - tw
                 if done:
                     break
-                if nxt is None:                                   # the reader was not ahead: wait for it now
+                if nxt is None:                                   # no reader was ahead: wait for one now
                     nxt = take()
                     if nxt is None:
                         break
@@ -218,40 +270,67 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                 t["close"] += time.perf_counter() - tc
         except Exception as e:                      # noqa: BLE001
             errors.append(e)
-        while not saw_end[0]:                       # keep draining so the reader never blocks on a full queue
-            take()
-        to_write.put(None)
+        while live:                                 # keep draining so no reader blocks on a full queue
+            try:
+                take()
+            except Exception:                       # noqa: BLE001
+                break
+        to_write[w].put(None)
 
-    def writer_thread():                            # c3_write_group releases the GIL: overlaps parsing and the GPUs
-        live = n_work
-        while live:
-            item = to_write.get()
+    def writer_thread(w):                           # c3_write_group releases the GIL: overlaps parsing and the GPUs
+        while True:
+            item = to_write[w].get()
             if item is None:
-                live -= 1
-                continue
+                break
             hb, sid, res, buf, coff, rb = item
             t0 = time.perf_counter()
             try:
                 if not errors:
-                    _lib.write_group(hb, res, buf, coff, sid, cons_paths, sub_paths, getattr(args, "zero", True))
+                    k = hb.range_index
+                    _lib.write_group(hb, res, buf, coff, sid, cons_parts[k], sub_parts[k], getattr(args, "zero", True))
             except Exception as e:                  # noqa: BLE001
                 errors.append(e)
-            t["write"] += time.perf_counter() - t0
-            k = hb.set_index
+            with lock:
+                t["write"] += time.perf_counter() - t0
+            k, j = hb.range_index, hb.set_index
             del hb, item, res, buf, coff
             free_results.put(rb)
-            free_sets.put(k)
+            free_sets[k].put(j)
 
-    threads = [threading.Thread(target=reader_thread, daemon=True), threading.Thread(target=writer_thread, daemon=True)]
-    threads += [threading.Thread(target=device_thread, args=(w % n_dev,), daemon=True) for w in range(n_work)]
-    for th in threads:
+    rthreads = [threading.Thread(target=reader_thread, args=(k,), daemon=True) for k in range(n_ranges)]
+    others = [threading.Thread(target=writer_thread, args=(w,), daemon=True) for w in range(n_work)]
+    others += [threading.Thread(target=device_thread, args=(w,), daemon=True) for w in range(n_work)]
+    for th in rthreads + others:
         th.start()
-    for th in threads[1:]:
+    for th in others:
         th.join()
     if errors:
         raise errors[0]
-    threads[0].join()
-    rd.close()
+    for th in rthreads:
+        th.join()
+    for rd in readers:
+        rd.close()
+    # ---- parts -> final files, in range order (range 0 wrote into the final file itself)
+    tm0 = time.perf_counter()
+    if n_ranges > 1:
+        finals = list(zip(cons_paths, *[cons_parts[k] for k in range(1, n_ranges)])) + \
+                 list(zip(sub_paths, *[sub_parts[k] for k in range(1, n_ranges)]))
+        if fused:
+            finals.append(tuple([finder_psl + ".part"] + psl_parts[1:]))
+        for group in finals:
+            final, parts = group[0], group[1:]
+            if not os.path.exists(final):
+                for p_ in parts:
+                    if os.path.exists(p_):
+                        os.remove(p_)
+                continue
+            with open(final, "ab") as dst:
+                for p_ in parts:
+                    if os.path.exists(p_):
+                        with open(p_, "rb") as src:
+                            shutil.copyfileobj(src, dst, 1 << 26)
+                        os.remove(p_)
+    t["merge"] = time.perf_counter() - tm0
     if fused:
         os.replace(finder_psl + ".part", finder_psl)              # a rerun finds the PSL and takes the two-pass route
         for n, cp, sp in zip(splint_names, cons_paths, sub_paths):

@@ -209,6 +209,10 @@ typedef struct c3_reader c3_reader;
 /* mm.fastx_read(path, read_comment=False) (C3POa.py:201,239): FASTA or FASTQ, multi-line, plain or .gz.
  * n_sets = how many groups stay valid at once (the buffers of a group are reused n_sets calls later). */
 int c3_reader_open(const char* path, int n_sets, c3_reader** out);
+/* the same over the byte range [beg, end) of a plain FASTA / 4-line FASTQ file: begins at the first record starting at or
+ * after beg, ends before the first record starting at or after end (end < 0: end of file), so ranges that tile the file
+ * read every record exactly once -- one reader per GPU worker (C3POa.py:236-256 sharded 1000-read groups over a pool) */
+int c3_reader_open_range(const char* path, int n_sets, int64_t beg, int64_t end, c3_reader** out);
 void c3_reader_close(c3_reader* r);
 const char* c3_reader_error(const c3_reader* r);
 /* names_only != 0: parse but do not store sequences/qualities (first pass of C3POa.py:200-207: names + counts) */

@@ -266,3 +266,45 @@ def test_native_splint_psl_rows_match_python_statement(tmp_path):
         e = tab[i, sid[i], 1 if st[i] == 45 else 0]
         want.append(preprocess.psl_row(recs[i][0], len(recs[i][1]), splints[sid[i]][0], splints[sid[i]][1], chr(st[i]), e[0], e[1], 5))
     assert open(psl).read().splitlines() == want + want and rows == 2 * len(want) and len(want) > 100
+
+
+def test_byte_range_readers_tile_the_file(tmp_path):
+    """c3_reader_open_range: ranges that tile the file read every record exactly once, in order -- also when quality
+    lines start with '@' (the FASTQ resync trap), with CRLF, and for FASTA (C3POa.py:236-256 shards reads over workers)"""
+    rng = np.random.default_rng(3)
+    recs = []
+    for i in range(300):
+        L = int(rng.integers(30, 400))
+        s = "".join("ACGT"[k] for k in rng.integers(0, 4, L))
+        q = "".join(chr(33 + int(v)) for v in rng.integers(0, 42, L))
+        if i % 3 == 0:
+            q = "@" + q[1:]                                  # quality line that looks like a header
+        if i % 7 == 0:
+            q = "@" + q[1:-1] + "+"
+        recs.append(("r%d extra words" % i, s, q))
+    for name, text in (("a.fastq", "".join("@%s\n%s\n+\n%s\n" % r for r in recs)),
+                       ("b.fastq", "".join("@%s\r\n%s\r\n+\r\n%s\r\n" % r for r in recs)),
+                       ("c.fasta", "".join(">%s\n%s\n" % (r[0], r[1]) for r in recs))):
+        p = str(tmp_path / name)
+        open(p, "w", newline="").write(text)
+        size = os.path.getsize(p)
+        whole = []
+        rd = _lib.Reader(p, n_sets=1)
+        while True:
+            hb = rd.next(64)
+            if hb.n == 0:
+                break
+            whole += [hb.read(i) for i in range(hb.n)]
+        assert [w[0] for w in whole] == ["r%d" % i for i in range(300)]
+        for cuts in ([0, size // 3, 2 * size // 3, size], [0, 1, 2, 50, size // 2, size // 2 + 1, size - 1, size],
+                     sorted([0, size] + [int(x) for x in rng.integers(0, size, 9)])):
+            got = []
+            for b, e in zip(cuts, cuts[1:]):
+                rr = _lib.Reader(p, n_sets=1, byte_range=(b, e))
+                while True:
+                    hb = rr.next(17)
+                    if hb.n == 0:
+                        break
+                    got += [hb.read(i) for i in range(hb.n)]
+                rr.close()
+            assert got == whole, (name, cuts)

@@ -80,7 +80,7 @@ class FakeHandle:
         pass
 
 
-def _run(tmp_path, tag, recs, n_dev, batch, monkeypatch):
+def _run(tmp_path, tag, recs, n_dev, batch, monkeypatch, readers_per_gpu=1, raw=False):
     out = str(tmp_path / tag) + "/"
     os.makedirs(out)
     fq = str(tmp_path / "reads.fastq")
@@ -90,12 +90,17 @@ def _run(tmp_path, tag, recs, n_dev, batch, monkeypatch):
                 fh.write("@%s\n%s\n+\n%s\n" % (r[0], r[1], r[2]))
     monkeypatch.setattr(_lib, "Handle", FakeHandle)
     monkeypatch.setenv("C3_GPU_BATCH_READS", str(batch))
+    monkeypatch.setenv("C3_READERS_PER_GPU", str(readers_per_gpu))
+    monkeypatch.setenv("C3_MIN_RANGE_BYTES", "1")
     args = types.SimpleNamespace(out_path=out, reads=fq, groupSize=1000, lencutoff=1000, mdistcutoff=500, zero=True,
                                  compress_output=False)
     sd = {"Splint1": [synth.SPLINT1, revcomp(synth.SPLINT1)]}
     adapter = {r[0]: ["Splint1", r[3]] for r in recs}
     n = stream.run(args, sd, adapter, {"Splint1"}, n_dev)
     assert n == len(recs)
+    assert sorted(os.listdir(out + "Splint1")) == ["R2C2_Consensus.fasta", "R2C2_Subreads.fastq"]       # no part file left
+    if raw:
+        return open(out + "Splint1/R2C2_Consensus.fasta", "rb").read(), open(out + "Splint1/R2C2_Subreads.fastq", "rb").read()
     return (sorted(fastx_read(out + "Splint1/R2C2_Consensus.fasta")), sorted(fastx_read(out + "Splint1/R2C2_Subreads.fastq")))
 
 
@@ -110,3 +115,13 @@ def test_three_workers_out_of_order_equal_one_worker(tmp_path, monkeypatch):
     for name, seq, qual in many[1][::7]:
         src = byname[name.rsplit("_", 1)[0]]
         assert seq in src[1] and qual in src[2]
+
+
+def test_byte_range_readers_give_the_sequential_output(tmp_path, monkeypatch):
+    """2 workers x 3 byte-range readers each (6 parser threads over 6 contiguous parts of the FASTQ): the part files are
+    concatenated in range order, so the output is byte for byte that of one sequential pass"""
+    recs = list(synth.generate("cfg1", n_reads=50))
+    one = _run(tmp_path, "one", recs, 1, 1000, monkeypatch, raw=True)
+    many = _run(tmp_path, "many", recs, 2, 3, monkeypatch, readers_per_gpu=3, raw=True)
+    assert one == many
+    assert one[0].count(b">") == 50
