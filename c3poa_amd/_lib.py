@@ -22,7 +22,7 @@ EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_create", "c
            "c3_reader_open", "c3_reader_open_range", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_reader_next_set", "c3_write_group",
            "c3_scan_adapters", "c3_match_index", "c3_match_index_batch",
            "c3_assign_open", "c3_assign_close", "c3_assign_batch", "c3_assign_seen", "c3_write_splint_psl",
-           "c3_host_alloc", "c3_host_free"]
+           "c3_host_alloc", "c3_host_free", "c3_writer_reset"]
 
 
 class Config(C.Structure):
@@ -110,6 +110,7 @@ def load():
     lib.c3_host_alloc.argtypes = [C.c_int64, C.POINTER(vp)]
     lib.c3_host_free.argtypes = [vp]
     lib.c3_host_free.restype = None
+    lib.c3_writer_reset.restype = None
     lib.c3_reader_open.argtypes = [cp, C.c_int, C.POINTER(vp)]
     lib.c3_reader_open_range.argtypes = [cp, C.c_int, C.c_int64, C.c_int64, C.POINTER(vp)]
     lib.c3_reader_close.argtypes = [vp]

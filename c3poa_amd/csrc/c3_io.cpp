@@ -19,7 +19,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/c3poa.h"
@@ -383,6 +385,24 @@ bool pwrite_all(int fd, const char* p, size_t n, off_t at) {
 // _0,_1 are written before the rescue is tried (:108-114); consensus header name_avgQ_rawLen_repeats_consLen (C3POa.py:168-171).
 // The group is cut into contiguous read ranges that are formatted and written (pwrite at precomputed offsets) by a few
 // threads: record order in the files is read order, exactly as with one thread.
+namespace {
+// Append reservations per output file: a group's bytes go to [at, at + total) of the file, where `at` is handed out under a
+// lock, so the writer threads of several GPU workers can format and pwrite into ONE file concurrently (no part files, no
+// merge pass).  c3_writer_reset forgets the table (the caller truncates its files at the start of a run).
+std::mutex g_res_mu;
+std::unordered_map<std::string, off_t> g_res_next;
+off_t reserve_append(const char* path, int fd, size_t total) {
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  const off_t end = lseek(fd, 0, SEEK_END);
+  auto it = g_res_next.find(path);
+  off_t at = (it == g_res_next.end()) ? end : std::max(end, it->second);
+  g_res_next[path] = at + (off_t)total;
+  return at;
+}
+}  // namespace
+
+extern "C" void c3_writer_reset(void) { std::lock_guard<std::mutex> lk(g_res_mu); g_res_next.clear(); }
+
 extern "C" int c3_write_group(const c3_host_batch* b, const c3_read_result* res, const char* cons, const int64_t* cons_off,
                               const int16_t* splint_id, int n_splints, const char* const* cons_paths,
                               const char* const* sub_paths, int zero) {
@@ -415,7 +435,7 @@ extern "C" int c3_write_group(const c3_host_batch* b, const c3_read_result* res,
       int fd = open(path, O_WRONLY | O_CREAT, 0644);
       if (fd < 0) { ok = false; break; }
       fds.push_back(fd);
-      off_t at = lseek(fd, 0, SEEK_END);
+      off_t at = reserve_append(path, fd, total);           // several writer threads (one per GPU worker) append to one file
       for (int k = 0; k < T; ++k) {
         const std::string& x = (kind ? os : oc)[(size_t)k][(size_t)s];
         if (!x.empty()) { jobs[(size_t)k].push_back({fd, &x, at}); at += (off_t)x.size(); }

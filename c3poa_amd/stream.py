@@ -93,25 +93,19 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
     n_work = n_dev * int(os.environ.get("C3_HANDLES_PER_GPU", HANDLES_PER_GPU))
     # ---- the input is cut into contiguous BYTE RANGES, one native reader (thread) per range, READERS_PER_GPU ranges per
     # worker: every GPU parses its own part of the file ("contiguous file ranges per GPU"), and one parser
-    # thread (~1.7 GB/s of FASTQ) no longer caps the node.  Range k writes its records to part files that are concatenated in
-    # range order at the end, so the output is byte-identical to a single sequential pass whatever the number of workers.
+    # thread (~2 GB/s of FASTQ) no longer caps the node.  All workers append to the same output files (c3_write_group
+    # reserves each group's byte range under a lock): no per-group temp files, no merge pass (C3POa.py:259-271 concatenates
+    # <splint>/tmp<k>/ directories in glob order -- the reference's record order is arbitrary as well; here it is the
+    # round-robin order of the ranges, and the file order itself with a single range).
     size = os.path.getsize(args.reads)
     splittable = not str(args.reads).endswith(".gz") and size > 0
     per_gpu = max(1, int(os.environ.get("C3_READERS_PER_GPU", READERS_PER_GPU)))
     min_range = int(os.environ.get("C3_MIN_RANGE_BYTES", MIN_RANGE_BYTES))
     n_ranges = max(1, min(n_work * per_gpu, size // max(min_range, 1))) if splittable else 1
-    n_ranges = max(n_ranges, 1)
     cuts = [size * k // n_ranges for k in range(n_ranges)] + [-1]
-
-    def part(path, k):
-        return path if k == 0 else "%s.part%03d" % (path, k)
-    cons_parts = [[part(p_, k) for p_ in cons_paths] for k in range(n_ranges)]
-    sub_parts = [[part(p_, k) for p_ in sub_paths] for k in range(n_ranges)]
-    psl_parts = [part(finder_psl + ".part", k) for k in range(n_ranges)] if fused else None
-    for k in range(1, n_ranges):
-        for p_ in cons_parts[k] + sub_parts[k] + ([psl_parts[k]] if fused else []):
-            if os.path.dirname(p_) and os.path.isdir(os.path.dirname(p_)):
-                open(p_, "w").close()
+    if gpu_batch <= 0:
+        batch_reads = max(batch_reads // max(1, n_ranges // n_work), 16384)       # same page-locked footprint per GPU as one reader
+    _lib.load().c3_writer_reset()
     # Ownership of the host buffers is explicit: a reader fills buffer set j only after taking j from its free list, and the
     # writer puts j back once the group has been written (device threads finish out of order, so a counting semaphore over
     # round-robin sets would let a reader overwrite a set a lagging device still holds).  Result buffers follow the same
@@ -129,7 +123,7 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
     parsed = [queue.Queue(maxsize=1) for _ in range(n_ranges)]
     to_write = [queue.Queue(maxsize=2) for _ in range(n_work)]
     t = dict(parse=0.0, assign=0.0, upload=0.0, upload_dev=0.0, run=0.0, run_dev=0.0, fetch=0.0, write=0.0, wait_in=0.0, wait_out=0.0,
-             setup=0.0, close=0.0, scan=0.0, merge=0.0, reads=0, batches=0, short=0, assigned=0, ranges=n_ranges)
+             setup=0.0, close=0.0, scan=0.0, reads=0, batches=0, short=0, assigned=0, ranges=n_ranges)
     seen = set()
     errors, lock = [], threading.Lock()
 
@@ -166,31 +160,21 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
         rr = [0]
 
         def take(block=True):
-            """next parsed batch of one of this worker's ranges (round-robin); None when all of them are exhausted"""
+            """next parsed batch of this worker's ranges in STRICT round-robin (the record order of a run does not depend on
+            thread timing); None when all ranges are exhausted; block=False raises queue.Empty when the range whose turn it is
+            has nothing ready"""
             tw = time.perf_counter()
             try:
                 while live:
-                    for step in range(len(live)):
-                        k = live[(rr[0] + step) % len(live)]
-                        try:
-                            item = parsed[k].get_nowait()
-                        except queue.Empty:
-                            continue
-                        if item is None:
-                            live.remove(k)
-                            break                                       # list changed: rescan
-                        rr[0] = (live.index(k) + 1) % len(live)
-                        return item
-                    else:
-                        if not block:
-                            raise queue.Empty
-                        k = live[rr[0] % len(live)]
-                        item = parsed[k].get()
-                        if item is None:
-                            live.remove(k)
-                            continue
-                        rr[0] = (live.index(k) + 1) % len(live)
-                        return item
+                    k = live[rr[0] % len(live)]
+                    item = parsed[k].get() if block else parsed[k].get_nowait()
+                    if item is None:
+                        i = live.index(k)
+                        live.remove(k)
+                        rr[0] = i                                     # the next range moved into this position
+                        continue
+                    rr[0] = (live.index(k) + 1) % len(live)
+                    return item
                 return None
             finally:
                 with lock:
@@ -219,7 +203,7 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                     tab, sid, st = h.scan_splints()
                     h.assign(sid, st)
                     with lock:
-                        na = _lib.write_splint_psl(hb, tab, sid, st, splint_names, sp_lens, h.cfg.conk_match, psl_parts[hb.range_index])
+                        na = _lib.write_splint_psl(hb, tab, sid, st, splint_names, sp_lens, h.cfg.conk_match, finder_psl + ".part")
                         t["assigned"] += na; t["scan"] += time.perf_counter() - ts
                         seen.update(splint_names[x] for x in np.unique(sid[sid >= 0]))
                 nxt, staged = None, False
@@ -286,8 +270,7 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
             t0 = time.perf_counter()
             try:
                 if not errors:
-                    k = hb.range_index
-                    _lib.write_group(hb, res, buf, coff, sid, cons_parts[k], sub_parts[k], getattr(args, "zero", True))
+                    _lib.write_group(hb, res, buf, coff, sid, cons_paths, sub_paths, getattr(args, "zero", True))
             except Exception as e:                  # noqa: BLE001
                 errors.append(e)
             with lock:
@@ -310,27 +293,6 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
         th.join()
     for rd in readers:
         rd.close()
-    # ---- parts -> final files, in range order (range 0 wrote into the final file itself)
-    tm0 = time.perf_counter()
-    if n_ranges > 1:
-        finals = list(zip(cons_paths, *[cons_parts[k] for k in range(1, n_ranges)])) + \
-                 list(zip(sub_paths, *[sub_parts[k] for k in range(1, n_ranges)]))
-        if fused:
-            finals.append(tuple([finder_psl + ".part"] + psl_parts[1:]))
-        for group in finals:
-            final, parts = group[0], group[1:]
-            if not os.path.exists(final):
-                for p_ in parts:
-                    if os.path.exists(p_):
-                        os.remove(p_)
-                continue
-            with open(final, "ab") as dst:
-                for p_ in parts:
-                    if os.path.exists(p_):
-                        with open(p_, "rb") as src:
-                            shutil.copyfileobj(src, dst, 1 << 26)
-                        os.remove(p_)
-    t["merge"] = time.perf_counter() - tm0
     if fused:
         os.replace(finder_psl + ".part", finder_psl)              # a rerun finds the PSL and takes the two-pass route
         for n, cp, sp in zip(splint_names, cons_paths, sub_paths):

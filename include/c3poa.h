@@ -231,6 +231,11 @@ int c3_write_group(const c3_host_batch* b, const c3_read_result* res, const char
                    const int16_t* splint_id, int n_splints, const char* const* cons_paths,
                    const char* const* sub_paths, int zero);
 
+/* c3_write_group may be called from several threads on the same files (one writer per GPU worker): every call reserves its
+ * byte range at the end of each file under a lock.  c3_writer_reset forgets the reservations; call it after truncating the
+ * output files at the start of a run. */
+void c3_writer_reset(void);
+
 /* splint assignment from the PSL (bin/preprocess.py:22-45) without per-read host objects: rows with qBaseInsert < 50 and
  * matches > 50 count, per read the row with the most matches wins (the earliest on ties).  Host code. */
 typedef struct c3_assign c3_assign;

@@ -116,9 +116,12 @@ def test_cfg5_streamed_cli_multi_batch_equals_single_batch(tmp_path, with_psl):
     recs = list(synth.generate("cfg5", n_reads=n))
     fq, fa = _write_inputs(tmp_path, recs, with_psl)
     one = _cli(tmp_path, "one", fq, fa, recs, with_psl, {"C3_GPU_BATCH_READS": "100000"})
-    # 4 GPU batches per range x 3 byte-range readers (parser threads) feeding the GPU
-    many = _cli(tmp_path, "many", fq, fa, recs, with_psl, {"C3_GPU_BATCH_READS": "64", "C3_READERS_PER_GPU": "3", "C3_MIN_RANGE_BYTES": "1"})
+    many = _cli(tmp_path, "many", fq, fa, recs, with_psl, {"C3_GPU_BATCH_READS": "200"})
     assert _files(one) == _files(many)
+    # 4 GPU batches per range x 3 byte-range readers (parser threads) feeding the GPU: the same records, in the round-robin
+    # order of the ranges
+    ranged = _cli(tmp_path, "ranged", fq, fa, recs, with_psl, {"C3_GPU_BATCH_READS": "64", "C3_READERS_PER_GPU": "3", "C3_MIN_RANGE_BYTES": "1"})
+    assert _sorted_records(ranged) == _sorted_records(one) and _files(ranged)[2] == _files(one)[2]
     got = {nm: s for nm, s, _q in fastx_read(many + "/Splint1/R2C2_Consensus.fasta")}
     assert len(got) >= n - 2
     log = open(many + "/c3poa.log").read().splitlines()

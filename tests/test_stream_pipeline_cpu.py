@@ -117,11 +117,14 @@ def test_three_workers_out_of_order_equal_one_worker(tmp_path, monkeypatch):
         assert seq in src[1] and qual in src[2]
 
 
-def test_byte_range_readers_give_the_sequential_output(tmp_path, monkeypatch):
-    """2 workers x 3 byte-range readers each (6 parser threads over 6 contiguous parts of the FASTQ): the part files are
-    concatenated in range order, so the output is byte for byte that of one sequential pass"""
+def test_byte_range_readers_cover_the_file_once(tmp_path, monkeypatch):
+    """2 workers x 3 byte-range readers each (6 parser threads over 6 contiguous parts of the FASTQ), all appending to the
+    same output files: every record exactly once; and with ONE worker the record order is the strict round-robin of its
+    ranges, i.e. it does not depend on thread timing"""
     recs = list(synth.generate("cfg1", n_reads=50))
-    one = _run(tmp_path, "one", recs, 1, 1000, monkeypatch, raw=True)
-    many = _run(tmp_path, "many", recs, 2, 3, monkeypatch, readers_per_gpu=3, raw=True)
-    assert one == many
-    assert one[0].count(b">") == 50
+    one = _run(tmp_path, "one", recs, 1, 1000, monkeypatch)
+    many = _run(tmp_path, "many", recs, 2, 3, monkeypatch, readers_per_gpu=3)
+    assert one == many and len(one[0]) == 50
+    a = _run(tmp_path, "a", recs, 1, 4, monkeypatch, readers_per_gpu=3, raw=True)
+    b = _run(tmp_path, "b", recs, 1, 4, monkeypatch, readers_per_gpu=3, raw=True)
+    assert a == b and a[0].count(b">") == 50

@@ -43,7 +43,7 @@ try:
         def work(k):
             rd = _lib.Reader(fq, n_sets=2, byte_range=(cuts[k], cuts[k + 1])) if T > 1 else _lib.Reader(fq, n_sets=2)
             while True:
-                hb = rd.next(131072, 1000, 1 << 30)
+                hb = rd.next(16384, 1000, 1 << 30)           # small groups: the page-locked buffers stay small, the parse rate is measured
                 if hb.n == 0:
                     break
                 counts[k] += hb.n
