@@ -294,6 +294,14 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
     }
     ++r->n_records;
     if ((int64_t)sl < (int64_t)min_len) { ++n_short; continue; }     // dropped: buffers are simply overwritten
+    if (n == 0 && !r->names_only && !r->hint_bases && sl > 0) {
+      // first kept record of the very first group: size the buffers for max_reads records of this length in ONE page-locked
+      // allocation instead of a dozen grow-and-copy steps (page-locking is slow and serialised by the driver)
+      size_t want = (size_t)max_reads * (sl + sl / 4) + 4096;
+      if (max_bases > 0) want = std::min(want, (size_t)max_bases + sl + 4096);
+      want = std::min(want, (size_t)2 << 30);
+      if (!s.seqs.reserve(want, sb + sl) || !s.quals.reserve(want, sb + sl)) return C3_E_NOMEM;
+    }
     nn += name_len; nb += sl; ++n;
     s.name_off.push_back((int64_t)nn); s.off.push_back((int64_t)nb);
   }
