@@ -1,8 +1,8 @@
 """Streaming driver of the CLI: native FASTQ reader -> GPU batches -> native writer.
 
 Replaces the read loop / mp.Pool dispatch / per-group temp files of /root/reference/C3POa.py:236-271 with a software
-pipeline that keeps every GPU busy: while batch i runs on the device (c3_batch_run is asynchronous), the host parses
-batch i+1 and writes the records of batch i-1.  No per-read Python objects are created for sequences or qualities: the
+pipeline that keeps every GPU busy: while batch i runs on the device (its worker thread blocks in c3_batch_run, which
+releases the GIL), other threads parse batch i+1, copy it to the device (c3_batch_stage) and write the records of batch i-1.  No per-read Python objects are created for sequences or qualities: the
 reader fills page-locked SoA buffers that c3_batch_upload copies by DMA and c3_write_group slices for the subread file.
 
 The reference's -g (group size) only decides how reads are partitioned into <splint>/tmp<k>/ directories that are

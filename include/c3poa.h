@@ -113,7 +113,8 @@ int c3_batch_commit(c3_handle* h);
 /* overwrite the splint row / strand of the resident batch (e.g. with the output of c3_scan_splints) before c3_batch_run */
 int c3_batch_assign(c3_handle* h, const int16_t* splint_id, const char* strand);
 
-/* run the resident batch through the hot path (asynchronous on the library's stream).
+/* run the resident batch through the hot path.  The call returns when the batch is done: the stage sizes (work lists,
+ * window count) are read back on the host between the kernels.  Overlap comes from c3_batch_stage on the second stream.
  * stages: bit0 conk, bit1 peaks+split, bit2 POA/draft, bit3 polish.  C3_STAGES_ALL = whole path
  * = one call of analyze_reads (C3POa.py:110-173) minus file I/O. */
 #define C3_STAGE_CONK 1
