@@ -16,6 +16,8 @@ __global__ void k(int iters, int* out) {
     if (MODE == 1) { REP64(asm volatile("v_add_u32 %0, %0, 1\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1" : "+v"(a), "+v"(b), "+v"(c2), "+v"(d));) }
     if (MODE == 2) { REP64(asm volatile("v_add_u32 %0, %0, 1\n s_add_u32 %4, %4, 1\n v_add_u32 %1, %1, 1\n s_add_u32 %5, %5, 1\n v_add_u32 %2, %2, 1\n s_add_u32 %6, %6, 1\n v_add_u32 %3, %3, 1\n s_add_u32 %7, %7, 1" : "+v"(a), "+v"(b), "+v"(c2), "+v"(d), "+s"(s0), "+s"(s1), "+s"(s2), "+s"(s3) : : "scc");) }
     if (MODE == 3) { REP64(asm volatile("v_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n v_max_i32_dpp %1, %1, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_max_i32_dpp %2, %2, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_max_i32_dpp %3, %3, %3 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(a), "+v"(b), "+v"(c2), "+v"(d));) }
+    if (MODE == 5) { REP64(asm volatile("v_pk_add_i16 %0, %0, %1\n v_pk_max_i16 %1, %1, %2\n v_pk_sub_i16 %2, %2, %3 clamp\n v_pk_mad_i16 %3, %3, %0, %1" : "+v"(a), "+v"(b), "+v"(c2), "+v"(d));) }
+    if (MODE == 6) { REP64(asm volatile("ds_bpermute_b32 %0, %1, %0\n v_add_u32 %1, %1, 1\n v_add_u32 %2, %2, 1\n v_add_u32 %3, %3, 1" : "+v"(a), "+v"(b), "+v"(c2), "+v"(d));) asm volatile("s_waitcnt lgkmcnt(0)"); }
     if (MODE == 4) { REP64(asm volatile("v_readlane_b32 %4, %0, 3\n v_add_u32 %1, %1, 1\n v_readlane_b32 %5, %2, 5\n v_add_u32 %3, %3, 1" : "+v"(a), "+v"(b), "+v"(c2), "+v"(d), "+s"(s0), "+s"(s1));) }
   }
   if (a + b + c2 + d + s0 + s1 + s2 + s3 == 0x7fffffff) out[0] = 1;
@@ -23,12 +25,12 @@ __global__ void k(int iters, int* out) {
 int main() {
   int* out; hipMalloc(&out, 64);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const char* names[] = {"SALU only (4 per group)", "VALU only (4 per group)", "VALU+SALU interleaved (4+4)", "VALU DPP only (4)", "readlane+VALU (2+2)"};
-  const int per_iter[] = {256, 256, 512, 256, 256};
+  const char* names[] = {"SALU only (4 per group)", "VALU only (4 per group)", "VALU+SALU interleaved (4+4)", "VALU DPP only (4)", "readlane+VALU (2+2)", "packed 16-bit VOP3P (4)", "bpermute+3 VALU"};
+  const int per_iter[] = {256, 256, 512, 256, 256, 256, 256};
   hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
   const double ghz = p.clockRate * 1e-6;
   printf("CUs %d clock %.2f GHz\n", p.multiProcessorCount, ghz); fflush(stdout);
-  for (int mode = 0; mode < 5; ++mode)
+  for (int mode = 0; mode < 7; ++mode)
     for (int wps : {1, 2, 4, 6, 8}) {
       const int iters = 2000, blocks = p.multiProcessorCount * wps;       // 256-thread blocks: 4 waves = one per SIMD
       auto launch = [&]() {
@@ -36,7 +38,9 @@ int main() {
                         case 1: hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, iters, out); break;
                         case 2: hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, iters, out); break;
                         case 3: hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, iters, out); break;
-                        default: hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, iters, out); } };
+                        case 4: hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, iters, out); break;
+                        case 5: hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, iters, out); break;
+                        default: hipLaunchKernelGGL(k<6>, dim3(blocks), dim3(256), 0, 0, iters, out); } };
       launch(); hipDeviceSynchronize();
       hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);
