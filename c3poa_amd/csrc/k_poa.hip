@@ -13,6 +13,7 @@
 // two DPP max-scans per 64-column chunk; row maxima (adaptive band) are DPP reductions.
 #include "c3_dev.h"
 #include "c3_args.h"
+#include <type_traits>
 
 #define WSYNC() __syncthreads()
 // adjacency slot k of node v.  Slot-major (all first edges, then all second edges, ...): nearly every node has one or two
@@ -105,6 +106,9 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 // carries no vector loads on its common path (descriptors arrive 64 rows at a time and are broadcast
 // with v_readlane).  Rows with a successor more than PR-1 rows ahead, or wider than a ring slot,
 // also go to the global arena; the direction words always do (4 B per cell).
+#ifndef C3_NEAR
+#define C3_NEAR 1
+#endif
 #define PW 128      // ring slot width (cells)
 #define PR 4        // ring rows
 #define PQW 112     // packed query words kept in LDS (1792 bases); longer subreads read the packed read
@@ -290,6 +294,106 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     const int p2 = __builtin_amdgcn_readlane(dB.z, li), p3 = __builtin_amdgcn_readlane(dB.w, li);
 #define PRED_IDX(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[EI(v, (k))]])
     int ncell = wave_first(u_ncell);
+    // ---- NEAR ROW: up to four predecessors, every one of them among the last PR-1 rows (so its cells and band record are in
+    // the LDS ring) and a band of at most 64 columns -- the usual member of an aligned block and the node after it.  Branch
+    // free: the four ring records and the sixteen predecessor cells are read unconditionally (clamped addresses), an absent
+    // predecessor is given an empty band far to the right so that every mask derived from it is false, the band arithmetic
+    // runs on the vector ALU (uniform values), and one ballot decides whether the row qualifies.  Tie order by tags exactly
+    // as in the general row below; direction byte + predecessor byte.
+    if (C3_NEAR && !ovf && qlds && v != SRC && idx - p0 < PR && (nin < 2 || idx - p1 < PR) && (nin < 3 || idx - p2 < PR) && (nin < 4 || idx - p3 < PR)) {
+      // one instance per predecessor count (1, 2, up to 4): a single scalar branch picks it, the body stays branch free
+      auto near_body = [&](auto NPc) -> bool {
+      constexpr int NP = decltype(NPc)::value;
+      UNI(u_ncell);
+      const int BIGB = 1 << 28;
+      int4 m_[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) m_[k] = L.meta[(k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3) & (PR - 1)];
+      int pb_[NP], pe_[NP];
+      int mplv = INT32_MAX / 2, mprv = 0, minb = INT32_MAX, maxe = INT32_MIN, wmax = 0;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const bool has = k < nin;                                             // scalar condition, used as a select mask
+        const int b = has ? m_[k].x : BIGB, e = has ? m_[k].y : -BIGB;
+        pb_[k] = b; pe_[k] = e;
+        minb = min(minb, b); maxe = max(maxe, e + 1); wmax = max(wmax, e - b);
+        const bool ne = e >= b;
+        mplv = ne ? min(mplv, m_[k].z + 1) : mplv; mprv = ne ? max(mprv, m_[k].w + 1) : mprv;
+      }
+      const int beg = max(max(0, min(mplv, qr) - w), minb);
+      int end = min(min(Q, max(mprv, qr) + w), maxe);
+      end = max(end, beg - 1);
+      const int wd = end - beg + 1;
+      if (__builtin_amdgcn_ballot_w64((unsigned)(wd - 1) < 64u && wmax < PW && u_ncell + 64 <= c.cells_cap) != 0) {
+        const int slot = idx & (PR - 1);
+        const int ro = u_ncell;
+        const int j = beg + lane;
+        const bool act = lane < wd;
+        const int jq = max(j - 1, 0);
+        const unsigned qw_ = L.qpk[min(jq >> 4, PQW - 1)];
+        int hd_[NP], hp_[NP], e1_[NP], e2_[NP];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const int sl = (k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3) & (PR - 1);
+          const int o = j - pb_[k];
+          const int oc = min(max(o, 0), PW - 1), om = min(max(o - 1, 0), PW - 1);
+          hd_[k] = L.H[sl][om]; hp_[k] = L.H[sl][oc]; e1_[k] = L.E1[sl][oc]; e2_[k] = L.E2[sl][oc];
+        }
+        int kM = INT32_MIN, kE1 = INT32_MIN, kE2 = INT32_MIN;
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+          const bool vd = j - 1 >= pb_[k] && j - 1 <= pe_[k], vp = j >= pb_[k] && j <= pe_[k];       // (j - 1 >= b >= 0 implies j > 0)
+          const int hd = vd ? hd_[k] : NEGS, hp = vp ? hp_[k] : NEGS, e1p = vp ? e1_[k] : NEGS, e2p = vp ? e2_[k] : NEGS;
+          kM = max(kM, hd + (511 - k));
+          kE1 = max(kE1, max(hp - oe1_9 + (511 - 2 * k), e1p - e1_9 + (510 - 2 * k)));
+          kE2 = max(kE2, max(hp - oe2_9 + (511 - 2 * k), e2p - e2_9 + (510 - 2 * k)));
+        }
+        const int qc = (int)((qw_ >> ((jq & 15) * 2)) & 3);
+        const int M9 = (j > 0) ? (kM & ~511) + ((vb == qc) ? mt9 : mm9) : NEGS;
+        const int E1c = kE1 & ~511, E2c = kE2 & ~511;
+        const int k2 = max(max(M9 + 2, E1c + 1), E2c);
+        const int ht9 = k2 & ~511;
+        const unsigned mp = 511u - ((unsigned)kM & 511u), c1 = 511u - ((unsigned)kE1 & 511u), c2 = 511u - ((unsigned)kE2 & 511u);
+        unsigned d = ((~c1) & 1u) | (((~c2) & 1u) << 1) | (((unsigned)k2 & 3u) << 2);
+        const unsigned pby = mp | ((c1 >> 1) << 2) | ((c2 >> 1) << 4);
+        const int htm = act ? ht9 : NEG2S;
+        int s1 = htm + le1, s2 = htm + le2, s3 = htm;
+        wave_scan_max3(s1, s2, s3);
+        const int px1 = wave_shr1(s1, NEG2S), px2 = wave_shr1(s2, NEG2S);
+        const int htl = wave_shr1(htm, NEGS);
+        const int f1 = px1 - lo1, f2 = px2 - lo2;                              // lane 0: NEG2S - ... (never wins)
+        const int k3 = max(max(ht9 + 2, f1 + 1), f2);
+        const int h9 = k3 & ~511;
+        d |= (((unsigned)k3 & 3u) << 4);
+        d |= (((unsigned)(htl - oe1_9 - f1)) >> 25) & 64u;                      // f1 > its "open" candidate: extended
+        d |= (((unsigned)(htl - oe2_9 - f2)) >> 24) & 128u;
+        pH = act ? h9 : NEGS; pE1 = act ? E1c : NEGS; pE2 = act ? E2c : NEGS; pv_ok = true;
+        // unmasked stores (see the fast row); every near row keeps a predecessor byte (type 1), also with one predecessor
+        c.D8()[(unsigned)(ro + lane)] = (uint8_t)d; c.P8()[(unsigned)(ro + lane)] = (uint8_t)pby;
+        L.H[slot][lane] = h9; L.E1[slot][lane] = E1c; L.E2[slot][lane] = E2c;
+        const int rb = __builtin_amdgcn_readlane(s3, 63);
+        const unsigned long long mxm = __ballot(htm == rb);
+        const int left = beg + __builtin_ctzll(mxm), right = beg + (63 - __builtin_clzll(mxm));
+        if (lane == 0) {
+          L.meta[slot] = make_int4(beg, end, left, right);
+          int off = 3 * idx; UNI(off);
+          int* rm = c.rowm() + off; rm[0] = beg; rm[1] = end | (1 << 28); rm[2] = ro;
+        }
+        if (far) {
+          if (act) { c.H()[ro + lane] = h9; c.E1()[ro + lane] = E1c; c.E2()[ro + lane] = E2c; }
+          if (lane == 0) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
+        }
+        u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ro + wd;
+#ifdef C3_PHASE_PROF
+        { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[10] += t_ - row_t0; row_t0 = t_; }
+#endif
+        return true;
+      }
+      return false;
+      };
+      const bool handled = nin == 1 ? near_body(std::integral_constant<int, 1>{}) : nin == 2 ? near_body(std::integral_constant<int, 2>{}) : near_body(std::integral_constant<int, 4>{});
+      if (handled) continue;
+    }
     // ---- GENERAL ROW.  Adaptive band: gather the hints of the predecessors (abPOA scatters them to the successors).  The
     // ring metadata of the first four predecessors is fetched in ONE LDS round trip (one 16-byte read each, issued
     // together) and pinned to scalars; predecessors that left the ring (or a fifth, sixth ... one) take global loads.
