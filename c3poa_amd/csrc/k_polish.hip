@@ -402,9 +402,8 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
     const int j = lane * CPL + cc;
     hp2[cc] = 0;
     qc[cc] = (j >= 1 && j <= Q) ? c3_code_at(pk, qbeg + j - 1) : 7;
-    hcur[cc] = j * g8;                                                      // virtual row 0
+    hcur[cc] = j * g8;                                                      // virtual row 0 (never stored: a row that needs it again takes gj8)
     gj8[cc] = (j <= Q) ? g8 * j : (1 << 28);                                // columns past Q drop out of the scan
-    if (j <= Q) ((short*)c.H)[cc * 64 + lane] = (short)(j * P.pol_gap);        // H rows are kept as 16-bit scores
   }
   // gfx9 has ONE in-order vmcnt for loads and stores: consuming any load waits for every older
   // store.  So the row loop carries no vector loads on its common path -- descriptors come 64 rows at
