@@ -100,18 +100,19 @@ def main(args):
         t_main += [time.perf_counter()] * 3
     else:
         # splint / strand per read from the PSL (bin/preprocess.py:12-45).  The PSL is reused when it exists (or written by
-        # blat); it is held in a native name -> (splint, strand) table, and the first pass over the reads
-        # (C3POa.py:200-207) only counts: no Python object per read.
+        # blat); it is held in a native name -> (splint, strand) table.  The reference's first pass over the reads
+        # (C3POa.py:200-207) only counts them for the log: those counts fall out of the one streaming pass below.
         assigner = _lib.Assigner(ensure_psl(blat, args, tmp_dir), sorted(splint_dict))
         t_main.append(time.perf_counter())
-        total_reads, short_reads, no_splint = stream.count_reads(args.reads, args.lencutoff, assigner)
         adapter_set, _rows = assigner.seen()
         for adapter in adapter_set:
             os.makedirs(args.out_path + adapter, exist_ok=True)
         t_main.append(time.perf_counter())
-        # streaming pipeline: native reader -> GPU batches -> native writer (c3poa_amd/stream.py); the tail group is
+        # streaming pipeline: native readers -> GPU batches -> native writers (c3poa_amd/stream.py); the tail group is
         # processed too (deliberate fix of SURVEY.md App. A.12)
-        stream.run(args, splint_dict, assigner, adapter_set, n_dev)
+        st = {}
+        stream.run(args, splint_dict, assigner, adapter_set, n_dev, stats=st)
+        total_reads, short_reads, no_splint = st["reads"], st["short"], st["reads"] - st["assigned"]
         assigner.close()
         t_main.append(time.perf_counter())
 
