@@ -36,27 +36,61 @@ __device__ __forceinline__ double dunkey(uint64_t k) {
   return __longlong_as_double((long long)u);
 }
 
-// k-th smallest (0-based) of x[0..n): 8-bit radix select, all threads return the key
+// exclusive prefix sum of one value per thread over the 256-thread workgroup; *total receives the sum.  sh4: 8 ints of LDS
+__device__ __forceinline__ unsigned block_excl_scan(unsigned v, int* sh4, unsigned* total) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const unsigned inc = (unsigned)wave_scan_add((int)v);
+  if (lane == 63) sh4[wv] = (int)inc;
+  __syncthreads();
+  unsigned base = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < PK_T / 64; ++w) { const unsigned t = (unsigned)sh4[w]; if (w < wv) base += t; tot += t; }
+  __syncthreads();
+  *total = tot;
+  return base + inc - v;
+}
+
+// k-th smallest (0-based) of x[0..n): 8-bit radix select, all threads return the key.  The histogram of a pass is built with
+// wave-aggregated LDS atomics for the bins that dominate a wave (in the leading passes every key falls into one or two bins:
+// 64 lanes hammering one LDS word serialise), and the bin holding the k-th key is found with a workgroup prefix sum of the
+// 256 bins instead of a serial walk by one thread.
 __device__ uint64_t block_select(const double* x, int n, int k, unsigned* hist, int* sh_i) {
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
   uint64_t prefix = 0, mask = 0;
   for (int pass = 7; pass >= 0; --pass) {
     const int shift = pass * 8;
     hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += PK_T) {
-      uint64_t key = dkey(x[i]);
-      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1u);
+    for (int i0 = 0; i0 < n; i0 += 4 * PK_T) {
+      // four independent loads per thread first (one memory round trip for four keys), then the histogram updates
+      double xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int i = i0 + u * PK_T + tid; xv[u] = i < n ? x[i] : 0.0; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + u * PK_T + tid;
+        const uint64_t key = dkey(xv[u]);
+        const bool match = i < n && (key & mask) == prefix;
+        const unsigned bin = (unsigned)(key >> shift) & 255u;
+        unsigned long long todo = __ballot(match);
+        for (int it = 0; it < 2 && todo; ++it) {               // peel the bins of the first two lanes still waiting
+          const int l = __builtin_ctzll(todo);
+          const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, l);
+          const unsigned long long m = __ballot(match && bin == b) & todo;
+          if (lane == l) atomicAdd(&hist[b], (unsigned)__popcll(m));
+          todo &= ~m;
+        }
+        if (match && ((todo >> lane) & 1ull)) atomicAdd(&hist[bin], 1u);
+      }
     }
     __syncthreads();
-    if (tid == 0) {
-      unsigned cum = 0; int digit = 255;
-      for (int bkt = 0; bkt < 256; ++bkt) {
-        unsigned c = hist[bkt];
-        if (cum + c > (unsigned)k) { digit = bkt; break; }
-        cum += c;
-      }
-      sh_i[0] = digit; sh_i[1] = (int)cum;
+    {
+      const unsigned c = hist[tid];
+      unsigned tot;
+      const unsigned cum = block_excl_scan(c, sh_i + 2, &tot);
+      // the bin of the k-th key: cum <= k < cum + c; if k is beyond the total (cannot happen) the last bin as before
+      if (cum <= (unsigned)k && (unsigned)k < cum + c) { sh_i[0] = tid; sh_i[1] = (int)cum; }
+      if (tid == PK_T - 1 && (unsigned)k >= tot) { sh_i[0] = 255; sh_i[1] = (int)tot; }
     }
     __syncthreads();
     prefix |= (uint64_t)sh_i[0] << shift;
@@ -221,9 +255,10 @@ __global__ __launch_bounds__(PK_T) void k_peaks(PeaksArgs a) {
           }
         }
         if (pass == 0) {
-          sh_idx[tid] = cnt;
-          __syncthreads();
-          if (tid == 0) { int c = 0; for (int t = 0; t < PK_T; ++t) { sh_cnt[t] = c; c += sh_idx[t]; } sh_cnt[PK_T] = c; }
+          unsigned tot;
+          const unsigned ex = block_excl_scan((unsigned)cnt, sh_i + 2, &tot);
+          sh_cnt[tid] = (int)ex;
+          if (tid == 0) sh_cnt[PK_T] = (int)tot;
           __syncthreads();
         }
       }
