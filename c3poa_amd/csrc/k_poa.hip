@@ -124,23 +124,54 @@ __shared__ PoaLds L;     // file scope: accesses stay in the LDS address space (
 // direction word (device-internal): mp[0..7] | e1code[8..16] | e2code[17..25] | hts[26..27] | hs[28..29]
 // | f1x[30] | f2x[31];  e?code = 2*pred + ext;  hts: 0 M, 1 E1, 2 E2;  hs: 0 Ht, 1 F1, 2 F2
 
-__device__ void poa_build_desc(Ctx& c, int lane, int Q, bool qlds) {
-  const int K = c.K, n = c.n;
-  for (int idx = lane; idx < n; idx += 64) {
-    const int v = c.order()[idx];
-    const int nin = c.n_in()[v];
-    unsigned p[4] = {0, 0, 0, 0};
-    for (int k = 0; k < nin && k < 4; ++k) p[k] = (unsigned)c.index()[c.in_from()[EI(v, k)]];
+// Row descriptors of one alignment AND the "remaining length" of every node in ONE reverse sweep over the topological order,
+// 64 positions at a time (lane = position).  rem[v] = hops from v to the sink along its heaviest out-edge (first maximum in
+// out-list order) - 1; the chain of a node continues at a LATER position, so when the chunks are taken from the last to
+// the first, a target outside the chunk is already final (one gather from hops[]), and the chains inside a chunk are
+// resolved by pointer doubling between lanes (ds_bpermute, at most six rounds).  Replaces log2(n) rounds of pointer jumping
+// over four node arrays in memory by four dependent memory levels per chunk.
+// descriptor A: x = node, y = unused, z = base | nin<<8 | far<<16 | (nin>4)<<17 | fast-row candidate<<18 | sink<<19, w = qr = Q - rem;
+// descriptor B: positions of the first four predecessors.  hops[] (by position) lives in col() (free until the MSA columns).
+__device__ void poa_sweep_desc(Ctx& c, int lane, int Q, bool qlds) {
+  const int n = c.n;
+  int* hops = c.col();
+  for (int c0 = ((n - 1) >> 6) << 6; c0 >= 0; c0 -= 64) {
+    const int idx = c0 + lane;
+    const bool live = idx < n;
+    const int v = live ? c.order()[idx] : SNK;
+    const int nin = live ? c.n_in()[v] : 0, nout = live ? c.n_out()[v] : 0;
+    int bw = INT32_MIN, bt = SNK;
     unsigned far = 0;
-    for (int k = 0; k < c.n_out()[v]; ++k) { const int t = c.out_to()[EI(v, k)]; if (t == SNK || c.index()[t] - idx > PR - 1) far = 1; }
-    uint4 A; A.x = (unsigned)v; A.y = (unsigned)c.rem()[v]; A.z = (unsigned)c.base()[v] | ((unsigned)min(nin, 255) << 8) | (far << 16) | ((unsigned)(nin > 4) << 17);
-    // bit 18: candidate for the fast row (one predecessor, the row above; query in LDS); bit 19: the sink (no DP row)
-    A.z |= ((unsigned)(qlds && nin == 1 && (int)p[0] == idx - 1 && v != SRC && v != SNK) << 18) | ((unsigned)(v == SNK) << 19);
-    A.w = (unsigned)(Q - c.rem()[v]);                    // qr: the query column this node would sit on by distance to the sink
-    uint4 B; B.x = p[0]; B.y = p[1]; B.z = p[2]; B.w = p[3];
-    c.descA()[idx] = A; c.descB()[idx] = B;
+    for (int k = 0; __builtin_amdgcn_ballot_w64(k < nout) != 0; ++k) {
+      if (k < nout) {
+        const int t = c.out_to()[EI(v, k)], ww = c.out_w()[EI(v, k)];
+        if (ww > bw) { bw = ww; bt = t; }
+        if (t == SNK || c.index()[t] - idx > PR - 1) far = 1;
+      }
+    }
+    unsigned p[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (k < nin) p[k] = (unsigned)c.index()[c.in_from()[EI(v, k)]];
+    // hops to the sink: d = hops to ptr, ptr = position still to follow (-1: d is final)
+    int d = (v == SNK) ? 0 : 1, ptr = (v == SNK || !live) ? -1 : c.index()[bt];
+    if (ptr >= c0 + 64) { d += hops[ptr]; ptr = -1; }                    // beyond this chunk: final already
+    for (int r = 0; r < 6 && __builtin_amdgcn_ballot_w64(ptr >= 0) != 0; ++r) {
+      const int src = (max(ptr, c0) - c0) << 2;
+      const int dd = __builtin_amdgcn_ds_bpermute(src, d), pp = __builtin_amdgcn_ds_bpermute(src, ptr);
+      if (ptr >= 0) { d += dd; ptr = pp; }
+    }
+    if (live) {
+      hops[idx] = d;
+      uint4 A; A.x = (unsigned)v; A.y = 0;
+      A.z = (unsigned)c.base()[v] | ((unsigned)min(nin, 255) << 8) | (far << 16) | ((unsigned)(nin > 4) << 17);
+      // bit 18: candidate for the fast row (one predecessor, the row above; query in LDS); bit 19: the sink (no DP row)
+      A.z |= ((unsigned)(qlds && nin == 1 && (int)p[0] == idx - 1 && v != SRC && v != SNK) << 18) | ((unsigned)(v == SNK) << 19);
+      A.w = (unsigned)(Q - (d - 1));                         // qr: the query column this node would sit on by distance to the sink
+      uint4 B; B.x = p[0]; B.y = p[1]; B.z = p[2]; B.w = p[3];
+      c.descA()[idx] = A; c.descB()[idx] = B;
+    }
+    WSYNC();                                                 // hops[] of this chunk is read by the next (earlier) chunk
   }
-  WSYNC();
 }
 
 // banded global alignment of subread [qb, qb+Q) against the graph; ops are written BACKWARDS
@@ -152,34 +183,8 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   const int w = wave_first(P.band_b + (int)(P.band_f * (double)Q));
   const int le1 = e1_9 * lane, le2 = e2_9 * lane;                   // the F scans run in lane coordinates: e*(j-beg) = e*lane
   const int lo1 = le1 + o1_9, lo2 = le2 + o2_9;
-  // remaining length along the heaviest out-edge (first maximum in out-list order): list ranking by
-  // pointer jumping, log2(n) parallel rounds instead of a serial reverse sweep
-  {
-    int *dA = c.rem(), *nA = c.nxt(), *dB = c.col(), *nB = c.col2t();
-    for (int v = lane; v < n; v += 64) {
-      int bw = INT32_MIN, bt = SNK;
-      for (int k = 0; k < c.n_out()[v]; ++k) { int ww = c.out_w()[EI(v, k)]; if (ww > bw) { bw = ww; bt = c.out_to()[EI(v, k)]; } }
-      if (v == SNK) bt = SNK;
-      nA[v] = bt; dA[v] = (v == SNK) ? 0 : 1;
-    }
-    WSYNC();
-    for (int span = 1; span < n; span <<= 1) {
-      int pending = 0;
-      for (int v = lane; v < n; v += 64) {
-        const int nx = nA[v];
-        dB[v] = dA[v] + dA[nx]; nB[v] = nA[nx];
-        pending |= nA[nx] != SNK;
-      }
-      WSYNC();
-      int* t = dA; dA = dB; dB = t; t = nA; nA = nB; nB = t;
-      if (!__ballot(pending)) break;
-    }
-    for (int v = lane; v < n; v += 64) dB[v] = dA[v] - 1;
-    WSYNC();
-    if (dB != c.rem()) { for (int v = lane; v < n; v += 64) c.rem()[v] = dB[v]; WSYNC(); }
-  }
   const bool qlds = Q <= PQW * 16;
-  poa_build_desc(c, lane, Q, qlds);
+  poa_sweep_desc(c, lane, Q, qlds);
   // the subread, 2-bit packed and re-aligned to its first base, goes to LDS: the row loop must not
   // touch global memory for it (a vector load would wait for every older row store)
   if (qlds) {
@@ -889,98 +894,95 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
           WSYNC();
           C = c.rem()[0];
         } else {
-          // ---- abPOA heaviest bundling: nxt[v] = out-edge of maximum weight, ties (equal weight) go to the LATER edge
-          // whose target has a score >= the current one, score[v] = weight + score[nxt[v]] (reverse topological sweep in
-          // the oracle).  Only nodes with a tie for the maximum ever look at a score, so: (a) every node picks its
-          // maximum-weight edge in parallel and flags ties; (b) pointer jumping, with tie nodes and SNK as terminators,
-          // gives every node the weight sum of its chain up to the next terminator; (c) the few tie nodes are resolved
-          // serially in reverse topological order from those sums.  The path itself is then read off binary-lifting jump
-          // tables instead of a 1500-step pointer chase.
+          // ---- abPOA heaviest bundling: nxt[v] = out-edge of maximum weight; among edges of equal (maximum) weight the one
+          // whose target has the higher downstream score, the LATER edge on equality; score[v] = weight + score[nxt[v]].
+          // ONE reverse sweep over the topological order, 64 positions at a time (lane = position): every successor sits at
+          // a later position, so a target outside the chunk is final (one gather), chains inside the chunk are resolved by
+          // pointer doubling between lanes (ds_bpermute; score and hop count ride along), and the few nodes with a tie for
+          // the maximum -- the only ones that look at scores -- are resolved one by one from the highest lane down, each
+          // after the lanes above it are final.  The consensus path is then marked by one FORWARD sweep (in-chunk doubling of
+          // "is on the path"), and a node's draft position is C - hops(node): no pointer chase, no jump tables.
           {
-            const int K = c.K, n = c.n;
-            int* nxA = c.jump(); int* nxB = c.jump() + (size_t)c.Ncap; int* ssA = c.jump() + 2 * (size_t)c.Ncap; int* ssB = c.jump() + 3 * (size_t)c.Ncap;
-            int* score = c.jump() + 4 * (size_t)c.Ncap; int* tief = c.jump() + 5 * (size_t)c.Ncap;     // all rebuilt below
-            for (int v = lane; v < n; v += 64) {
-              const int no = c.n_out()[v];
+            const int n = c.n;
+            int* scp = c.jump(); int* hpp = c.jump() + (size_t)c.Ncap; int* nxp = c.jump() + 2 * (size_t)c.Ncap;     // by position: score, hops to the sink, position of nxt
+            int* onf = c.jump() + 3 * (size_t)c.Ncap;                                                               // by position: on the consensus path
+            for (int c0 = ((n - 1) >> 6) << 6; c0 >= 0; c0 -= 64) {
+              const int idx = c0 + lane;
+              const bool live = idx < n;
+              const int v = live ? c.order()[idx] : SNK;
+              const int no = (live && v != SNK) ? c.n_out()[v] : 0;
               int bw = INT32_MIN, bt = SNK, cm = 0;
-              for (int k = 0; k < no; ++k) {
-                const int ww = c.out_w()[EI(v, k)];
-                if (ww > bw) { bw = ww; bt = c.out_to()[EI(v, k)]; cm = 1; } else if (ww == bw) ++cm;
-              }
-              const bool term = (v == SNK) || cm >= 2 || no == 0;
-              c.nxt()[v] = bt; tief[v] = (v != SNK && cm >= 2) ? 1 : 0;
-              nxA[v] = term ? v : bt; ssA[v] = term ? 0 : bw;
-              score[v] = (v == SNK) ? 0 : (no == 0 ? INT32_MIN : 0);
-            }
-            WSYNC();
-            for (int span = 1; span < n; span <<= 1) {
-              int pending = 0;
-              for (int v = lane; v < n; v += 64) {
-                const int u = nxA[v], uu = nxA[u];
-                ssB[v] = ssA[v] + ssA[u]; nxB[v] = uu;
-                pending |= nxA[uu] != uu;
-              }
-              WSYNC();
-              int* t1 = nxA; nxA = nxB; nxB = t1; t1 = ssA; ssA = ssB; ssB = t1;
-              if (!__ballot(pending)) break;
-            }
-            // (c) tie nodes, last in topological order first
-            for (int i1 = n; i1 > 0; i1 -= 64) {
-              const int i = i1 - 1 - lane;
-              const int vl = i >= 0 ? c.order()[i] : 0;
-              unsigned long long todo = __ballot(i >= 0 && tief[vl]);
-              while (todo) {
-                const int t = __builtin_ctzll(todo); todo &= todo - 1;
-                const int vv = wave_bcast(vl, t);
-                const int no = c.n_out()[vv];
-                // lane k evaluates out-edge k: weight, target, score of the target
-                int ww = INT32_MIN, tt = SNK, st = 0;
-                if (lane < min(no, 64)) {
-                  ww = c.out_w()[EI(vv, lane)]; tt = c.out_to()[EI(vv, lane)];
-                  const int tm = nxA[tt];
-                  st = (tm == tt) ? score[tt] : ssA[tt] + score[tm];
+              for (int k = 0; __builtin_amdgcn_ballot_w64(k < no) != 0; ++k) {
+                if (k < no) {
+                  const int ww = c.out_w()[EI(v, k)];
+                  if (ww > bw) { bw = ww; bt = c.out_to()[EI(v, k)]; cm = 1; } else if (ww == bw) ++cm;
                 }
-                int bw = INT32_MIN, bt = SNK, sbt = 0;
-                for (int k = 0; k < no; ++k) {
-                  int wk, tk, sk;
-                  if (k < 64) { wk = wave_bcast(ww, k); tk = wave_bcast(tt, k); sk = wave_bcast(st, k); }
-                  else {                                     // more than 64 out-edges: uniform loads
-                    wk = c.out_w()[EI(vv, k)]; tk = c.out_to()[EI(vv, k)];
-                    const int tm = nxA[tk];
-                    sk = (tm == tk) ? score[tk] : ssA[tk] + score[tm];
+              }
+              bool tie = cm >= 2;
+              // acc / hp: score and hops from this node to ptr; ptr = position still to follow, -1 = final
+              int acc = no > 0 ? bw : (v == SNK ? 0 : INT32_MIN / 2), hp = no > 0 ? 1 : 0;
+              int ptr = (no > 0 && !tie) ? c.index()[bt] : -1;
+              int np = ptr;                                                     // position of nxt (tie lanes: set when resolved)
+              bool done = no == 0;                                              // the sink (and padding lanes)
+              if (ptr >= c0 + 64) { acc += scp[ptr]; hp += hpp[ptr]; ptr = -1; done = true; }
+              for (;;) {
+                // pointer doubling among the lanes that know their successor; a pointer to an unresolved tie lane waits
+                for (int r = 0; r < 6 && __builtin_amdgcn_ballot_w64(!done && !tie) != 0; ++r) {
+                  const int src = (max(ptr, c0) - c0) << 2;
+                  const int a2 = __builtin_amdgcn_ds_bpermute(src, acc), h2 = __builtin_amdgcn_ds_bpermute(src, hp);
+                  const int p2 = __builtin_amdgcn_ds_bpermute(src, ptr);
+                  const int d2 = __builtin_amdgcn_ds_bpermute(src, (int)done), t2 = __builtin_amdgcn_ds_bpermute(src, (int)tie);
+                  if (!done && !tie && ptr >= 0) {
+                    if (d2) { acc += a2; hp += h2; ptr = -1; done = true; }
+                    else if (!t2) { acc += a2; hp += h2; ptr = p2; }
                   }
-                  if (wk > bw) { bw = wk; bt = tk; sbt = sk; }
-                  else if (wk == bw && sbt <= sk) { bt = tk; sbt = sk; }
                 }
-                if (lane == 0) { score[vv] = bw + sbt; c.nxt()[vv] = bt; }
+                const unsigned long long tm = __builtin_amdgcn_ballot_w64(tie && !done);
+                if (!tm) break;
+                const int T = 63 - __builtin_clzll(tm);                         // highest unresolved tie lane: everything above it is final
+                const int vT = __builtin_amdgcn_readlane(v, T), noT = __builtin_amdgcn_readlane(no, T);
+                int tbw = INT32_MIN, tbt = SNK, tsb = 0, thp = 0, tnp = -1;
+                for (int k = 0; k < noT; ++k) {
+                  const int wk = c.out_w()[EI(vT, k)], tk = c.out_to()[EI(vT, k)];
+                  const int pk_ = c.index()[tk];
+                  int sk, hk;
+                  if (pk_ >= c0 + 64) { sk = scp[pk_]; hk = hpp[pk_]; }
+                  else { sk = wave_bcast(acc, pk_ - c0); hk = wave_bcast(hp, pk_ - c0); }
+                  if (wk > tbw) { tbw = wk; tbt = tk; tsb = sk; thp = hk; tnp = pk_; }
+                  else if (wk == tbw && tsb <= sk) { tbt = tk; tsb = sk; thp = hk; tnp = pk_; }
+                }
+                if (lane == T) { acc = tbw + tsb; hp = 1 + thp; np = tnp; done = true; tie = false; ptr = -1; }
+              }
+              if (live) { scp[idx] = acc; hpp[idx] = hp; nxp[idx] = np; onf[idx] = 0; }
+              WSYNC();
+            }
+            C = hpp[0] - 1;                                                     // SRC sits at position 0: hops to the sink - 1 = consensus length
+            if (lane == 0) onf[0] = 1;
+            WSYNC();
+            for (int c0 = 0; c0 < n && C > 0; c0 += 64) {
+              const int idx = c0 + lane;
+              const bool live = idx < n;
+              int on = live ? onf[idx] : 0;
+              const int np = live ? nxp[idx] : -1;
+              int J = (np >= c0 && np < c0 + 64) ? np - c0 : -1;                  // successor lane inside the chunk
+              for (int r = 0; r < 6; ++r) {
+                L.qpk[lane] = 0;
+                WSYNC();
+                if (on && J >= 0) L.qpk[J] = 1;
+                WSYNC();
+                on |= (int)L.qpk[lane];
+                const int J2 = __builtin_amdgcn_ds_bpermute(max(J, 0) << 2, J);
+                J = J >= 0 ? J2 : -1;
                 WSYNC();
               }
-            }
-            WSYNC();
-            // jump tables J_r = nxt^(2^r) and hop counts; level r lives in c.jump() + r*Ncap (level 0 = nxt)
-            int* d0 = c.mpl(); int* d1 = c.mpr();
-            for (int v = lane; v < n; v += 64) { c.jump()[v] = c.nxt()[v]; d0[v] = (v == SNK) ? 0 : 1; }
-            WSYNC();
-            int levels = 1;
-            for (int r = 0; (1 << r) < n && r + 1 < C3_JUMP_LEVELS; ++r) {
-              const int* Jr = c.jump() + (size_t)r * c.Ncap; int* Jn = c.jump() + (size_t)(r + 1) * c.Ncap;
-              for (int v = lane; v < n; v += 64) { const int u = Jr[v]; Jn[v] = Jr[u]; d1[v] = d0[v] + d0[u]; }
-              WSYNC();
-              int* tsw = d0; d0 = d1; d1 = tsw;
-              levels = r + 2;
-            }
-            const int hops = d0[SRC];                      // edges from SRC to SNK
-            C = hops - 1;
-            if (n > (1 << (C3_JUMP_LEVELS - 1))) C = -1;                           // graph larger than the tables reach
-            for (int p0 = 0; p0 < C; p0 += 64) {
-              const int pp = p0 + lane;
-              if (pp < C) {
-                int node = SRC; const int steps = pp + 1;
-                for (int r = 0; r < levels; ++r) if ((steps >> r) & 1) node = c.jump()[(size_t)r * c.Ncap + node];
-                draft[pp] = c.base()[node]; c.col2t()[c.col()[node]] = pp;
+              if (on && np >= c0 + 64) onf[np] = 1;
+              if (on && live) {
+                const int v = c.order()[idx];
+                if (v != SRC && v != SNK) { const int pp = C - hpp[idx]; draft[pp] = c.base()[v]; c.col2t()[c.col()[v]] = pp; }
               }
+              WSYNC();
             }
-            if (C < 0) { fail = 2; C = 0; }
+            if (C < 0) C = 0;
             WSYNC();
           }
 
