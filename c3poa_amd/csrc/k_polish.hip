@@ -620,34 +620,67 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
 __device__ __forceinline__ int win_consensus(WCtx& c, int* s_score, unsigned short* s_pred, int tgs, int nl, uint8_t* out, int wout_cap, int lane) {
   int olen = 0;
   const int K = c.K, n = c.n;
-  for (int v = lane; v < n; v += 64) { s_score[v] = -1; s_pred[v] = 0xffff; }
-  WSYNC();
-  int max_id = 0;
-  for (int i0 = 0; i0 < n; i0 += 64) {
-    const int i = i0 + lane;
-    int v = 0, nin = 0, u0 = 0, w0 = 0, u1 = 0, w1 = 0;
-    if (i < n) {
-      v = c.order()[i]; nin = c.n_in()[v];
-      if (nin > 0) { u0 = c.in_from()[EI(v, 0)]; w0 = c.in_w()[EI(v, 0)]; }
-      if (nin > 1) { u1 = c.in_from()[EI(v, 1)]; w1 = c.in_w()[EI(v, 1)]; }
-    }
-    const int cnt = min(64, n - i0);
-    for (int t = 0; t < cnt; ++t) {
-      const int vv = wave_bcast(v, t), nn = wave_bcast(nin, t);
-      int sc = -1, pr = -1;
-      for (int k = 0; k < nn; ++k) {
-        int u, w;
-        if (k == 0) { u = wave_bcast(u0, t); w = wave_bcast(w0, t); }
-        else if (k == 1) { u = wave_bcast(u1, t); w = wave_bcast(w1, t); }
-        else { u = c.in_from()[EI(vv, k)]; w = c.in_w()[EI(vv, k)]; }
-        if (sc < w || (sc == w && s_score[pr] <= s_score[u])) { sc = w; pr = u; }
+  // spoa's forward sweep: pred[v] = in-edge of maximum weight, among equal weights the predecessor with the higher score, the
+  // LATER edge on equality; score[v] = weight + score[pred[v]] (a node without in-edges scores -1); the consensus ends at the
+  // first node of maximal score.  Done 64 positions of the topological order at a time (lane = position): a predecessor
+  // outside the chunk is final (one lookup), chains inside the chunk are resolved by pointer doubling between lanes, and
+  // the few nodes with a tie for the maximum weight -- the only ones that compare scores -- one by one from the lowest
+  // lane up, each after the lanes below it are final.  (The serial sweep spent ~5 dependent LDS round trips per node.)
+  int max_id = 0, max_sc = -1;
+  bool have_max = false;
+  for (int c0 = 0; c0 < n; c0 += 64) {
+    const int idx = c0 + lane;
+    const bool live = idx < n;
+    const int v = live ? c.order()[idx] : 0;
+    const int nin = live ? c.n_in()[v] : 0;
+    int bw = -1, bu = -1, cm = 0;
+    for (int k = 0; __builtin_amdgcn_ballot_w64(k < nin) != 0; ++k) {
+      if (k < nin) {
+        const int w = c.in_w()[EI(v, k)];
+        if (w > bw) { bw = w; bu = c.in_from()[EI(v, k)]; cm = 1; } else if (w == bw) ++cm;
       }
-      if (pr != -1) sc += s_score[pr];
-      if (lane == 0) { s_score[vv] = sc; s_pred[vv] = (unsigned short)pr; }
-      __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): the LDS write has landed
-      if (s_score[max_id] < sc) max_id = vv;
     }
+    bool tie = cm >= 2;
+    int acc = nin > 0 ? bw : -1, pr = (nin > 0 && !tie) ? bu : -1;
+    int ptr = (nin > 0 && !tie) ? c.index()[bu] : -1;              // position of the predecessor still to follow, -1 = final
+    bool done = nin == 0;
+    if (!done && !tie && ptr < c0) { acc += s_score[bu]; ptr = -1; done = true; }
+    for (;;) {
+      for (int r = 0; r < 6 && __builtin_amdgcn_ballot_w64(!done && !tie) != 0; ++r) {
+        const int src = (max(ptr, c0) - c0) << 2;
+        const int a2 = __builtin_amdgcn_ds_bpermute(src, acc), p2 = __builtin_amdgcn_ds_bpermute(src, ptr);
+        const int d2 = __builtin_amdgcn_ds_bpermute(src, (int)done), t2 = __builtin_amdgcn_ds_bpermute(src, (int)tie);
+        if (!done && !tie && ptr >= 0) {
+          if (d2) { acc += a2; ptr = -1; done = true; }
+          else if (!t2) { acc += a2; ptr = p2; }
+        }
+      }
+      const unsigned long long tm = __builtin_amdgcn_ballot_w64(tie && !done);
+      if (!tm) break;
+      const int T = __builtin_ctzll(tm);                              // lowest unresolved tie lane: everything below it is final
+      const int vT = __builtin_amdgcn_readlane(v, T), nT = __builtin_amdgcn_readlane(nin, T);
+      int sc = -1, tp = -1, tps = 0;                                   // running best weight, its predecessor and that one's score
+      for (int k = 0; k < nT; ++k) {
+        const int u = c.in_from()[EI(vT, k)], w = c.in_w()[EI(vT, k)];
+        const int pu = c.index()[u];
+        const int su = pu < c0 ? s_score[u] : wave_bcast(acc, pu - c0);
+        if (sc < w || (sc == w && tps <= su)) { sc = w; tp = u; tps = su; }
+      }
+      if (lane == T) { acc = sc + tps; pr = tp; done = true; tie = false; ptr = -1; }
+    }
+    if (live) { s_score[v] = acc; s_pred[v] = pr < 0 ? (unsigned short)0xffff : (unsigned short)pr; }
+    // first node of maximal score (strictly greater than everything before it)
+    const int cm_ = wave_max(live ? acc : INT32_MIN);
+    if (cm_ > max_sc || !have_max) {
+      if (cm_ > max_sc) {
+        const unsigned long long mm = __builtin_amdgcn_ballot_w64(live && acc == cm_);
+        max_id = __builtin_amdgcn_readlane(v, __builtin_ctzll(mm)); max_sc = cm_;
+      }
+      have_max = true;
+    }
+    WSYNC();
   }
+  if (max_sc < 0) max_id = 0;
   WSYNC();
   if (c.n_out()[max_id] > 0) {
     // branch completion (rare): spill to the global arrays and run spoa's re-scoring there
