@@ -300,15 +300,15 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
 #define PRED_IDX(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[EI(v, (k))]])
     int ncell = wave_first(u_ncell);
     // ---- NEAR ROW: up to four predecessors, every one of them among the last PR-1 rows (so its cells and band record are in
-    // the LDS ring) and a band of at most 64 columns -- the usual member of an aligned block and the node after it.  Branch
-    // free: the four ring records and the sixteen predecessor cells are read unconditionally (clamped addresses), an absent
-    // predecessor is given an empty band far to the right so that every mask derived from it is false, the band arithmetic
-    // runs on the vector ALU (uniform values), and one ballot decides whether the row qualifies.  Tie order by tags exactly
-    // as in the general row below; direction byte + predecessor byte.
+    // the LDS ring) -- the usual member of an aligned block and the node after it -- and a band of at most 64 (one chunk) or
+    // 128 columns (two chunks: the rows whose nominal column has drifted away from the predecessors' maxima).  Branch free: the
+    // ring records and the predecessor cells are read unconditionally (clamped addresses), an absent predecessor is given an
+    // empty band far to the right so that every mask derived from it is false, the band arithmetic runs on the vector ALU
+    // (uniform values), and one ballot decides whether the row qualifies.  Tie order by tags exactly as in the general row
+    // below; direction byte + predecessor byte.  One instance per (predecessor count, chunk count).
     if (C3_NEAR && !ovf && qlds && v != SRC && idx - p0 < PR && (nin < 2 || idx - p1 < PR) && (nin < 3 || idx - p2 < PR) && (nin < 4 || idx - p3 < PR)) {
-      // one instance per predecessor count (1, 2, up to 4): a single scalar branch picks it, the body stays branch free
-      auto near_body = [&](auto NPc) -> bool {
-      constexpr int NP = decltype(NPc)::value;
+      auto near_body = [&](auto NPc, auto NCHc) -> bool {
+      constexpr int NP = decltype(NPc)::value, NCH = decltype(NCHc)::value;
       UNI(u_ncell);
       const int BIGB = 1 << 28;
       int4 m_[NP];
@@ -329,11 +329,16 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       int end = min(min(Q, max(mprv, qr) + w), maxe);
       end = max(end, beg - 1);
       const int wd = end - beg + 1;
-      if (__builtin_amdgcn_ballot_w64((unsigned)(wd - 1) < 64u && wmax < PW && u_ncell + 64 <= c.cells_cap) != 0) {
-        const int slot = idx & (PR - 1);
-        const int ro = u_ncell;
-        const int j = beg + lane;
-        const bool act = lane < wd;
+      if (__builtin_amdgcn_ballot_w64((unsigned)(wd - 1) < (unsigned)(64 * NCH) && wmax < PW && u_ncell + 64 * NCH <= c.cells_cap) == 0) return false;
+      const int slot = idx & (PR - 1);
+      const int ro = u_ncell;
+      int carry1 = NEG2S, carry2 = NEG2S, prev_ht = NEGS;                       // scan carries from the first chunk
+      int best = INT32_MIN, left = 0, right = 0;
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const int c0 = 64 * ch;
+        const int j = beg + c0 + lane;
+        const bool act = c0 + lane < wd;
         const int jq = max(j - 1, 0);
         const unsigned qw_ = L.qpk[min(jq >> 4, PQW - 1)];
         int hd_[NP], hp_[NP], e1_[NP], e2_[NP];
@@ -362,41 +367,44 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         unsigned d = ((~c1) & 1u) | (((~c2) & 1u) << 1) | (((unsigned)k2 & 3u) << 2);
         const unsigned pby = mp | ((c1 >> 1) << 2) | ((c2 >> 1) << 4);
         const int htm = act ? ht9 : NEG2S;
-        int s1 = htm + le1, s2 = htm + le2, s3 = htm;
+        const int cl1 = le1 + e1_9 * c0, cl2 = le2 + e2_9 * c0;               // e * (column - beg)
+        int s1 = htm + cl1, s2 = htm + cl2, s3 = htm;
         wave_scan_max3(s1, s2, s3);
-        const int px1 = wave_shr1(s1, NEG2S), px2 = wave_shr1(s2, NEG2S);
-        const int htl = wave_shr1(htm, NEGS);
-        const int f1 = px1 - lo1, f2 = px2 - lo2;                              // lane 0: NEG2S - ... (never wins)
+        const int px1 = max(wave_shr1(s1, NEG2S), carry1), px2 = max(wave_shr1(s2, NEG2S), carry2);
+        const int htl = wave_shr1(htm, prev_ht);
+        const int f1 = px1 - o1_9 - cl1, f2 = px2 - o2_9 - cl2;               // column beg: NEG2S - ... (never wins)
+        if (NCH > 1) { carry1 = max(carry1, wave_bcast(s1, 63)); carry2 = max(carry2, wave_bcast(s2, 63)); prev_ht = wave_bcast(htm, 63); }
         const int k3 = max(max(ht9 + 2, f1 + 1), f2);
         const int h9 = k3 & ~511;
         d |= (((unsigned)k3 & 3u) << 4);
         d |= (((unsigned)(htl - oe1_9 - f1)) >> 25) & 64u;                      // f1 > its "open" candidate: extended
         d |= (((unsigned)(htl - oe2_9 - f2)) >> 24) & 128u;
-        pH = act ? h9 : NEGS; pE1 = act ? E1c : NEGS; pE2 = act ? E2c : NEGS; pv_ok = true;
+        if (ch == 0) { pH = act ? h9 : NEGS; pE1 = act ? E1c : NEGS; pE2 = act ? E2c : NEGS; }
         // unmasked stores (see the fast row); every near row keeps a predecessor byte (type 1), also with one predecessor
-        c.D8()[(unsigned)(ro + lane)] = (uint8_t)d; c.P8()[(unsigned)(ro + lane)] = (uint8_t)pby;
-        L.H[slot][lane] = h9; L.E1[slot][lane] = E1c; L.E2[slot][lane] = E2c;
-        const int rb = __builtin_amdgcn_readlane(s3, 63);
-        const unsigned long long mxm = __ballot(htm == rb);
-        const int left = beg + __builtin_ctzll(mxm), right = beg + (63 - __builtin_clzll(mxm));
-        if (lane == 0) {
-          L.meta[slot] = make_int4(beg, end, left, right);
-          int off = 3 * idx; UNI(off);
-          int* rm = c.rowm() + off; rm[0] = beg; rm[1] = end | (1 << 28); rm[2] = ro;
-        }
-        if (far) {
-          if (act) { c.H()[ro + lane] = h9; c.E1()[ro + lane] = E1c; c.E2()[ro + lane] = E2c; }
-          if (lane == 0) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
-        }
-        u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ro + wd;
-#ifdef C3_PHASE_PROF
-        { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[10] += t_ - row_t0; row_t0 = t_; }
-#endif
-        return true;
+        c.D8()[(unsigned)(ro + c0 + lane)] = (uint8_t)d; c.P8()[(unsigned)(ro + c0 + lane)] = (uint8_t)pby;
+        L.H[slot][c0 + lane] = h9; L.E1[slot][c0 + lane] = E1c; L.E2[slot][c0 + lane] = E2c;
+        if (far) { if (act) { c.H()[ro + c0 + lane] = h9; c.E1()[ro + c0 + lane] = E1c; c.E2()[ro + c0 + lane] = E2c; } }
+        const int cmx = __builtin_amdgcn_readlane(s3, 63);                      // maximum of Ht over the chunk (== maximum of H)
+        const unsigned long long mxm = __ballot(htm == cmx);
+        if (NCH == 1 || cmx > best) { best = cmx; left = beg + c0 + __builtin_ctzll(mxm); right = beg + c0 + (63 - __builtin_clzll(mxm)); }
+        else if (cmx == best && mxm) right = beg + c0 + (63 - __builtin_clzll(mxm));
       }
-      return false;
+      pv_ok = NCH == 1;
+      if (lane == 0) {
+        L.meta[slot] = make_int4(beg, end, left, right);
+        int off = 3 * idx; UNI(off);
+        int* rm = c.rowm() + off; rm[0] = beg; rm[1] = end | (1 << 28); rm[2] = ro;
+        if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
+      }
+      u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ro + wd;
+#ifdef C3_PHASE_PROF
+      { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[10] += t_ - row_t0; row_t0 = t_; }
+#endif
+      return true;
       };
-      const bool handled = nin == 1 ? near_body(std::integral_constant<int, 1>{}) : nin == 2 ? near_body(std::integral_constant<int, 2>{}) : near_body(std::integral_constant<int, 4>{});
+      typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 4> I4;
+      bool handled = nin == 1 ? near_body(I1{}, I1{}) : nin == 2 ? near_body(I2{}, I1{}) : near_body(I4{}, I1{});
+      if (!handled) handled = nin == 1 ? near_body(I1{}, I2{}) : nin == 2 ? near_body(I2{}, I2{}) : near_body(I4{}, I2{});
       if (handled) continue;
     }
     // ---- GENERAL ROW.  Adaptive band: gather the hints of the predecessors (abPOA scatters them to the successors).  The
@@ -561,6 +569,8 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     }
     u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ncell;
 #ifdef C3_PHASE_PROF
+    { bool anyfar = false; for (int k = 0; k < nin && k < 4; ++k) anyfar |= (idx - PRED_IDX(k) >= PR);
+      ph_acc_[9] += (anyfar ? (1ull << 32) : 0ull) + (wd > 64 ? 1ull : 0ull) + ((!anyfar && wd <= 64) ? (1ull << 52) : 0ull); }
     { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[11] += t_ - row_t0; row_t0 = t_; }
 #endif
     pH = gH; pE1 = gE1; pE2 = gE2; pv_ok = wd <= 64;

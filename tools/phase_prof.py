@@ -28,3 +28,5 @@ for which, kn in ((0, "k_poa"), (1, "k_window")):
     h.lib.c3_debug_phases(h.h, which, out)
     tot = float(sum(out)) or 1.0
     print(kn, " ".join("%s=%.1f%%" % (names[which][i], 100 * out[i] / tot) for i in range(10) if out[i]), "| raw[8..11] =", out[8], out[9], out[10], out[11])
+    if which == 0:
+        print("   general rows: wide (> 64 cells) %d, with a far predecessor %d, neither %d" % (out[9] & 0xffffffff, (out[9] >> 32) & 0xfffff, out[9] >> 52))
