@@ -64,11 +64,21 @@ __device__ __forceinline__ void g_add_edge(Ctx& c, int u, int v, int w) {
 
 // block extents from order/grp (parallel)
 __device__ void g_blocks(Ctx& c, int lane) {
-  for (int i = lane; i < c.n; i += 64) { c.gfirst()[i] = 1 << 30; c.glast()[i] = -1; }
-  WSYNC();
-  for (int i = lane; i < c.n; i += 64) {
-    int r = c.grp()[c.order()[i]];
-    atomicMin(&c.gfirst()[r], i); atomicMax(&c.glast()[r], i);
+  // The members of an aligned block are CONTIGUOUS in the topological order (a new sibling is merged right behind its
+  // block), so a block's extent is a run of equal group ids: its first / last position are where the id changes --
+  // plain stores, no initialisation pass, no atomics.
+  for (int i0 = 0; i0 < c.n; i0 += 64) {
+    const int i = i0 + lane;
+    const bool live = i < c.n;
+    const int r = live ? c.grp()[c.order()[i]] : -2;
+    int rp = __builtin_amdgcn_update_dpp(-1, r, 0x138, 0xf, 0xf, false);          // lane - 1 (wave_shr:1)
+    int rn = __builtin_amdgcn_update_dpp(-1, r, 0x130, 0xf, 0xf, false);          // lane + 1 (wave_shl:1)
+    if (lane == 0 && i > 0) rp = c.grp()[c.order()[i - 1]];
+    if (lane == 63 && i + 1 < c.n) rn = c.grp()[c.order()[i + 1]];
+    if (live) {
+      if (r != rp) c.gfirst()[r] = i;
+      if (r != rn || i + 1 >= c.n) c.glast()[r] = i;
+    }
   }
   WSYNC();
 }
