@@ -34,6 +34,9 @@
 // plus one DPP max-scan, cells are KEY = score*4 + tag (3 diag, 2 up, 1 left) so one v_max per
 // candidate keeps the oracle's tie order.  Only the direction bytes go to memory (8 per lane per row);
 // the draft sits in LDS and the piece bases arrive 64 rows at a time, so the row loop has no loads.
+#ifndef C3_PREP_WAVES
+#define C3_PREP_WAVES 5
+#endif
 #define EC 5
 #define EXT_DCAP 4096        // draft bases kept in LDS; longer drafts read the global copy
 // DL: the draft fits the LDS copy.  A template parameter, not a run-time flag: `dl ? ldraft[i] : draft[i]` makes the
@@ -249,7 +252,7 @@ __device__ __forceinline__ void prep_one(const PrepArgs& a, int wi, int lane, ui
     WSYNC();
 }
 
-__global__ __launch_bounds__(64) void k_prep(PrepArgs a) {
+__global__ __launch_bounds__(64, C3_PREP_WAVES) void k_prep(PrepArgs a) {
   const int lane = wave_lane();
   const int slot = blockIdx.x;
   __shared__ uint8_t ldraft[EXT_DCAP];
