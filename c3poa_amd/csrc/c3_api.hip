@@ -160,6 +160,9 @@ extern "C" int c3_create(const c3_config* cfg, c3_handle** out) {
   hipError_t e = hipGetDeviceCount(&ndev);
   if (e != hipSuccess || ndev <= 0) { g_create_err = "no HIP device: the c3poa HIP backend has no CPU fallback"; return C3_E_NO_DEVICE; }
   if (cfg->device < 0 || cfg->device >= ndev) { g_create_err = "bad device ordinal"; return C3_E_ARG; }
+  if (cfg->conk_match < -127 || cfg->conk_match > 127 || cfg->conk_mismatch < -127 || cfg->conk_mismatch > 127) {
+    g_create_err = "conk_match / conk_mismatch must fit a signed byte"; return C3_E_ARG;                 // k_conk keeps them in byte tables
+  }
   if (cfg->sg_order != 2 && cfg->sg_order != 3) { g_create_err = "sg_order must be 2 or 3"; return C3_E_ARG; }
   if (cfg->sg_window < 5 || cfg->sg_window > 127 || !(cfg->sg_window & 1)) { g_create_err = "sg_window must be odd, 5..127"; return C3_E_ARG; }
   c3_handle* h = new c3_handle();

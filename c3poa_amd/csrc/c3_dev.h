@@ -47,6 +47,11 @@ __device__ __forceinline__ int wave_shr1(int v, int carry) {
   return __builtin_amdgcn_update_dpp(carry, v, 0x138, 0xf, 0xf, false);
 }
 
+// value of lane-1; lane 0 receives 0 (bound_ctrl: no register has to be preset)
+__device__ __forceinline__ int wave_shr1z(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
+}
+
 // value of lane+1; lane 63 receives `carry` (wave_shl:1)
 __device__ __forceinline__ int wave_shl1(int v, int carry) {
   return __builtin_amdgcn_update_dpp(carry, v, 0x130, 0xf, 0xf, false);

@@ -9,23 +9,24 @@
 // traffic is two DPP wave_shr:1 moves per step: the bottom-row H of the lane above, and the
 // running diagonal sum.  A diagonal's partial sum rides down the lanes as a token (one hop
 // every R+1 steps) and leaves lane 63 complete, where it is stored exactly once: the track is
-// written with plain stores, never read-modified.  Read bases arrive 2-bit packed, 16 per
-// dword, re-aligned once per 16 steps with v_alignbit.
+// written with plain stores, never read-modified (16 diagonals per block of 16 steps, under one predicate).  Read bases
+// arrive 2-bit packed, 16 per dword, re-aligned once per 16 steps with v_alignbit.
 #include "c3_dev.h"
 #include "c3_args.h"
 
 
+// One anti-diagonal step of the R cells a lane owns.  The substitution score is a signed-byte table per splint row
+// (tbl[k] byte r = score against read base r), so one v_bfe_i32 replaces compare + select; rc8 = 8 * read base.
 template <int R, bool CHECK>
-__device__ __forceinline__ void conk_step(int rc, bool kill, int (&hprev)[R], int (&P)[R], int& W,
-                                          int& up_prev, const int (&code)[R],
-                                          int match, int mismatch, int penalty) {
-  int up = wave_shr1(hprev[R - 1], 0);
-  int recv = wave_shr1(W, 0);
+__device__ __forceinline__ void conk_step(int rc8, bool kill, int (&hprev)[R], int (&P)[R], int& W,
+                                          int& up_prev, const int (&tbl)[R], int penalty) {
+  int up = wave_shr1z(hprev[R - 1]);
+  int recv = wave_shr1z(W);
   int u = up, d = up_prev;
   up_prev = up;
 #pragma unroll
   for (int k = 0; k < R; ++k) {
-    int s = (code[k] == rc) ? match : mismatch;
+    int s = __builtin_amdgcn_sbfe(tbl[k], rc8, 8);
     int m = max(u, hprev[k]) - penalty;
     int hh = max(max(d + s, m), 0);
     if (CHECK) hh = kill ? 0 : hh;
@@ -64,13 +65,16 @@ __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
     const int S = a.sp_len[sid];
     const uint8_t* sp = a.sp_codes + ((size_t)sid * 2 + (st == '-')) * C3_SPLINT_MAX;
     const uint32_t* pk = a.b.pk + a.b.woff[rid];
+    const int last_word = L > 0 ? (L - 1) >> 4 : 0;
     int32_t* track = a.track + off;
     const int pad = 64 * R - S;
-    int code[R], hprev[R], P[R];
+    const int mm4 = (a.mismatch & 255) * 0x01010101;
+    int tbl[R], hprev[R], P[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       int i = lane * R + k - pad;
-      code[k] = (i >= 0) ? (int)sp[i] : 5;   // padding rows never match
+      int code = (i >= 0) ? (int)sp[i] : 5;              // padding rows (and splint N) never match
+      tbl[k] = code < 4 ? (mm4 & ~(255 << (8 * code))) | ((a.match & 255) << (8 * code)) : mm4;
       hprev[k] = 0; P[k] = 0;
     }
     int W = 0, up_prev = 0;
@@ -80,27 +84,39 @@ __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
     const int T_end = L + c0;                 // last useful step is L-1+c0
     for (int t0 = 0; t0 < T_end; t0 += 16) {
       const bool fast = (t0 >= 63) && (t0 + 15 < L);
+      // 16 read bases of this lane's columns jb .. jb+15 (word indices clamped: columns outside the read are killed below)
+      const int jb = t0 - lane;
+      const int wi = jb >> 4;
+      const uint32_t w0 = pk[min(max(wi, 0), last_word)], w1 = pk[min(max(wi + 1, 0), last_word)];
+      const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, (jb & 15) * 2);
+      const int d0 = t0 - c0;
+      int o[16];
       if (fast) {
-        const int jb = t0 - lane;
-        const uint32_t w0 = pk[jb >> 4], w1 = pk[(jb >> 4) + 1];
-        const uint32_t x = __builtin_amdgcn_alignbit(w1, w0, (jb & 15) * 2);
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-          int rc = (x >> (2 * s)) & 3;
-          conk_step<R, false>(rc, false, hprev, P, W, up_prev, code, a.match, a.mismatch, a.penalty);
-          int d = t0 + s - c0;
-          if (SCAN) { if (d >= 0 && d < L) { ssum += P[R - 1]; if (P[R - 1] > smax) { smax = P[R - 1]; sarg = d; } } }
-          else if (lane == 63 && d >= 0 && d < L) track[d] = P[R - 1];
+          const int rc8 = s >= 2 ? (int)((x >> (2 * s - 3)) & 24) : (int)((x << (3 - 2 * s)) & 24);
+          conk_step<R, false>(rc8, false, hprev, P, W, up_prev, tbl, a.penalty);
+          o[s] = P[R - 1];
+          if (SCAN) { int d = d0 + s; if (d >= 0 && d < L) { ssum += P[R - 1]; if (P[R - 1] > smax) { smax = P[R - 1]; sarg = d; } } }
         }
       } else {
+#pragma unroll
         for (int s = 0; s < 16; ++s) {
-          int j = t0 + s - lane;
-          bool oob = (j < 0) || (j >= L);
-          int rc = oob ? 4 : c3_code_at(pk, j);
-          conk_step<R, true>(rc, oob, hprev, P, W, up_prev, code, a.match, a.mismatch, a.penalty);
-          int d = t0 + s - c0;
-          if (SCAN) { if (d >= 0 && d < L) { ssum += P[R - 1]; if (P[R - 1] > smax) { smax = P[R - 1]; sarg = d; } } }
-          else if (lane == 63 && d >= 0 && d < L) track[d] = P[R - 1];
+          const int rc8 = s >= 2 ? (int)((x >> (2 * s - 3)) & 24) : (int)((x << (3 - 2 * s)) & 24);
+          const bool oob = (unsigned)(jb + s) >= (unsigned)L;
+          conk_step<R, true>(rc8, oob, hprev, P, W, up_prev, tbl, a.penalty);
+          o[s] = P[R - 1];
+          if (SCAN) { int d = d0 + s; if (d >= 0 && d < L) { ssum += P[R - 1]; if (P[R - 1] > smax) { smax = P[R - 1]; sarg = d; } } }
+        }
+      }
+      // the 16 finished diagonals of this block leave lane 63 together: one predicate per block, no per-step branch
+      if (!SCAN && lane == 63) {
+        if (d0 >= 0 && d0 + 15 < L) {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) track[d0 + s] = o[s];
+        } else {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) if (d0 + s >= 0 && d0 + s < L) track[d0 + s] = o[s];
         }
       }
     }

@@ -368,7 +368,9 @@ __device__ void win_build_desc(WCtx& c, int R, int lane, unsigned long long* m2,
       if (np == 0) np = 1;                      // no masked predecessor: virtual row 0
       two = allow2 && np == 1;
       adj = two && (int)p[0] == r - 1;
-      uint4 d; d.x = (unsigned)c.base()[v] | ((unsigned)min(np, 255) << 8) | (ovf << 16) | (needh << 17) | ((has ^ 1u) << 18) | ((unsigned)two << 19);
+      // bit 20: the row loop's fast row -- one predecessor, the row right above, nothing to keep for later (no far successor, not an end row)
+      const unsigned fast = adj && !needh && has;
+      uint4 d; d.x = (unsigned)c.base()[v] | ((unsigned)min(np, 255) << 8) | (ovf << 16) | (needh << 17) | ((has ^ 1u) << 18) | ((unsigned)two << 19) | (fast << 20);
       d.y = p[0] | (p[1] << 16); d.z = p[2] | (p[3] << 16); d.w = 0;
       c.rdesc[r] = d;
       c.hend()[r] = INT32_MIN;
@@ -394,33 +396,69 @@ __device__ int win_pred_row(const WCtx& c, const uint4& de, int r, int t) {
 // the row loop.  The row just computed stays in registers and feeds the next row directly (the
 // common predecessor); H rows go to memory only when a non-adjacent successor will need them.
 //
-// Cells are carried as KEY = score*256 + tag with tag = 255 - p, p = 0..63 diagonal from predecessor
-// t, 64..127 vertical from predecessor t-64, 128 horizontal.  One v_max per candidate then
-// implements "highest score, first candidate in (diag preds, vert preds, horizontal) order" exactly.
-// The D byte of a cell is its tag.
+// Cells are 16-bit KEYS = score*4 + type (3 diagonal, 2 vertical, 1 horizontal) in the low half of a register; the high
+// half is "don't care".  On gfx950 the 16-bit VOP2 v_max_i16 and 32-bit add / sub / and issue at twice the rate of
+// v_max_i32, v_max3, compares, selects, DPP and every VALU instruction with an SGPR operand (tools/ubench/valu_cost.hip),
+// so the row is written in exactly those: one v_max_i16 per candidate implements "highest score, diagonal before vertical
+// before horizontal"; among several predecessors the FIRST one that reaches the maximum keeps the cell (strict >), which
+// only rows with more than one predecessor have to track.  The D byte of a cell is tag = 255 - p, p = 0..63 diagonal from
+// predecessor p, 64..127 vertical from predecessor p-64, 128..191 horizontal; single-predecessor rows store the 2-bit type.
+// (Columns past Q compute garbage that only ever flows to the right: never read.)
 #ifndef C3_WIN_RING
 #define C3_WIN_RING 1
 #endif
-#define W_TAG_H 127           /* 255 - 128 */
+#define W_NEG16 (-32000)
+#define W_TAG_H 127           /* byte rows of the linear fallback: 255 - 128 */
+#define VREG(x) asm volatile("" : "+v"(x))       /* keep a uniform value in a vector register (no instruction) */
 __device__ __forceinline__ int win_d_type(int tag) { return (255 - tag) >> 6; }       // 0 diag 1 vert 2 horiz
 __device__ __forceinline__ int win_d_pred(int tag) { return (255 - tag) & 63; }
+__device__ __forceinline__ int max16(int a, int b) { int d; asm("v_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
+// Arguments of a real (not inlined) call arrive in vector registers: make the uniform ones scalar again.  Pointers arrive
+// generic: GP() names the global address space again (a flat load could be private memory, so the compiler must treat its
+// result as divergent and the access as FLAT).
+#define GP(T, p) ((__attribute__((address_space(1))) T*)(p))
+__device__ __forceinline__ int uni32(int x) { return __builtin_amdgcn_readfirstlane(x); }
+template <class T> __device__ __forceinline__ T* uni_ptr(T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  return (T*)(((unsigned long long)(unsigned)uni32((int)(v >> 32)) << 32) | (unsigned)uni32((int)v));
+}
+
+// NOT inlined on purpose: k_window carries some thirty vector registers of per-window state across the layer loop, and
+// inlined here the register allocator spilled the row loop's own arrays (eight scratch reloads per row, each waiting for
+// every older store).  As a function the rows get a register file of their own; the call costs a few dozen instructions
+// per LAYER.
 template <int CPL>
-__device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane, unsigned long long* dbg, unsigned* ring) {
+__device__ __attribute__((noinline)) int win_rows(WCtx cv, int mt_, int mm_, int g_, const uint32_t* pk_, int qbeg_, int Q_, int R_, unsigned long long* dbg_, int ring_off_) {
+  WCtx c;
+  c.I = uni_ptr(cv.I); c.E = uni_ptr(cv.E); c.B8 = uni_ptr(cv.B8); c.score = uni_ptr(cv.score); c.H = uni_ptr(cv.H); c.D = uni_ptr(cv.D);
+  c.rdesc = uni_ptr(cv.rdesc); c.K = uni32(cv.K); c.n = uni32(cv.n); c.Ncap = uni32(cv.Ncap);
+  c.hcap = ((long long)uni32((int)(cv.hcap >> 32)) << 32) | (unsigned)uni32((int)cv.hcap);
+  const uint32_t* pk = uni_ptr(pk_);
+  unsigned long long* dbg = uni_ptr(dbg_);
+  const int qbeg = uni32(qbeg_), Q = uni32(Q_), R = uni32(R_);
+  const int lane = wave_lane();
+  extern __shared__ int lds_dyn[];
+  unsigned* ring = (unsigned*)lds_dyn + uni32(ring_off_);
+  struct { int pol_match, pol_mismatch, pol_gap; } P = {uni32(mt_), uni32(mm_), uni32(g_)};
   const int RS = 64 * CPL, K = c.K;
-  const int mt8 = P.pol_match * 256, mm8 = P.pol_mismatch * 256, g8 = P.pol_gap * 256;
   constexpr int DS = (CPL + 3) & ~3, RSD = 64 * DS;                        // D row: natural column order, DS bytes per lane
   if ((long long)(R + 1) * RSD > c.hcap || R >= 65535) return -1;
-  const int NEG8 = -(1 << 30);
-  int qc[CPL], hcur[CPL], hp2[CPL], gj8[CPL];                               // hcur = row r-1, hp2 = row r-2
+  const int mt3 = P.pol_match * 4 + 3, mm3 = P.pol_mismatch * 4 + 3, g4 = P.pol_gap * 4;
+  const int mm3x4 = (mm3 & 255) * 0x01010101;
+  int tbl[CPL], hcur[CPL], hp2[CPL], g41[CPL];                              // hcur = row r-1, hp2 = row r-2 (score * 4)
 #pragma unroll
   for (int cc = 0; cc < CPL; ++cc) {
     const int j = lane * CPL + cc;
+    const int qc = (j >= 1 && j <= Q) ? c3_code_at(pk, qbeg + j - 1) : 7;
+    // byte b of tbl: 4 * substitution score + 3 (the diagonal type) of this column against graph base b
+    tbl[cc] = qc < 4 ? (mm3x4 & ~(255 << (8 * qc))) | ((mt3 & 255) << (8 * qc)) : mm3x4;
     hp2[cc] = 0;
-    qc[cc] = (j >= 1 && j <= Q) ? c3_code_at(pk, qbeg + j - 1) : 7;
-    hcur[cc] = j * g8;                                                      // virtual row 0 (never stored: a row that needs it again takes gj8)
-    gj8[cc] = (j <= Q) ? g8 * j : (1 << 28);                                // columns past Q drop out of the scan
+    hcur[cc] = j * g4;                                                      // virtual row 0 (never stored: a row that needs it again takes g41 - 1)
+    g41[cc] = j * g4 + 1;                                                   // horizontal candidate = 4 * (best y + g * j) + 1
   }
+  int cV = g4 + 2;                                                          // vertical candidate = H4[pred][j] + 4 * g + 2
+  VREG(cV);
   // gfx9 has ONE in-order vmcnt for loads and stores: consuming any load waits for every older
   // store.  So the row loop carries no vector loads on its common path -- descriptors come 64 rows at
   // a time (one per lane) and are broadcast with v_readlane; only rows with a non-adjacent
@@ -430,37 +468,71 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
   // waits for every older direction / H store (one in-order vmcnt)
   int rt0 = -1, rt1 = -1, rt2 = -1, rt3 = -1, rnext = 0;
   constexpr int RW = (CPL + 1) / 2 * 64;                                    // dwords per ring slot
+  unsigned doff = (CPL <= 8 ? 2 : 4) * lane;                                 // byte offset of this lane's 2-bit word in D row r (kept in a vector register: + RSD per row)
   for (int rb = 1; rb <= R; rb += 64) {
-  uint4 dblk = c.rdesc[min(rb + lane, R)];
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const u32x4 dv = GP(const u32x4, c.rdesc)[min(rb + lane, R)];
+  uint4 dblk = make_uint4(dv.x, dv.y, dv.z, dv.w);
   // pin the wait for this load HERE (the asm "uses" the registers), not inside the row loop
   asm volatile("" : "+v"(dblk.x), "+v"(dblk.y), "+v"(dblk.z));
   const int cnt = min(64, R - rb + 1);
   for (int li = 0; li < cnt; ++li) {
     const int r = rb + li;
     uint4 de;
-    de.x = __builtin_amdgcn_readlane(dblk.x, li); de.y = __builtin_amdgcn_readlane(dblk.y, li);
+    de.x = __builtin_amdgcn_readlane(dblk.x, li);
+    doff += RSD;
+    if (de.x & (1u << 20)) {
+      // FAST ROW (most rows): one predecessor = the row above, held in hcur; nothing stored but the 2-bit directions.  One
+      // scalar test, no further descriptor words, no scalar address arithmetic: the scalar unit is shared by the CU's
+      // four SIMDs, and a row of the general path below spends some seventy scalar instructions and a dozen branches
+      int vb8 = (de.x & 3) * 8;
+      VREG(vb8);
+      int key[CPL];
+      const int hleft = wave_shr1(hcur[CPL - 1], W_NEG16);
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) {
+        const int hd = cc == 0 ? hleft : hcur[cc - 1];
+        key[cc] = max16(hd + __builtin_amdgcn_sbfe(tbl[cc], vb8, 8), hcur[cc] + cV);
+      }
+      int run = W_NEG16;
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) run = max16(run, key[cc] - g41[cc]);
+      int ex = wave_shr1(wave_scan_max(__builtin_amdgcn_sbfe(run, 0, 16)), W_NEG16);
+      unsigned w2 = 0;
+#pragma unroll
+      for (int cc = 0; cc < CPL; ++cc) {
+        const int k2 = max16(key[cc], (ex & ~3) + g41[cc]);
+        ex = max16(ex, key[cc] - g41[cc]);
+        hp2[cc] = hcur[cc];
+        hcur[cc] = k2 & ~3;
+        w2 |= ((unsigned)k2 & 3u) << (2 * cc);
+      }
+      if (CPL <= 8) *GP(unsigned short, c.D + doff) = (unsigned short)w2;
+      else *GP(unsigned, c.D + doff) = w2;
+      continue;
+    }
+    de.y = __builtin_amdgcn_readlane(dblk.y, li);
     de.z = __builtin_amdgcn_readlane(dblk.z, li); de.w = 0;
     const int vb = de.x & 0xff, np = (de.x >> 8) & 0xff;
     const bool ovf = (de.x >> 16) & 1, needh = (de.x >> 17) & 1, isend = (de.x >> 18) & 1, two = (de.x >> 19) & 1;
     if (np > 64) return -1;
-    int sel[CPL], key[CPL];
-#pragma unroll
-    for (int cc = 0; cc < CPL; ++cc) { sel[cc] = (vb == qc[cc]) ? mt8 : mm8; key[cc] = INT32_MIN; }
+    int key[CPL];                                                            // bits 16..21: the predecessor that set the cell (rows with several)
+    int vb8 = (vb & 3) * 8;                                                  // (graph bases are 2-bit codes)
+    VREG(vb8);
     int kedge = 0;
     for (int t = 0; t < np; ++t) {
       int prow;
       if (!ovf) prow = (t == 0) ? (de.y & 0xffff) : (t == 1) ? (de.y >> 16) : (t == 2) ? (de.z & 0xffff) : (de.z >> 16);
       else {                                                                 // >4 predecessors: walk the in-edges
-        const int v = c.rows()[r];
+        const int v = GP(const int, c.rows())[r];
         prow = -1;
-        while (kedge < c.n_in()[v]) { int pr = c.rowof()[c.in_from()[EI(v, kedge)]]; ++kedge; if (pr >= 0) { prow = pr; break; } }
+        while (kedge < GP(const int, c.n_in())[v]) { int pr = GP(const int, c.rowof())[GP(const int, c.in_from())[EI(v, kedge)]]; ++kedge; if (pr >= 0) { prow = pr; break; } }
         if (prow < 0) break;
       }
 #ifdef C3_PHASE_PROF
       if (prow != r - 1) dbg[0]++;
       if (t == 0) { dbg[1]++; if (needh) dbg[2]++; }
 #endif
-      const int tagd = 255 - t, tagv = 191 - t;
       int hp[CPL];
       if (prow == r - 1) {
 #pragma unroll
@@ -470,7 +542,7 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
         for (int cc = 0; cc < CPL; ++cc) hp[cc] = hp2[cc];
       } else if (prow == 0) {                                                // the virtual start row: H[0][j] = j * gap
 #pragma unroll
-        for (int cc = 0; cc < CPL; ++cc) hp[cc] = gj8[cc];                   // (columns past Q hold a large value there: never used)
+        for (int cc = 0; cc < CPL; ++cc) hp[cc] = g41[cc] - 1;
       } else {
         const int sl = !C3_WIN_RING ? -1 : prow == rt0 ? 0 : prow == rt1 ? 1 : prow == rt2 ? 2 : prow == rt3 ? 3 : -1;
         if (sl >= 0) {
@@ -478,79 +550,87 @@ __device__ int win_rows(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg
 #pragma unroll
           for (int m = 0; m < (CPL + 1) / 2; ++m) {
             const unsigned x = rp[m * 64 + lane];
-            hp[2 * m] = ((int)(x << 16)) >> 8;
-            if (2 * m + 1 < CPL) hp[2 * m + 1] = ((int)x >> 8) & ~0xff;
+            hp[2 * m] = (int)x;                                              // (the high half is never looked at)
+            if (2 * m + 1 < CPL) hp[2 * m + 1] = (int)(x >> 16);
           }
         } else {
-          const short* hp_ = (const short*)c.H + (size_t)prow * RS;
+          const auto* hp_ = GP(const unsigned short, c.H) + (size_t)prow * RS;
 #pragma unroll
-          for (int cc = 0; cc < CPL; ++cc) hp[cc] = ((int)hp_[cc * 64 + lane]) << 8;
+          for (int cc = 0; cc < CPL; ++cc) hp[cc] = (int)hp_[cc * 64 + lane];
         }
       }
-      const int hleft = wave_shr1(hp[CPL - 1], NEG8);                        // column lane*CPL-1 of the predecessor
+      const int hleft = wave_shr1(hp[CPL - 1], W_NEG16);                     // column lane*CPL-1 of the predecessor
+      if (t == 0) {
 #pragma unroll
-      for (int cc = 0; cc < CPL; ++cc) {
-        const int hd = cc == 0 ? hleft : hp[cc - 1];
-        key[cc] = max(key[cc], max(hd + sel[cc] + tagd, hp[cc] + g8 + tagv));
+        for (int cc = 0; cc < CPL; ++cc) {
+          const int hd = cc == 0 ? hleft : hp[cc - 1];
+          key[cc] = max16(hd + __builtin_amdgcn_sbfe(tbl[cc], vb8, 8), hp[cc] + cV);
+        }
+      } else {
+        const int tmark = t << 16;
+#pragma unroll
+        for (int cc = 0; cc < CPL; ++cc) {
+          const int hd = cc == 0 ? hleft : hp[cc - 1];
+          const int nk = max16(key[cc], max16(hd + __builtin_amdgcn_sbfe(tbl[cc], vb8, 8), hp[cc] + cV));
+          key[cc] = nk != (key[cc] & 0xffff) ? (nk | tmark) : key[cc];      // strictly better only: the first predecessor keeps a tie
+        }
       }
     }
-    // horizontal gap: in-lane prefix + one cross-lane max-scan over y = H - g*j
-    int y[CPL];
-    int run = NEG8;
+    // horizontal gap: in-lane prefix + one cross-lane max-scan over y = H - g*j (carried as key - g41: the low bits stay
+    // below 4, so the order of the y is the order of the keys)
+    int run = W_NEG16;
 #pragma unroll
-    for (int cc = 0; cc < CPL; ++cc) { y[cc] = (key[cc] & ~0xff) - gj8[cc]; run = max(run, y[cc]); }
-    const int s = wave_scan_max(run);
-    int ex = wave_shr1(s, NEG8);                                             // max over all previous lanes
-    short* hrow = (short*)c.H + (size_t)r * RS;
+    for (int cc = 0; cc < CPL; ++cc) run = max16(run, key[cc] - g41[cc]);
+    const int s = wave_scan_max(__builtin_amdgcn_sbfe(run, 0, 16));
+    int ex = wave_shr1(s, W_NEG16);                                          // max over all previous lanes
     if (two) {
-      // single-predecessor row: the tag is 255 (diag), 191 (vert) or 127 (horiz) -> 2 bits per cell, one dword per
-      // lane, 256 contiguous bytes per row instead of 64*DS
+      // single-predecessor row: 2 bits per cell (3 diag, 2 vert, 1 horiz), one word per lane, 128 or 256 contiguous bytes
+      // per row instead of 64*DS
       unsigned w2 = 0;
 #pragma unroll
       for (int cc = 0; cc < CPL; ++cc) {
-        const int k2 = max(key[cc], ex + gj8[cc] + W_TAG_H);                 // for j == 0 ex is NEG8: never wins
-        ex = max(ex, y[cc]);
+        const int k2 = max16(key[cc], (ex & ~3) + g41[cc]);                  // for j == 0 ex is W_NEG16: never wins
+        ex = max16(ex, key[cc] - g41[cc]);
         hp2[cc] = hcur[cc];
-        hcur[cc] = k2 & ~0xff;
-        w2 |= (((unsigned)k2 >> 6) & 3u) << (2 * cc);
+        hcur[cc] = k2 & ~3;
+        w2 |= ((unsigned)k2 & 3u) << (2 * cc);
       }
-      if (CPL <= 8) ((unsigned short*)(c.D + (size_t)r * RSD))[lane] = (unsigned short)w2;         // 16 bits hold 8 cells: 128 bytes per row
-      else ((unsigned*)(c.D + (size_t)r * RSD))[lane] = w2;
+      if (CPL <= 8) GP(unsigned short, c.D + (size_t)r * RSD)[lane] = (unsigned short)w2;         // 16 bits hold 8 cells: 128 bytes per row
+      else GP(unsigned, c.D + (size_t)r * RSD)[lane] = w2;
     } else {
       unsigned dpk[DS / 4];
 #pragma unroll
       for (int w = 0; w < DS / 4; ++w) dpk[w] = 0;
 #pragma unroll
       for (int cc = 0; cc < CPL; ++cc) {
-        const int k2 = max(key[cc], ex + gj8[cc] + W_TAG_H);
-        ex = max(ex, y[cc]);
+        const int k2 = max16(key[cc], (ex & ~3) + g41[cc]);
+        ex = max16(ex, key[cc] - g41[cc]);
         hp2[cc] = hcur[cc];
-        hcur[cc] = k2 & ~0xff;
-        dpk[cc / 4] |= (unsigned)(k2 & 0xff) << (8 * (cc & 3));
+        hcur[cc] = k2 & ~3;
+        const unsigned tag = (((unsigned)k2 & 3u) << 6) + 63u - ((unsigned)key[cc] >> 16);      // horizontal: 127 - p, still type 2
+        dpk[cc / 4] |= tag << (8 * (cc & 3));
       }
-      unsigned* drow = (unsigned*)(c.D + (size_t)r * RSD) + lane * (DS / 4);
+      auto* drow = GP(unsigned, c.D + (size_t)r * RSD) + lane * (DS / 4);
 #pragma unroll
       for (int w = 0; w < DS / 4; ++w) drow[w] = dpk[w];
     }
     if (needh) {
+      auto* hrow = GP(short, c.H) + (size_t)r * RS;
 #pragma unroll
-      for (int cc = 0; cc < CPL; ++cc) hrow[cc * 64 + lane] = (short)(hcur[cc] >> 8);      // (columns past Q: inside the row, never read)
+      for (int cc = 0; cc < CPL; ++cc) hrow[cc * 64 + lane] = (short)hcur[cc];             // (columns past Q: inside the row, never read)
       if (C3_WIN_RING) {
       const int sl = rnext;
       rnext = (rnext + 1) & 3;
       rt0 = sl == 0 ? r : rt0; rt1 = sl == 1 ? r : rt1; rt2 = sl == 2 ? r : rt2; rt3 = sl == 3 ? r : rt3;
       unsigned* wp = ring + sl * RW;
 #pragma unroll
-      for (int m = 0; m < (CPL + 1) / 2; ++m) {
-        const unsigned lo = ((unsigned)(hcur[2 * m] >> 8)) & 0xffffu;
-        const unsigned hi = (2 * m + 1 < CPL) ? ((unsigned)(hcur[2 * m + 1] >> 8)) << 16 : 0u;
-        wp[m * 64 + lane] = lo | hi;
-      }
+      for (int m = 0; m < (CPL + 1) / 2; ++m)
+        wp[m * 64 + lane] = __builtin_amdgcn_perm((unsigned)(2 * m + 1 < CPL ? hcur[2 * m + 1] : 0), (unsigned)hcur[2 * m], 0x05040100u);
       }
     }
     if (isend) {
 #pragma unroll
-      for (int cc = 0; cc < CPL; ++cc) if (lane * CPL + cc == Q) c.hend()[r] = hcur[cc] >> 8;
+      for (int cc = 0; cc < CPL; ++cc) if (lane * CPL + cc == Q) GP(int, c.hend())[r] = __builtin_amdgcn_sbfe(hcur[cc], 2, 14);
     }
   }
   }
@@ -610,20 +690,23 @@ __device__ int win_rows_lin(WCtx& c, const C3Params& P, const uint32_t* pk, int 
 __device__ __forceinline__ int win_idx(int j, int cpl) { return cpl ? (j / cpl) * ((cpl + 3) & ~3) + j % cpl : j; }
 
 __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane, int* cpl_out, int* rs_out, unsigned long long* dbg,
-                                 unsigned long long* m2, unsigned long long* ma, unsigned* ring) {
+                                 unsigned long long* m2, unsigned long long* ma, int ring_off) {
   const int need = (Q + 1 + 63) / 64;
   int cpl;
-  if (5 * (R + Q + 2) >= 32000) cpl = 0;            // 16-bit H rows of the register-blocked rows: |score| <= 5 * (R + Q)
+  // 16-bit keys (score * 4 + type) of the register-blocked rows: |score| <= pm * max(R, Q), |score - g * j| <= (match + |g|) * Q,
+  // and the substitution scores live in signed bytes
+  const int pm = max(max(abs(P.pol_match), abs(P.pol_mismatch)), abs(P.pol_gap));
+  if (4 * pm * (max(R, Q) + 4) >= 31000 || 4 * (abs(P.pol_match) + abs(P.pol_gap)) * (Q + 4) >= 31000 || pm > 30 || P.pol_gap >= 0) cpl = 0;
   else if (need <= 2) cpl = 2; else if (need <= 4) cpl = 4; else if (need <= 6) cpl = 6; else if (need <= 8) cpl = 8;
   else if (need <= 10) cpl = 10; else cpl = 0;
   *cpl_out = cpl; *rs_out = cpl ? 64 * ((cpl + 3) & ~3) : need * 64;    // D row stride in bytes
   win_build_desc(c, R, lane, m2, ma, cpl != 0);
   switch (cpl) {
-    case 2: return win_rows<2>(c, P, pk, qbeg, Q, R, lane, dbg, ring);
-    case 4: return win_rows<4>(c, P, pk, qbeg, Q, R, lane, dbg, ring);
-    case 6: return win_rows<6>(c, P, pk, qbeg, Q, R, lane, dbg, ring);
-    case 8: return win_rows<8>(c, P, pk, qbeg, Q, R, lane, dbg, ring);
-    case 10: return win_rows<10>(c, P, pk, qbeg, Q, R, lane, dbg, ring);
+    case 2: return win_rows<2>(c, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+    case 4: return win_rows<4>(c, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+    case 6: return win_rows<6>(c, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+    case 8: return win_rows<8>(c, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+    case 10: return win_rows<10>(c, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
     default: return win_rows_lin(c, P, pk, qbeg, Q, R, lane);
   }
 }
@@ -855,7 +938,7 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
         PH_MARK(2)
         int cpl = 0, RS = 0;
         unsigned long long dbg_[3] = {0, 0, 0};
-        if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, (unsigned*)(mabits + ((a.Ncap + 64) >> 6) + 1)) < 0) { fail = 1; break; }
+        if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, 4 * (((a.Ncap + 64) >> 6) + 1)) < 0) { fail = 1; break; }   // (LDS ring behind the two bitmasks, in dwords)
 #ifdef C3_PHASE_PROF
         ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1]; ph_acc_[9] += dbg_[2];
 #endif
