@@ -214,6 +214,8 @@ extern "C" int c3_set_splints(c3_handle* h, int n, const char* cat, const int64_
   for (int i = 0; i < n; ++i) {
     int S = (int)(off[i + 1] - off[i]);
     if (S <= 0 || S > C3_SPLINT_MAX) return c3_fail(h, C3_E_LIMIT, "splint length must be 1..512");
+    if ((long long)std::max(h->cfg.conk_match, 0) * S > 32000 || h->cfg.conk_penalty < 0 || h->cfg.conk_penalty > 32000)
+      return c3_fail(h, C3_E_LIMIT, "conk_match * splint length and conk_penalty must stay below 32000 (16-bit score cells in k_conk)");
     h->sp_len[i] = S; h->max_spl = std::max(h->max_spl, S);
     for (int k = 0; k < S; ++k) {
       int c = code_of(cat[off[i] + k]);

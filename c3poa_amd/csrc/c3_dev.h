@@ -52,6 +52,9 @@ __device__ __forceinline__ int wave_shr1z(int v) {
   return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
 }
 
+// 16-bit signed max of the low halves, zero-extended (VOP2 16-bit: twice the issue rate of v_max_i32 on gfx950)
+__device__ __forceinline__ int max16(int a, int b) { int d; asm("v_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+
 // value of lane+1; lane 63 receives `carry` (wave_shl:1)
 __device__ __forceinline__ int wave_shl1(int v, int carry) {
   return __builtin_amdgcn_update_dpp(carry, v, 0x130, 0xf, 0xf, false);

@@ -26,9 +26,11 @@ __device__ __forceinline__ void conk_step(int rc8, bool kill, int (&hprev)[R], i
   up_prev = up;
 #pragma unroll
   for (int k = 0; k < R; ++k) {
+    // H <= match * splint length fits 16 bits: v_max_i16 issues at twice the rate of v_max_i32 / v_max3 (tools/ubench/valu_cost.hip);
+    // its result is zero-extended, so the 32-bit diagonal sums below add clean values
     int s = __builtin_amdgcn_sbfe(tbl[k], rc8, 8);
-    int m = max(u, hprev[k]) - penalty;
-    int hh = max(max(d + s, m), 0);
+    int m = max16(u, hprev[k]) - penalty;
+    int hh = max16(max16(d + s, m), 0);
     if (CHECK) hh = kill ? 0 : hh;
     d = hprev[k];
     hprev[k] = hh;
@@ -78,6 +80,8 @@ __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
       hprev[k] = 0; P[k] = 0;
     }
     int W = 0, up_prev = 0;
+    int pen = a.penalty;
+    asm volatile("" : "+v"(pen));                      // a VALU instruction with an SGPR operand issues at half rate
     int smax = -1, sarg = 0; long long ssum = 0;          // SCAN accumulators (meaningful in lane 63)
     // lane 63 finishes diagonal d = t - c0 at step t
     const int c0 = 63 * (R + 1) + (R - 1) - pad;
@@ -95,7 +99,7 @@ __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
           const int rc8 = s >= 2 ? (int)((x >> (2 * s - 3)) & 24) : (int)((x << (3 - 2 * s)) & 24);
-          conk_step<R, false>(rc8, false, hprev, P, W, up_prev, tbl, a.penalty);
+          conk_step<R, false>(rc8, false, hprev, P, W, up_prev, tbl, pen);
           o[s] = P[R - 1];
           if (SCAN) { int d = d0 + s; if (d >= 0 && d < L) { ssum += P[R - 1]; if (P[R - 1] > smax) { smax = P[R - 1]; sarg = d; } } }
         }
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
         for (int s = 0; s < 16; ++s) {
           const int rc8 = s >= 2 ? (int)((x >> (2 * s - 3)) & 24) : (int)((x << (3 - 2 * s)) & 24);
           const bool oob = (unsigned)(jb + s) >= (unsigned)L;
-          conk_step<R, true>(rc8, oob, hprev, P, W, up_prev, tbl, a.penalty);
+          conk_step<R, true>(rc8, oob, hprev, P, W, up_prev, tbl, pen);
           o[s] = P[R - 1];
           if (SCAN) { int d = d0 + s; if (d >= 0 && d < L) { ssum += P[R - 1]; if (P[R - 1] > smax) { smax = P[R - 1]; sarg = d; } } }
         }

@@ -579,8 +579,6 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     }
     u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ncell;
 #ifdef C3_PHASE_PROF
-    { bool anyfar = false; for (int k = 0; k < nin && k < 4; ++k) anyfar |= (idx - PRED_IDX(k) >= PR);
-      ph_acc_[9] += (anyfar ? (1ull << 32) : 0ull) + (wd > 64 ? 1ull : 0ull) + ((!anyfar && wd <= 64) ? (1ull << 52) : 0ull); }
     { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[11] += t_ - row_t0; row_t0 = t_; }
 #endif
     pH = gH; pE1 = gE1; pE2 = gE2; pv_ok = wd <= 64;

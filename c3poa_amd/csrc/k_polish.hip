@@ -412,7 +412,6 @@ __device__ int win_pred_row(const WCtx& c, const uint4& de, int r, int t) {
 #define VREG(x) asm volatile("" : "+v"(x))       /* keep a uniform value in a vector register (no instruction) */
 __device__ __forceinline__ int win_d_type(int tag) { return (255 - tag) >> 6; }       // 0 diag 1 vert 2 horiz
 __device__ __forceinline__ int win_d_pred(int tag) { return (255 - tag) & 63; }
-__device__ __forceinline__ int max16(int a, int b) { int d; asm("v_max_i16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
 // Arguments of a real (not inlined) call arrive in vector registers: make the uniform ones scalar again.  Pointers arrive
 // generic: GP() names the global address space again (a flat load could be private memory, so the compiler must treat its
@@ -487,6 +486,9 @@ __device__ __attribute__((noinline)) int win_rows(WCtx cv, int mt_, int mm_, int
       // four SIMDs, and a row of the general path below spends some seventy scalar instructions and a dozen branches
       int vb8 = (de.x & 3) * 8;
       VREG(vb8);
+#ifdef C3_PHASE_PROF
+      dbg[1]++;
+#endif
       int key[CPL];
       const int hleft = wave_shr1(hcur[CPL - 1], W_NEG16);
 #pragma unroll
@@ -530,8 +532,9 @@ __device__ __attribute__((noinline)) int win_rows(WCtx cv, int mt_, int mm_, int
         if (prow < 0) break;
       }
 #ifdef C3_PHASE_PROF
-      if (prow != r - 1) dbg[0]++;
-      if (t == 0) { dbg[1]++; if (needh) dbg[2]++; }
+      // row census: [0] low = general rows with the single predecessor r-1 (kept for later), high = all general rows;
+      // [1] low = all rows, high = rows with several predecessors
+      if (t == 0) { dbg[0] += (1ull << 32) + (two && prow == r - 1); dbg[1] += 1 + ((unsigned long long)!two << 32); }
 #endif
       int hp[CPL];
       if (prow == r - 1) {
@@ -940,7 +943,7 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
         unsigned long long dbg_[3] = {0, 0, 0};
         if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, 4 * (((a.Ncap + 64) >> 6) + 1)) < 0) { fail = 1; break; }   // (LDS ring behind the two bitmasks, in dwords)
 #ifdef C3_PHASE_PROF
-        ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1]; ph_acc_[9] += dbg_[2];
+        ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1];
 #endif
         PH_MARK(3)
         cells += (long long)(R + 1) * (Q + 1);
