@@ -51,7 +51,8 @@ assert RESULT_DTYPE.itemsize == C.sizeof(ReadResult)
 class Timing(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("ms_pack", "ms_conk", "ms_peaks", "ms_poa", "ms_prep", "ms_window",
                                          "ms_stitch", "ms_total")] + \
-               [(n, C.c_int64) for n in ("n_reads", "n_bases", "n_windows", "cells_conk", "cells_poa", "cells_polish", "n_poa_redo")]
+               [(n, C.c_int64) for n in ("n_reads", "n_bases", "n_windows", "cells_conk", "cells_poa", "cells_polish", "n_poa_redo")] + \
+               [(n, C.c_float) for n in ("ms_wall", "ms_host_worklist", "ms_alloc")]
 
 
 class HostBatchStruct(C.Structure):

@@ -88,14 +88,17 @@ static inline double dbg_now_ms() { using namespace std::chrono; return duration
 #define DBG(...) do { if (getenv("C3_DEBUG")) { fprintf(stderr, "[c3 %.3f] ", dbg_now_ms()); fprintf(stderr, __VA_ARGS__); fflush(stderr); } } while (0)
 
 // ---- handle -----------------------------------------------------------------------------
+static thread_local double g_alloc_ms = 0.0;   // host time spent growing device buffers (hipFree synchronises the device)
 struct DBuf {
   void* p = nullptr; size_t cap = 0;
   hipError_t ensure(size_t bytes) {
     if (bytes <= cap) return hipSuccess;
+    const double t0 = dbg_now_ms();
     if (p) { hipError_t e = hipFree(p); p = nullptr; cap = 0; if (e != hipSuccess) return e; }
     size_t want = bytes + bytes / 8 + 256;
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
+    g_alloc_ms += dbg_now_ms() - t0;
     return e;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
@@ -651,6 +654,8 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
   float ms;
   hipEvent_t t0 = h->ev[0], t1 = h->ev[1], t2 = h->ev[2], t3 = h->ev[3], t4 = h->ev[4];
   DBG("run: start n=%d\n", h->n);
+  const auto wall0 = std::chrono::steady_clock::now();
+  const double alloc0 = g_alloc_ms;
   // per-run figures start from zero: repeated runs of one resident batch (bench.py, tools/) must not accumulate
   if (stages & C3_STAGE_CONK) { h->tm.ms_conk = 0; h->tm.cells_conk = 0; }
   if (stages & C3_STAGE_PEAKS) h->tm.ms_peaks = 0;
@@ -664,7 +669,9 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
   float ms_prep = 0, ms_win = 0, ms_st = 0;
   if (stages & (C3_STAGE_POA | C3_STAGE_POLISH)) {
     DBG("run: conk+peaks launched\n");
+    const auto wl0 = std::chrono::steady_clock::now();
     if ((rc = fetch_summary(h))) return rc;
+    h->tm.ms_host_worklist = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wl0).count();
     DBG("run: work list ready (%zu reads)\n", h->work.size());
     HIPCHK(hipEventRecord(t3, h->stream));
     if (stages & C3_STAGE_POA) {
@@ -689,6 +696,8 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
   if (stages & C3_STAGE_PEAKS) { HIPCHK(hipEventElapsedTime(&ms, t1, t2)); h->tm.ms_peaks = ms; }
   if (stages & C3_STAGE_POLISH) { h->tm.ms_prep = ms_prep; h->tm.ms_window = ms_win; h->tm.ms_stitch = ms_st; }
   h->tm.ms_total = h->tm.ms_conk + h->tm.ms_peaks + h->tm.ms_poa + h->tm.ms_prep + h->tm.ms_window + h->tm.ms_stitch;
+  h->tm.ms_wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  h->tm.ms_alloc = (float)(g_alloc_ms - alloc0);
   h->stages_done |= stages;
   return C3_E_OK;
 }

@@ -122,7 +122,7 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
         free_results.put(_lib.ResultBuffers())
     parsed = [queue.Queue(maxsize=1) for _ in range(n_ranges)]
     to_write = [queue.Queue(maxsize=2) for _ in range(n_work)]
-    t = dict(parse=0.0, assign=0.0, upload=0.0, upload_dev=0.0, run=0.0, run_dev=0.0, fetch=0.0, write=0.0, wait_in=0.0, wait_out=0.0,
+    t = dict(parse=0.0, assign=0.0, upload=0.0, upload_dev=0.0, run=0.0, run_c=0.0, run_dev=0.0, alloc=0.0, fetch=0.0, write=0.0, wait_in=0.0, wait_out=0.0,
              setup=0.0, close=0.0, scan=0.0, reads=0, batches=0, short=0, assigned=0, ranges=n_ranges)
     seen = set()
     errors, lock = [], threading.Lock()
@@ -224,11 +224,12 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                 t2 = time.perf_counter()
                 up_dev = h.last_timing["ms_pack"] * 1e-3
                 run_dev = h.last_timing["ms_total"] * 1e-3
+                run_c = h.last_timing.get("ms_wall", 0.0) * 1e-3; wl_c = h.last_timing.get("ms_alloc", 0.0) * 1e-3
                 rb = free_results.get()
                 res, buf, coff = h.results_raw(into=rb)
                 t3 = time.perf_counter()
                 with lock:
-                    t["upload_dev"] += up_dev; t["run_dev"] += run_dev
+                    t["upload_dev"] += up_dev; t["run_dev"] += run_dev; t["run_c"] += run_c; t["alloc"] += wl_c
                     t["run"] += t2 - t1; t["fetch"] += t3 - t2
                 tw = time.perf_counter()
                 to_write[w].put((hb, sid, res, buf, coff, rb))

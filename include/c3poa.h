@@ -78,6 +78,9 @@ typedef struct {
   int64_t n_reads, n_bases, n_windows;
   int64_t cells_conk, cells_poa, cells_polish;
   int64_t n_poa_redo;      /* reads whose POA scratch (sized for the typical alignment) overflowed and were redone full-size */
+  float ms_wall;           /* host wall time of the whole c3_batch_run call; ms_wall - ms_total = time the GPU waited for the host */
+  float ms_host_worklist;  /* of which: conk + peaks summary fetch and the POA work list (the GPU is busy for most of it) */
+  float ms_alloc;          /* of which: growing device scratch buffers (only while batch shapes are still growing) */
 } c3_timing;
 
 typedef struct c3_handle c3_handle;
