@@ -128,7 +128,7 @@ struct c3_handle {
   int peaks_grid = 0; bool debug_msa = false; bool injected = false;
   int n_windows = 0;
   c3_timing tm;
-  unsigned long long phase_poa[12] = {0}, phase_win[12] = {0};
+  unsigned long long phase_poa[16] = {0}, phase_win[16] = {0};
   int stages_done = 0;
 };
 
@@ -553,7 +553,7 @@ static int run_poa(c3_handle* h) {
     c3k_launch_zero_finish(&z, std::min((int)h->zwork.size(), 512), h->stream);
     HIPCHK(hipGetLastError());
   }
-  HIPCHK(hipMemcpyAsync(h->phase_poa, h->d_counter.as<char>() + 64, 96, hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(h->phase_poa, h->d_counter.as<char>() + 64, 128, hipMemcpyDeviceToHost, h->stream));
   return 0;
 }
 
@@ -626,7 +626,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
     c3k_launch_window(&a, slots, h->stream);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h->phase_win, h->d_counter.as<char>() + 64, 96, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(h->phase_win, h->d_counter.as<char>() + 64, 128, hipMemcpyDeviceToHost, h->stream));
   }
   HIPCHK(hipEventRecord(h->ev[8], h->stream));
   StitchArgs s; memset(&s, 0, sizeof(s));
@@ -759,7 +759,7 @@ extern "C" int c3_debug_calibrate(c3_handle* h, long long bytes) {
 // diagnostic builds (-DC3_PHASE_PROF) only: per-phase cycle sums of k_poa (which=0) / k_window (which=1)
 extern "C" int c3_debug_phases(c3_handle* h, int which, unsigned long long* out) {
   if (!h || !out) return C3_E_ARG;
-  memcpy(out, which ? h->phase_win : h->phase_poa, 96);
+  memcpy(out, which ? h->phase_win : h->phase_poa, 128);
   return C3_E_OK;
 }
 

@@ -101,9 +101,9 @@ __device__ __forceinline__ int wave_scan_add(int x) {
 
 // diagnostic build only (-DC3_PHASE_PROF): per-phase cycle sums, never in the shipped library
 #ifdef C3_PHASE_PROF
-#define PH_DECL unsigned long long ph_t0_ = __builtin_readcyclecounter(), ph_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define PH_DECL unsigned long long ph_t0_ = __builtin_readcyclecounter(), ph_acc_[16] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
 #define PH_MARK(i) { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[i] += t_ - ph_t0_; ph_t0_ = t_; }
-#define PH_FLUSH(p) if (wave_lane() == 0) { for (int i_ = 0; i_ < 12; ++i_) atomicAdd((p) + i_, ph_acc_[i_]); }
+#define PH_FLUSH(p) if (wave_lane() == 0) { for (int i_ = 0; i_ < 16; ++i_) atomicAdd((p) + i_, ph_acc_[i_]); }
 #else
 #define PH_DECL
 #define PH_MARK(i)

@@ -104,7 +104,7 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 }
 
 #ifdef C3_PHASE_PROF
-#define PHA , unsigned long long& ph_t0_, unsigned long long (&ph_acc_)[12]
+#define PHA , unsigned long long& ph_t0_, unsigned long long (&ph_acc_)[16]
 #define PHP , ph_t0_, ph_acc_
 #else
 #define PHA

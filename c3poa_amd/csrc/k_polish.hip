@@ -513,6 +513,9 @@ __device__ __attribute__((noinline)) int win_rows(WCtx cv, int mt_, int mm_, int
       else *GP(unsigned, c.D + doff) = w2;
       continue;
     }
+#ifdef C3_PHASE_PROF
+    const unsigned long long gen_t0 = __builtin_readcyclecounter();
+#endif
     de.y = __builtin_amdgcn_readlane(dblk.y, li);
     de.z = __builtin_amdgcn_readlane(dblk.z, li); de.w = 0;
     const int vb = de.x & 0xff, np = (de.x >> 8) & 0xff;
@@ -635,6 +638,10 @@ __device__ __attribute__((noinline)) int win_rows(WCtx cv, int mt_, int mm_, int
 #pragma unroll
       for (int cc = 0; cc < CPL; ++cc) if (lane * CPL + cc == Q) GP(int, c.hend())[r] = __builtin_amdgcn_sbfe(hcur[cc], 2, 14);
     }
+#ifdef C3_PHASE_PROF
+    // cycles of the general rows by kind: [2] several predecessors, [3] one predecessor that is not r-1, [4] r-1 but kept; [5] all rows
+    dbg[!two ? 2 : ((de.y & 0xffff) == (unsigned)(r - 1) ? 4 : 3)] += __builtin_readcyclecounter() - gen_t0;
+#endif
   }
   }
   WSYNC();
@@ -940,10 +947,10 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
         WSYNC();
         PH_MARK(2)
         int cpl = 0, RS = 0;
-        unsigned long long dbg_[3] = {0, 0, 0};
+        unsigned long long dbg_[6] = {0, 0, 0, 0, 0, 0};
         if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, 4 * (((a.Ncap + 64) >> 6) + 1)) < 0) { fail = 1; break; }   // (LDS ring behind the two bitmasks, in dwords)
 #ifdef C3_PHASE_PROF
-        ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1];
+        ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1]; ph_acc_[12] += dbg_[2]; ph_acc_[13] += dbg_[3]; ph_acc_[14] += dbg_[4]; ph_acc_[15] += dbg_[5];
 #endif
         PH_MARK(3)
         cells += (long long)(R + 1) * (Q + 1);

@@ -24,7 +24,7 @@ names = [["remain/init", "DP rows", "traceback", "fuse", "reorder", "columns", "
          ["backbone", "sort+mask", "compaction", "DP rows", "end select", "traceback", "fuse", "reorder", "consensus", "queue/other"]]
 h.lib.c3_debug_phases.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
 for which, kn in ((0, "k_poa"), (1, "k_window")):
-    out = (C.c_uint64 * 12)()
+    out = (C.c_uint64 * 16)()
     h.lib.c3_debug_phases(h.h, which, out)
     tot = float(sum(out[:8]) + out[9] + (out[8] if which else 0)) or 1.0
     print(kn, " ".join("%s=%.1f%%" % (names[which][i], 100 * out[i] / tot) for i in range(10) if out[i]), "| raw[8..11] =", out[8], out[9], out[10], out[11])
@@ -32,5 +32,8 @@ for which, kn in ((0, "k_poa"), (1, "k_window")):
         rows = out[11] & 0xffffffff; gen = out[10] >> 32; kept = out[10] & 0xffffffff; multi = out[11] >> 32
         print("   rows %d: fast %.1f%%, general %.1f%% = predecessor r-1 but kept for later %.1f%% + several predecessors %.1f%% + one far predecessor %.1f%%" % (
             rows, 100.0 * (rows - gen) / rows, 100.0 * gen / rows, 100.0 * kept / rows, 100.0 * multi / rows, 100.0 * (gen - kept - multi) / rows))
+        far = gen - kept - multi
+        print("   cycles per general row: several predecessors %.0f, one far predecessor %.0f, r-1 kept %.0f; all DP-row cycles / all rows = %.0f" % (
+            out[12] / max(multi, 1), out[13] / max(far, 1), out[14] / max(kept, 1), out[3] / max(rows, 1)))
     if which == 0 and out[1]:
         print("   DP rows by kind (cycles): fast %.1f%%, near %.1f%%, general %.1f%% of the row loop" % tuple(100.0 * out[i] / max(out[8] + out[10] + out[11], 1) for i in (8, 10, 11)))
