@@ -186,10 +186,12 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
             h.set_splints([splint_dict[n][0] for n in splint_names])
             with lock:
                 t["setup"] += time.perf_counter() - ts
+                t["at_setup_done"] = time.perf_counter() - t_start
             # software pipeline on one handle: while batch i runs, batch i+1 (if a reader already has it) is copied
             # and 2-bit packed on the handle's second stream (c3_batch_stage); c3_batch_commit makes it resident once
             # the results of batch i have been fetched
             cur = take()
+            t["at_first_batch"] = time.perf_counter() - t_start
             if cur is not None and not errors:
                 t0 = time.perf_counter()
                 h.upload_host(cur[0], cur[2], np.maximum(cur[1], 0))
@@ -250,6 +252,7 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                     t["upload"] += time.perf_counter() - t0
                 cur = nxt
             tc = time.perf_counter()
+            t["at_last_run_done"] = tc - t_start
             h.close()
             with lock:
                 t["close"] += time.perf_counter() - tc
@@ -281,6 +284,7 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
             free_results.put(rb)
             free_sets[k].put(j)
 
+    t_start = time.perf_counter()
     rthreads = [threading.Thread(target=reader_thread, args=(k,), daemon=True) for k in range(n_ranges)]
     others = [threading.Thread(target=writer_thread, args=(w,), daemon=True) for w in range(n_work)]
     others += [threading.Thread(target=device_thread, args=(w,), daemon=True) for w in range(n_work)]
@@ -288,12 +292,14 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
         th.start()
     for th in others:
         th.join()
+    t["at_workers_done"] = time.perf_counter() - t_start
     if errors:
         raise errors[0]
     for th in rthreads:
         th.join()
     for rd in readers:
         rd.close()
+    t["at_readers_closed"] = time.perf_counter() - t_start
     if fused:
         os.replace(finder_psl + ".part", finder_psl)              # a rerun finds the PSL and takes the two-pass route
         for n, cp, sp in zip(splint_names, cons_paths, sub_paths):
