@@ -320,15 +320,30 @@ __device__ void w_blocks(WCtx& c, int lane) {
   }
   WSYNC();
 }
-__device__ void w_reorder(WCtx& c, int n_old, int lane) {
+__device__ void w_reorder(WCtx& c, int n_old, int lane, int* lds, int lds_cap) {
   const int n_new = c.n - n_old;
-  for (int i = lane; i < n_old; i += 64) {
-    int lo = 0, hi = n_new;
-    while (lo < hi) { int m = (lo + hi) >> 1; if (c.anchor()[m] < i) lo = m + 1; else hi = m; }
-    c.order2()[i + lo] = c.order()[i];
+  // old node at old index i moves to i + #(anchor < i); new node k goes to anchor[k] + 1 + k.  The (sorted) anchors of the new
+  // nodes are staged in LDS first: the binary search per old node is then 6-8 LDS reads instead of 6-8 dependent global loads
+  // per 64 nodes (the LDS scratch of the alignment is idle during the graph phases)
+  if (n_new <= lds_cap) {
+    for (int k = lane; k < n_new; k += 64) lds[k] = c.anchor()[k];
+    WSYNC();
+    for (int i = lane; i < n_old; i += 64) {
+      int lo = 0, hi = n_new;                 // first k with anchor[k] >= i
+      while (lo < hi) { int m = (lo + hi) >> 1; if (lds[m] < i) lo = m + 1; else hi = m; }
+      c.order2()[i + lo] = c.order()[i];
+    }
+    for (int k = lane; k < n_new; k += 64) c.order2()[lds[k] + 1 + k] = n_old + k;
+    WSYNC();                                  // (the LDS words are free again)
+  } else {
+    for (int i = lane; i < n_old; i += 64) {
+      int lo = 0, hi = n_new;
+      while (lo < hi) { int m = (lo + hi) >> 1; if (c.anchor()[m] < i) lo = m + 1; else hi = m; }
+      c.order2()[i + lo] = c.order()[i];
+    }
+    for (int k = lane; k < n_new; k += 64) c.order2()[c.anchor()[k] + 1 + k] = n_old + k;
+    WSYNC();
   }
-  for (int k = lane; k < n_new; k += 64) c.order2()[c.anchor()[k] + 1 + k] = n_old + k;
-  WSYNC();
   for (int i = lane; i < c.n; i += 64) { int v = c.order2()[i]; c.order()[i] = v; c.index()[v] = i; }
   WSYNC();
   w_blocks(c, lane);
@@ -858,6 +873,7 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
   int* s_score = lds_dyn; unsigned short* s_pred = (unsigned short*)(lds_dyn + a.Lcap);
   // the same LDS holds the row-type bitmasks of the layer being aligned (DP rows + traceback; the consensus sweep comes later)
   unsigned long long* m2bits = (unsigned long long*)lds_dyn; unsigned long long* mabits = m2bits + ((a.Ncap + 64) >> 6) + 1;
+  const int lds_ints = (int)(max((size_t)a.Lcap * 6 + 16, (size_t)16 * (((a.Ncap + 64) >> 6) + 1) + 4 * 5 * 64 * 4 + 64) / 4);    // = the launch's dynamic LDS
   PH_DECL
 
   for (;;) {
@@ -1109,7 +1125,7 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
         WSYNC();
         c.n = nn;
         PH_MARK(6)
-        w_reorder(c, n_old, lane);
+        w_reorder(c, n_old, lane, lds_dyn, lds_ints);     // the whole dynamic LDS is idle between traceback and consensus
         PH_MARK(7)
       }
       if (!fail) {
