@@ -22,6 +22,9 @@
 // adjacency slot k of node v.  Slot-major (all first edges, then all second edges, ...): nearly every node has one or two
 // edges, so the arrays a wave actually touches are contiguous runs of Ncap ints instead of one 64-byte line per node
 #define EI(v, k) ((size_t)(k) * (size_t)c.Ncap + (size_t)(v))
+#ifndef C3_WIN_RING
+#define C3_WIN_RING 1          /* LDS ring of the last four kept H rows in k_window's row loop */
+#endif
 
 
 
@@ -360,9 +363,12 @@ __device__ void w_reorder(WCtx& c, int n_old, int lane, int* lds, int lds_cap) {
 // of a round without a dependent global load (allow2 = false: every row uses byte cells, e.g. the linear fallback).
 __device__ void win_build_desc(WCtx& c, int R, int lane, unsigned long long* m2, unsigned long long* ma, bool allow2) {
   const int K = c.K;
+  int* kept = c.opn();                          // kept[r] = number of kept (needH) rows before row r (free between two tracebacks)
+  int nkept = 0;
   for (int r0 = 1; r0 <= R; r0 += 64) {
     const int r = r0 + lane;
     bool two = false, adj = false;
+    unsigned needh = 0;
     if (r <= R) {
       const int v = c.rows()[r];
       const int nin = c.n_in()[v];
@@ -374,7 +380,7 @@ __device__ void win_build_desc(WCtx& c, int R, int lane, unsigned long long* m2,
         if (np < 4) p[np] = (unsigned)pr;
         ++np;
       }
-      unsigned needh = 0, has = 0;
+      unsigned has = 0;
       for (int k = 0; k < c.n_out()[v]; ++k) {
         const int sr = c.rowof()[c.out_to()[EI(v, k)]];
         if (sr >= 0) { has = 1; if (sr != r + 1 && sr != r + 2) needh = 1; }     // rows r-1 and r-2 stay in registers
@@ -390,10 +396,29 @@ __device__ void win_build_desc(WCtx& c, int R, int lane, unsigned long long* m2,
       c.rdesc[r] = d;
       c.hend()[r] = INT32_MIN;
     }
-    const unsigned long long b2 = __ballot(two), ba = __ballot(adj);
+    const unsigned long long b2 = __ballot(two), ba = __ballot(adj), bk = __ballot(needh != 0);
+    if (r <= R) kept[r] = nkept + __popcll(bk & ((1ull << lane) - 1));
+    nkept += __popcll(bk);
     if (lane == 0) { m2[r0 >> 6] = b2; ma[r0 >> 6] = ba; }
   }
   WSYNC();
+  // bit 21 of a kept row: some far successor will NOT find it in the LDS ring any more, so its H row must also go to global
+  // memory.  The ring holds the last four kept rows in the order they were written: row p is still there at row s iff at most
+  // three kept rows lie between them.  Most kept rows are consumed within a few rows and never leave the CU.
+  if (C3_WIN_RING) {
+    for (int r = 1 + lane; r <= R; r += 64) {
+      const unsigned dx = ((const unsigned*)(c.rdesc + r))[0];
+      if (!((dx >> 17) & 1)) continue;
+      const int v = c.rows()[r], kr = kept[r];
+      unsigned miss = 0;
+      for (int k = 0; k < c.n_out()[v]; ++k) {
+        const int sr = c.rowof()[c.out_to()[EI(v, k)]];
+        if (sr >= 0 && sr != r + 1 && sr != r + 2 && kept[sr] - kr - 1 > 3) miss = 1;
+      }
+      if (miss) ((unsigned*)(c.rdesc + r))[0] = dx | (1u << 21);
+    }
+    WSYNC();
+  }
 }
 
 // predecessor row number t of DP row r (descriptor order); rows with more than 4 masked
@@ -419,9 +444,6 @@ __device__ int win_pred_row(const WCtx& c, const uint4& de, int r, int t) {
 // only rows with more than one predecessor have to track.  The D byte of a cell is tag = 255 - p, p = 0..63 diagonal from
 // predecessor p, 64..127 vertical from predecessor p-64, 128..191 horizontal; single-predecessor rows store the 2-bit type.
 // (Columns past Q compute garbage that only ever flows to the right: never read.)
-#ifndef C3_WIN_RING
-#define C3_WIN_RING 1
-#endif
 #define W_NEG16 (-32000)
 #define W_TAG_H 127           /* byte rows of the linear fallback: 255 - 128 */
 #define VREG(x) asm volatile("" : "+v"(x))       /* keep a uniform value in a vector register (no instruction) */
@@ -636,9 +658,11 @@ __device__ __attribute__((noinline)) int win_rows(WCtx cv, int mt_, int mm_, int
       for (int w = 0; w < DS / 4; ++w) drow[w] = dpk[w];
     }
     if (needh) {
-      auto* hrow = GP(short, c.H) + (size_t)r * RS;
+      if (!C3_WIN_RING || ((de.x >> 21) & 1)) {                            // only rows that outlive their stay in the ring
+        auto* hrow = GP(short, c.H) + (size_t)r * RS;
 #pragma unroll
-      for (int cc = 0; cc < CPL; ++cc) hrow[cc * 64 + lane] = (short)hcur[cc];             // (columns past Q: inside the row, never read)
+        for (int cc = 0; cc < CPL; ++cc) hrow[cc * 64 + lane] = (short)hcur[cc];           // (columns past Q: inside the row, never read)
+      }
       if (C3_WIN_RING) {
       const int sl = rnext;
       rnext = (rnext + 1) & 3;
