@@ -274,33 +274,33 @@ __global__ __launch_bounds__(64, C3_PREP_WAVES) void k_prep(PrepArgs a) {
 
 // ------------------------------------------------------------------------------------------
 
-// Per-slot scratch of k_window.  Only three base pointers are kept live (the array pointers are
-// base + constant multiples of Ncap), which keeps the uniform state in SGPRs instead of VGPRs.
+// Per-slot scratch of k_window.  Only the base pointers are kept live: an array accessor returns (base, element offset) and
+// its operator[] forms the address as base + 32-bit byte offset, i.e. a scalar base with a vector offset (`global_load v, v,
+// s[..]`).  Handing out base + k*Ncap as POINTERS made the compiler keep some twenty-five derived 64-bit pointers alive:
+// it spilled ~190 SGPRs into vector lanes and re-read them with v_readlane all over the graph phases.
+template <class T> struct WArr {
+  T* base; unsigned off;
+  __device__ __forceinline__ T& at(unsigned i) const { return *(T*)((char*)base + ((i + off) * (unsigned)sizeof(T))); }
+  __device__ __forceinline__ T& operator[](int i) const { return at((unsigned)i); }
+  __device__ __forceinline__ T& operator[](unsigned i) const { return at(i); }
+  __device__ __forceinline__ T& operator[](long long i) const { return at((unsigned)i); }
+  __device__ __forceinline__ T& operator[](size_t i) const { return at((unsigned)i); }
+  __device__ __forceinline__ T* ptr() const { return base + off; }
+};
 struct WCtx {
   int* I; int* E; uint8_t* B8; long long* score; int32_t* H; uint8_t* D; uint4* rdesc;
   int K, n, Ncap; long long hcap;
-  __device__ __forceinline__ int* n_in() const { return I; }
-  __device__ __forceinline__ int* n_out() const { return I + (size_t)Ncap; }
-  __device__ __forceinline__ int* grp() const { return I + 2 * (size_t)Ncap; }
-  __device__ __forceinline__ int* order() const { return I + 3 * (size_t)Ncap; }
-  __device__ __forceinline__ int* order2() const { return I + 4 * (size_t)Ncap; }
-  __device__ __forceinline__ int* index() const { return I + 5 * (size_t)Ncap; }
-  __device__ __forceinline__ int* gfirst() const { return I + 6 * (size_t)Ncap; }
-  __device__ __forceinline__ int* glast() const { return I + 7 * (size_t)Ncap; }
-  __device__ __forceinline__ int* ncov() const { return I + 8 * (size_t)Ncap; }
-  __device__ __forceinline__ int* rowof() const { return I + 9 * (size_t)Ncap; }
-  __device__ __forceinline__ int* anchor() const { return I + 10 * (size_t)Ncap; }
-  __device__ __forceinline__ int* pred() const { return I + 11 * (size_t)Ncap; }
-  __device__ __forceinline__ int* hend() const { return I + 11 * (size_t)Ncap; }      // shares pred (disjoint lifetimes)
-  __device__ __forceinline__ int* opn() const { return I + 12 * (size_t)Ncap; }       // 2N
-  __device__ __forceinline__ int* opq() const { return I + 14 * (size_t)Ncap; }       // 2N
-  __device__ __forceinline__ int* rows() const { return I + 16 * (size_t)Ncap; }      // N+1
-  __device__ __forceinline__ int* in_from() const { return E; }
-  __device__ __forceinline__ int* in_w() const { return E + (size_t)Ncap * K; }
-  __device__ __forceinline__ int* out_to() const { return E + 2 * (size_t)Ncap * K; }
-  __device__ __forceinline__ int* out_w() const { return E + 3 * (size_t)Ncap * K; }
-  __device__ __forceinline__ uint8_t* base() const { return B8; }
-  __device__ __forceinline__ uint8_t* mask() const { return B8 + (size_t)Ncap; }
+#define W_I(name, k) __device__ __forceinline__ WArr<int> name() const { return {I, (unsigned)(k) * (unsigned)Ncap}; }
+  W_I(n_in, 0) W_I(n_out, 1) W_I(grp, 2) W_I(order, 3) W_I(order2, 4) W_I(index, 5) W_I(gfirst, 6) W_I(glast, 7) W_I(ncov, 8)
+  W_I(rowof, 9) W_I(anchor, 10) W_I(pred, 11) W_I(hend, 11) /* shares pred (disjoint lifetimes) */ W_I(opn, 12) /* 2N */ W_I(opq, 14) /* 2N */
+  W_I(rows, 16) /* N+1 */
+#undef W_I
+  __device__ __forceinline__ WArr<int> in_from() const { return {E, 0u}; }
+  __device__ __forceinline__ WArr<int> in_w() const { return {E, (unsigned)Ncap * (unsigned)K}; }
+  __device__ __forceinline__ WArr<int> out_to() const { return {E, 2u * (unsigned)Ncap * (unsigned)K}; }
+  __device__ __forceinline__ WArr<int> out_w() const { return {E, 3u * (unsigned)Ncap * (unsigned)K}; }
+  __device__ __forceinline__ WArr<uint8_t> base() const { return {B8, 0u}; }
+  __device__ __forceinline__ WArr<uint8_t> mask() const { return {B8, (unsigned)Ncap}; }
 };
 #define W_INTS 18   // ints of Ncap per slot in WCtx::I (17*Ncap + 1 used)
 
@@ -363,7 +363,7 @@ __device__ void w_reorder(WCtx& c, int n_old, int lane, int* lds, int lds_cap) {
 // of a round without a dependent global load (allow2 = false: every row uses byte cells, e.g. the linear fallback).
 __device__ void win_build_desc(WCtx& c, int R, int lane, unsigned long long* m2, unsigned long long* ma, bool allow2) {
   const int K = c.K;
-  int* kept = c.opn();                          // kept[r] = number of kept (needH) rows before row r (free between two tracebacks)
+  const WArr<int> kept = c.opn();               // kept[r] = number of kept (needH) rows before row r (free between two tracebacks)
   int nkept = 0;
   for (int r0 = 1; r0 <= R; r0 += 64) {
     const int r = r0 + lane;
@@ -566,9 +566,9 @@ __device__ __attribute__((noinline)) int win_rows(WCtx cv, int mt_, int mm_, int
       int prow;
       if (!ovf) prow = (t == 0) ? (de.y & 0xffff) : (t == 1) ? (de.y >> 16) : (t == 2) ? (de.z & 0xffff) : (de.z >> 16);
       else {                                                                 // >4 predecessors: walk the in-edges
-        const int v = GP(const int, c.rows())[r];
+        const int v = GP(const int, c.rows().ptr())[r];
         prow = -1;
-        while (kedge < GP(const int, c.n_in())[v]) { int pr = GP(const int, c.rowof())[GP(const int, c.in_from())[EI(v, kedge)]]; ++kedge; if (pr >= 0) { prow = pr; break; } }
+        while (kedge < GP(const int, c.n_in().ptr())[v]) { int pr = GP(const int, c.rowof().ptr())[GP(const int, c.in_from().ptr())[EI(v, kedge)]]; ++kedge; if (pr >= 0) { prow = pr; break; } }
         if (prow < 0) break;
       }
 #ifdef C3_PHASE_PROF
@@ -675,7 +675,7 @@ __device__ __attribute__((noinline)) int win_rows(WCtx cv, int mt_, int mm_, int
     }
     if (isend) {
 #pragma unroll
-      for (int cc = 0; cc < CPL; ++cc) if (lane * CPL + cc == Q) GP(int, c.hend())[r] = __builtin_amdgcn_sbfe(hcur[cc], 2, 14);
+      for (int cc = 0; cc < CPL; ++cc) if (lane * CPL + cc == Q) GP(int, c.hend().ptr())[r] = __builtin_amdgcn_sbfe(hcur[cc], 2, 14);
     }
 #ifdef C3_PHASE_PROF
     // cycles of the general rows by kind: [2] several predecessors, [3] one predecessor that is not r-1, [4] r-1 but kept; [5] all rows
@@ -951,7 +951,7 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
           // blocks (the block graph is a DAG, so greatest == least fixpoint); a few parallel sweeps.
           const int K = c.K;
           const int eidx = c.glast()[c.grp()[l.end]];
-          int* gseed = c.rowof();
+          const WArr<int> gseed = c.rowof();
           for (int i = lane; i < c.n; i += 64) { const int v = c.order()[i]; c.mask()[v] = (v >= l.begin && i <= eidx) ? 1 : 0; }
           WSYNC();
           for (;;) {
@@ -1007,7 +1007,7 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
         // LDS read: the wave checks 64 cells down the diagonal at once ("diagonal move from the row above"?), consumes the
         // run, and resolves the cell that breaks it.  One memory round trip per 64 rows instead of one per break -- and
         // the traceback no longer fetches about as many bytes as the fill wrote.
-        int* rq = c.opq(); int* tq = c.opn();
+        const WArr<int> rq = c.opq(), tq = c.opn();
         {
           unsigned* WD = (unsigned*)(mabits + ((a.Ncap + 64) >> 6) + 1);       // [64][4] dwords, behind the row-type bitmasks
           const int cdiv = cpl ? (65536 + cpl - 1) / cpl : 0;                   // j / cpl == (j * cdiv) >> 16 for j < 2^13
