@@ -3,6 +3,7 @@
 #include "c3_dev.h"
 #include "c3_args.h"
 #include <algorithm>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -68,12 +69,12 @@ __global__ void k_init_info(C3Info* info, int n) {
   if (i < n) { C3Info* p = &info[i]; p->status = C3_ST_OK; p->n_peaks = 0; p->n_sub = 0; p->has_front = p->has_tail = 0;
                p->front_end = p->tail_beg = 0; p->cons_len = 0; p->draft_len = 0; p->n_win = 0; }
 }
-struct Summary { int status, n_sub, max_sub, sum_sub, max_dang, front, tail; };
+struct Summary { int status, n_sub, max_sub, sum_sub, max_dang, front, tail, n_peaks; };
 __global__ void k_summary(const C3Info* info, const int64_t* off, int n, Summary* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const C3Info* p = &info[i];
-  Summary s; s.status = p->status; s.n_sub = p->n_sub; s.max_sub = 0; s.sum_sub = 0; s.max_dang = 0;
+  Summary s; s.status = p->status; s.n_sub = p->n_sub; s.max_sub = 0; s.sum_sub = 0; s.max_dang = 0; s.n_peaks = p->n_peaks;
   for (int k = 0; k < p->n_sub; ++k) { int l = p->sub_end[k] - p->sub_beg[k]; s.sum_sub += l; if (l > s.max_sub) s.max_sub = l; }
   int L = (int)(off[i + 1] - off[i]);
   s.front = p->has_front ? p->front_end : 0; s.tail = p->has_tail ? L - p->tail_beg : 0;
@@ -125,6 +126,7 @@ struct c3_handle {
   DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc;
   DBuf s_zero_d, d_zinfo, d_zflag, d_zwork; std::vector<int> zwork;  // window scratch
   std::vector<Summary> sum; std::vector<int> work;
+  int res_prefix = 0;            // entries of peaks[] / sub_beg[] / sub_end[] that any read of the resident batch uses (0: unknown)
   int peaks_grid = 0; bool debug_msa = false; bool injected = false;
   int n_windows = 0;
   c3_timing tm;
@@ -315,7 +317,7 @@ extern "C" int c3_batch_commit(c3_handle* h) {
   HIPCHK(hipGetLastError());
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev_up[0], h->ev_up[1]));
   memset(&h->tm, 0, sizeof(h->tm)); h->tm.ms_pack = ms; h->tm.n_reads = n; h->tm.n_bases = h->total;
-  h->stages_done = 0; h->injected = false; h->n_windows = 0;
+  h->stages_done = 0; h->injected = false; h->n_windows = 0; h->res_prefix = 0;
   return C3_E_OK;
 }
 
@@ -402,6 +404,10 @@ static int copy_summary(c3_handle* h) {
   h->sum.resize(n);
   HIPCHK(hipMemcpyAsync(h->sum.data(), h->d_sum.p, sizeof(Summary) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  // longest used prefix of the per-read arrays (peaks / kept subreads are final after k_peaks; the zero-repeat rescue adds two)
+  int k = 2;
+  for (int i = 0; i < n; ++i) k = std::max(k, std::max(h->sum[i].n_peaks, h->sum[i].n_sub));
+  h->res_prefix = std::min((k + 7) & ~7, (int)C3_MAX_PEAKS);
   return 0;
 }
 
@@ -712,7 +718,19 @@ extern "C" int c3_batch_sync(c3_handle* h) {
 extern "C" int c3_batch_results(c3_handle* h, c3_read_result* res, char* cons, int64_t cons_cap, int64_t* cons_off) {
   if (!h || h->n <= 0 || !res) return C3_E_ARG;
   HIPCHK(hipSetDevice(h->cfg.device));
-  HIPCHK(hipMemcpyAsync(res, h->d_info.p, sizeof(C3Info) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  // A record is 3 kB of which a typical read uses ~150 bytes: the header plus the first n_peaks / n_sub entries of three
+  // arrays.  When the batch's longest prefix is known (after the POA / polish stages) only those bytes cross PCIe, as three
+  // strided copies; array entries past a read's n_peaks / n_sub are then UNSPECIFIED in the caller's records.
+  const int kp = h->res_prefix;
+  if (kp > 0 && kp * 4 < C3_MAX_PEAKS && (h->stages_done & (C3_STAGE_POA | C3_STAGE_POLISH)) && !getenv("C3_FULL_RESULTS")) {
+    const size_t pitch = sizeof(C3Info), head = offsetof(C3Info, peaks);
+    const char* src = h->d_info.as<char>(); char* dst = (char*)res;
+    HIPCHK(hipMemcpy2DAsync(dst, pitch, src, pitch, head + 4 * (size_t)kp, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpy2DAsync(dst + offsetof(C3Info, sub_beg), pitch, src + offsetof(C3Info, sub_beg), pitch, 4 * (size_t)kp, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpy2DAsync(dst + offsetof(C3Info, sub_end), pitch, src + offsetof(C3Info, sub_end), pitch, 4 * (size_t)kp, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  } else {
+    HIPCHK(hipMemcpyAsync(res, h->d_info.p, sizeof(C3Info) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   if (!cons_off) return C3_E_OK;
   cons_off[0] = 0;

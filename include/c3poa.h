@@ -130,7 +130,9 @@ int c3_batch_sync(c3_handle* h);
 
 /* results of the resident batch.  cons receives the consensus bytes of read i at cons_off[i]
  * (cons_off[n+1] is written by the call; capacity cons_cap bytes; returns C3_E_LIMIT and the
- * needed size in cons_off[n] if too small).  Pass cons=NULL to fetch only the per-read records. */
+ * needed size in cons_off[n] if too small).  Pass cons=NULL to fetch only the per-read records.
+ * After the POA / polish stages only the used part of every record is copied: peaks[k >= n_peaks] and
+ * sub_beg / sub_end[k >= n_sub] of the caller's records are then unspecified (left as they were). */
 int c3_batch_results(c3_handle* h, c3_read_result* res, char* cons, int64_t cons_cap, int64_t* cons_off);
 int c3_batch_timing(c3_handle* h, c3_timing* t);
 
