@@ -465,11 +465,14 @@ template <class T> __device__ __forceinline__ T* uni_ptr(T* p) {
 // every older store).  As a function the rows get a register file of their own; the call costs a few dozen instructions
 // per LAYER.
 template <int CPL>
-__device__ __attribute__((noinline)) int win_rows(WCtx cv, int mt_, int mm_, int g_, const uint32_t* pk_, int qbeg_, int Q_, int R_, unsigned long long* dbg_, int ring_off_) {
+// (the context travels as scalars: a struct passed by value gets an 80-byte stack slot PER CALL SITE, and the kernel's scratch
+// segment -- sized for every wave slot of the device -- decides how long the process's first launch waits for the runtime)
+__device__ __attribute__((noinline)) int win_rows(int* cI, int* cE, int32_t* cH, uint8_t* cD, uint4* crdesc, int cK, int cn, int cNcap, long long chcap,
+                                                  int mt_, int mm_, int g_, const uint32_t* pk_, int qbeg_, int Q_, int R_, unsigned long long* dbg_, int ring_off_) {
   WCtx c;
-  c.I = uni_ptr(cv.I); c.E = uni_ptr(cv.E); c.B8 = uni_ptr(cv.B8); c.score = uni_ptr(cv.score); c.H = uni_ptr(cv.H); c.D = uni_ptr(cv.D);
-  c.rdesc = uni_ptr(cv.rdesc); c.K = uni32(cv.K); c.n = uni32(cv.n); c.Ncap = uni32(cv.Ncap);
-  c.hcap = ((long long)uni32((int)(cv.hcap >> 32)) << 32) | (unsigned)uni32((int)cv.hcap);
+  c.I = uni_ptr(cI); c.E = uni_ptr(cE); c.B8 = nullptr; c.score = nullptr; c.H = uni_ptr(cH); c.D = uni_ptr(cD);
+  c.rdesc = uni_ptr(crdesc); c.K = uni32(cK); c.n = uni32(cn); c.Ncap = uni32(cNcap);
+  c.hcap = ((long long)uni32((int)(chcap >> 32)) << 32) | (unsigned)uni32((int)chcap);
   const uint32_t* pk = uni_ptr(pk_);
   unsigned long long* dbg = uni_ptr(dbg_);
   const int qbeg = uni32(qbeg_), Q = uni32(Q_), R = uni32(R_);
@@ -751,11 +754,11 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
   *cpl_out = cpl; *rs_out = cpl ? 64 * ((cpl + 3) & ~3) : need * 64;    // D row stride in bytes
   win_build_desc(c, R, lane, m2, ma, cpl != 0);
   switch (cpl) {
-    case 2: return win_rows<2>(c, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
-    case 4: return win_rows<4>(c, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
-    case 6: return win_rows<6>(c, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
-    case 8: return win_rows<8>(c, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
-    case 10: return win_rows<10>(c, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+    case 2: return win_rows<2>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+    case 4: return win_rows<4>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+    case 6: return win_rows<6>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+    case 8: return win_rows<8>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+    case 10: return win_rows<10>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
     default: return win_rows_lin(c, P, pk, qbeg, Q, R, lane);
   }
 }
