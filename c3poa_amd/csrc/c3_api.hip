@@ -449,9 +449,11 @@ static int run_zero(c3_handle* h) {
 }
 
 static int fetch_summary(c3_handle* h) {
-  int rc = copy_summary(h);
+  int rc = copy_summary(h);                       // (waits for k_conk + k_peaks: not host time)
   DBG("summary copied\n");
   if (rc) return rc;
+  const auto wl0 = std::chrono::steady_clock::now();
+  struct WlTimer { c3_handle* h; std::chrono::steady_clock::time_point t0; ~WlTimer() { h->tm.ms_host_worklist = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } wl_timer_{h, wl0};
   HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 64, h->stream));
   if ((rc = run_zero(h))) return rc;
   const int n = h->n;
@@ -610,7 +612,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   int cnt[16];
   HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 64, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  h->tm.cells_polish += *(long long*)(cnt + 2);
+  h->tm.cells_polish += *(long long*)(cnt + 2); h->tm.cells_polish_computed += *(long long*)(cnt + 2);       // dangling-piece extensions
   // k_prep reserves windows with an atomicAdd BEFORE its capacity check: after an overflow the counter exceeds wcap, and
   // the records past wcap were never written (the reads that overflowed carry C3_ST_LIMIT and n_win = 0)
   const int n_win = (int)std::min<long long>(cnt[8], std::min<long long>(wcap, 0x7fffffff));
@@ -623,7 +625,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     const int Ncap = 3 * WL + 40 * NLcap, K = NLcap + 2;   // cfg2: 1700 nodes -> 10.2 KB of LDS per wave, 16 waves per CU
     const long long hcap = (long long)(Ncap + 1) * 64 * 12;
     const size_t N = (size_t)Ncap;
-    const int NI = 18;
+    const int NI = 19;      // W_INTS of k_polish.hip
     const size_t per_slot = N * (NI * 4 + 8 + 2) + N * K * 16 + (size_t)hcap * 6;
     const int slots = auto_slots(h, h->cfg.slots_win, per_slot, n_win, 20);
     HIPCHK(h->s_win_i.ensure(sizeof(int) * N * NI * slots + 64)); HIPCHK(h->s_win_nk.ensure(sizeof(int) * N * K * 4 * slots));
@@ -656,7 +658,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   HIPCHK(hipEventRecord(h->ev[9], h->stream));
   HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 64, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (n_win > 0) h->tm.cells_polish += *(long long*)(cnt + 2);
+  if (n_win > 0) { h->tm.cells_polish += *(long long*)(cnt + 2); h->tm.cells_polish_computed += *(long long*)(cnt + 4); h->tm.n_band_layers = cnt[6]; h->tm.n_band_fallback = cnt[7]; }
   HIPCHK(hipEventElapsedTime(ms_prep, h->ev[5], h->ev[6]));
   HIPCHK(hipEventElapsedTime(ms_win, h->ev[7], h->ev[8]));
   HIPCHK(hipEventElapsedTime(ms_st, h->ev[8], h->ev[9]));
@@ -677,7 +679,7 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
   if (stages & C3_STAGE_CONK) { h->tm.ms_conk = 0; h->tm.cells_conk = 0; }
   if (stages & C3_STAGE_PEAKS) h->tm.ms_peaks = 0;
   if (stages & C3_STAGE_POA) { h->tm.ms_poa = 0; h->tm.cells_poa = 0; }
-  if (stages & C3_STAGE_POLISH) { h->tm.ms_prep = h->tm.ms_window = h->tm.ms_stitch = 0; h->tm.cells_polish = 0; h->tm.n_windows = 0; }
+  if (stages & C3_STAGE_POLISH) { h->tm.ms_prep = h->tm.ms_window = h->tm.ms_stitch = 0; h->tm.cells_polish = 0; h->tm.cells_polish_computed = 0; h->tm.n_band_layers = h->tm.n_band_fallback = 0; h->tm.n_windows = 0; }
   HIPCHK(hipEventRecord(t0, h->stream));
   if (stages & C3_STAGE_CONK) { if ((rc = run_conk(h))) return rc; h->tm.cells_conk = 0; for (int i = 0; i < h->n; ++i) h->tm.cells_conk += (h->off[i + 1] - h->off[i]) * (int64_t)h->max_spl; }
   HIPCHK(hipEventRecord(t1, h->stream));
@@ -686,9 +688,7 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
   float ms_prep = 0, ms_win = 0, ms_st = 0;
   if (stages & (C3_STAGE_POA | C3_STAGE_POLISH)) {
     DBG("run: conk+peaks launched\n");
-    const auto wl0 = std::chrono::steady_clock::now();
     if ((rc = fetch_summary(h))) return rc;
-    h->tm.ms_host_worklist = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wl0).count();
     DBG("run: work list ready (%zu reads)\n", h->work.size());
     HIPCHK(hipEventRecord(t3, h->stream));
     if (stages & C3_STAGE_POA) {
@@ -715,6 +715,7 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
   h->tm.ms_total = h->tm.ms_conk + h->tm.ms_peaks + h->tm.ms_poa + h->tm.ms_prep + h->tm.ms_window + h->tm.ms_stitch;
   h->tm.ms_wall = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
   h->tm.ms_alloc = (float)(g_alloc_ms - alloc0);
+  h->tm.ms_host_gap = h->tm.ms_wall - h->tm.ms_total;
   h->stages_done |= stages;
   return C3_E_OK;
 }

@@ -79,8 +79,12 @@ typedef struct {
   int64_t cells_conk, cells_poa, cells_polish;
   int64_t n_poa_redo;      /* reads whose POA scratch (sized for the typical alignment) overflowed and were redone full-size */
   float ms_wall;           /* host wall time of the whole c3_batch_run call; ms_wall - ms_total = time the GPU waited for the host */
-  float ms_host_worklist;  /* of which: conk + peaks summary fetch and the POA work list (the GPU is busy for most of it) */
+  float ms_host_worklist;  /* of which: building + uploading the POA work list on the host (timer starts AFTER the wait for k_conk / k_peaks) */
   float ms_alloc;          /* of which: growing device scratch buffers (only while batch shapes are still growing) */
+  float ms_host_gap;       /* ms_wall - ms_total: time the GPU was not running one of the six timed kernels during the call */
+  int64_t cells_polish_computed;   /* polish DP cells actually computed: banded layers fill 64*CB columns per row, a layer whose band
+                                      certificate failed counts band + full matrix.  cells_polish stays the full-matrix count (= oracle) */
+  int64_t n_band_layers, n_band_fallback;   /* window layers aligned in a band and accepted / redone unbanded after a failed certificate */
 } c3_timing;
 
 typedef struct c3_handle c3_handle;

@@ -110,6 +110,10 @@ int c3o_poa_msa(const char* const* seqs, const int* lens, int n, const c3o_param
 
 /* end-cell DP scores of the alignments of the last c3o_poa_msa call on this thread (checker hook); returns their number */
 int c3o_poa_last_scores(int32_t* out, int cap);
+/* checker hook of the window polish: capture every window alignment of this thread (graph, mask, query, end score, path);
+ * record layout in c3o_polish.c.  _get returns the number of int32 words captured so far (copies up to cap of them). */
+void c3o_win_capture(int on);
+int64_t c3o_win_capture_get(int32_t* out, int64_t cap);
 
 /* bin/consensus.py pairwise_consensus: rows have msa_len chars */
 int c3o_pairwise_consensus(const char* rowA, const char* rowB, int msa_len,

@@ -23,6 +23,29 @@
 
 static const char ACGT[] = "ACGT";
 
+/* ---------- checker hook (tests/test_independent_checkers.py, tools/band_model.py) ----------
+ * When capture is on, every window alignment of this thread appends one record of int32 words (system heap, not the
+ * arena):  [W_MAGIC, window serial, layer serial in the window, blen, begin, end, full, n, Q, score, end node, n_ops]
+ * then base[n], grp[n] (aligned-block representative), order[n], per node (n_in, in_from...), mask[n] (all 1 when full), query codes[Q], ops as (node, q) pairs. */
+#undef malloc
+#undef realloc
+#undef free
+static __thread int32_t* g_cap = NULL;
+static __thread int64_t g_cap_n = 0, g_cap_cap = 0;
+static __thread int g_cap_on = 0, g_cap_win = 0, g_cap_layer = 0, g_cap_blen = 0, g_cap_begin = 0, g_cap_end = 0;
+static void cap_push(int32_t v) {
+  if (g_cap_n == g_cap_cap) { g_cap_cap = g_cap_cap ? 2 * g_cap_cap : (1 << 16); g_cap = (int32_t*)realloc(g_cap, sizeof(int32_t) * (size_t)g_cap_cap); }
+  g_cap[g_cap_n++] = v;
+}
+void c3o_win_capture(int on) { g_cap_on = on; g_cap_n = 0; g_cap_win = 0; if (!on) { free(g_cap); g_cap = NULL; g_cap_cap = 0; } }
+int64_t c3o_win_capture_get(int32_t* out, int64_t cap) {
+  if (out) for (int64_t i = 0; i < g_cap_n && i < cap; ++i) out[i] = g_cap[i];
+  return g_cap_n;
+}
+#define malloc(n) c3o_alloc(n)
+#define realloc(p, n) c3o_regrow(p, n)
+#define free(p) c3o_release(p)
+
 typedef struct { int* node; int* q; int n, cap; } oplist;
 static void op_push(oplist* o, int node, int q) {
   if (o->n == o->cap) {
@@ -165,6 +188,17 @@ static void win_align(const c3o_graph* g, const char* mask, const uint8_t* q, in
     r = nr;
   }
   for (int k = rv.n - 1; k >= 0; --k) op_push(ops, rv.node[k], rv.q[k]);
+  if (g_cap_on) {
+    cap_push(0x57494e44); cap_push(g_cap_win); cap_push(g_cap_layer); cap_push(g_cap_blen); cap_push(g_cap_begin); cap_push(g_cap_end);
+    cap_push(mask ? 0 : 1); cap_push(n); cap_push(Q); cap_push(br < 0 ? INT_MIN : bs); cap_push(br < 0 ? -1 : rows[br]); cap_push(rv.n);
+    for (int v = 0; v < n; ++v) cap_push(g->base[v]);
+    for (int v = 0; v < n; ++v) cap_push(g->grp[v]);
+    for (int i = 0; i < n; ++i) cap_push(g->order[i]);
+    for (int v = 0; v < n; ++v) { cap_push(g->n_in[v]); for (int k = 0; k < g->n_in[v]; ++k) cap_push(g->in_from[v * K + k]); }
+    for (int v = 0; v < n; ++v) cap_push(mask ? mask[v] : 1);
+    for (int j = 0; j < Q; ++j) cap_push(q[j]);
+    for (int k = rv.n - 1; k >= 0; --k) { cap_push(rv.node[k]); cap_push(rv.q[k]); }
+  }
   free(rv.node); free(rv.q); free(rowof); free(rows); free(H); free(D);
 }
 
@@ -261,11 +295,13 @@ static int window_polish(const uint8_t* bb, int blen, const wlayer* L, int nl, i
   for (int t = 0; t < nl; ++t) {
     const wlayer* l = &L[rank[t]];
     oplist ops; memset(&ops, 0, sizeof(ops));
+    g_cap_layer = t; g_cap_blen = blen; g_cap_begin = l->begin; g_cap_end = l->end;
     if (l->begin < offset && l->end > blen - offset) win_align(&g, NULL, l->seq, l->len, P, &ops, cells);
     else { subgraph_mask(&g, l->begin, l->end, mask); win_align(&g, mask, l->seq, l->len, P, &ops, cells); }
     win_fuse(&g, &ops, l->seq, l->qual, l->len);
     free(ops.node); free(ops.q);
   }
+  ++g_cap_win;
   int* cons = (int*)malloc(sizeof(int) * (size_t)g.n);
   int nc = win_consensus(&g, cons);
   int b = 0, e = nc - 1;

@@ -184,6 +184,39 @@ def poa_last_scores():
     return [int(out[i]) for i in range(min(n, 256))]
 
 
+def win_capture(on=True):
+    """checker hook: start (and clear) / stop the capture of the polish's window alignments on this thread"""
+    lib().c3o_win_capture(1 if on else 0)
+
+
+def win_captured():
+    """the captured window alignments as dicts: win, layer, blen, begin, end, full, n, Q, score, end_node, base[n], grp[n], order[n],
+    preds[n] (in-edge order), mask[n], query[Q], ops [(node, q)] (-1 = none)"""
+    L = lib()
+    L.c3o_win_capture_get.restype = C.c_int64
+    L.c3o_win_capture_get.argtypes = [C.c_void_p, C.c_int64]
+    n = L.c3o_win_capture_get(None, 0)
+    buf = np.zeros(max(n, 1), dtype=np.int32)
+    L.c3o_win_capture_get(buf.ctypes.data_as(C.c_void_p), n)
+    out, i = [], 0
+    while i < n:
+        assert buf[i] == 0x57494e44
+        win, layer, blen, begin, end, full, nn, Q, score, endn, nops = (int(x) for x in buf[i + 1:i + 12])
+        i += 12
+        base = buf[i:i + nn].copy(); i += nn
+        grp = buf[i:i + nn].copy(); i += nn
+        order = buf[i:i + nn].copy(); i += nn
+        preds = []
+        for _v in range(nn):
+            k = int(buf[i]); preds.append([int(x) for x in buf[i + 1:i + 1 + k]]); i += 1 + k
+        mask = buf[i:i + nn].astype(bool); i += nn
+        query = buf[i:i + Q].copy(); i += Q
+        ops = buf[i:i + 2 * nops].reshape(nops, 2).copy(); i += 2 * nops
+        out.append(dict(win=win, layer=layer, blen=blen, begin=begin, end=end, full=bool(full), n=nn, Q=Q, score=score,
+                        end_node=endn, base=base, grp=grp, order=order, preds=preds, mask=mask, query=query, ops=ops))
+    return out
+
+
 def normalize_len(row, qual):
     r, q = _b(row), _b(qual)
     out = C.create_string_buffer(len(r) + 8)
