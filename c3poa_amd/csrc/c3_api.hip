@@ -623,7 +623,8 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   if (n_win > 0) {
     HIPCHK(h->d_wout.ensure((size_t)n_win * wout_cap));
     const int Ncap = 3 * WL + 40 * NLcap, K = NLcap + 2;   // cfg2: 1700 nodes -> 10.2 KB of LDS per wave, 16 waves per CU
-    const long long hcap = (long long)(Ncap + 1) * 64 * 12;
+    long long hcap = (long long)(Ncap + 1) * 64 * 12;
+    if (const char* e = getenv("C3_DEBUG_HCAP_DIV")) hcap = hcap / std::max(1, atoi(e)) / 64 * 64;       // experiment: smaller DP scratch per slot (wide unbanded layers then fail)
     const size_t N = (size_t)Ncap;
     const int NI = 19;      // W_INTS of k_polish.hip
     const size_t per_slot = N * (NI * 4 + 8 + 2) + N * K * 16 + (size_t)hcap * 6;

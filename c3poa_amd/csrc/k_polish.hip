@@ -875,6 +875,7 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
   c.rdesc = uni_ptr(crdesc); c.K = uni32(cK); c.n = uni32(cn); c.Ncap = uni32(cNcap);
   c.hcap = ((long long)uni32((int)(chcap >> 32)) << 32) | (unsigned)uni32((int)chcap);
   const uint32_t* pk = uni_ptr(pk_);
+  unsigned long long* dbg = uni_ptr(dbg_);
   const int qbeg = uni32(qbeg_), Q = uni32(Q_), R = uni32(R_);
   const int lane = wave_lane();
   extern __shared__ int lds_dyn[];
@@ -917,6 +918,12 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
 #pragma unroll
     for (int cc = 0; cc < CB; ++cc) E16[eidx + cc] = (unsigned short)hcur[cc];
   }
+#ifdef C3_EXP_NOROWS
+  if (R > 0) return 0;
+#endif
+#ifdef C3_PHASE_PROF
+  unsigned long long pf_fast = 0, pf_d0 = 0, pf_d1 = 0, pf_c2 = 0, pf_c3 = 0, pf_c4 = 0;
+#endif
   for (int rb = 1; rb <= R; rb += 64) {
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   const u32x4 dv = GP(const u32x4, c.rdesc)[min(rb + lane, R)];
@@ -930,11 +937,17 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
     doff += 256;
     int key[CB];
     bool two;
+#ifdef C3_PHASE_PROF
+    unsigned long long gen_t0 = 0; bool gen = false;
+#endif
     if (de.x & (1u << 20)) {
       // FAST ROW: the row above, band shift 0 or 1
       int vb8 = (de.x & 3) * 8;
       VREG(vb8);
       two = true;
+#ifdef C3_PHASE_PROF
+      ++pf_fast;
+#endif
       if (de.x & (1u << 22)) {
         lo += 1;
         const int hnext = wave_shl1(hcur[0], W_NEG16);                      // offset CB*lane + CB of the row above
@@ -952,6 +965,9 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
         }
       }
     } else {
+#ifdef C3_PHASE_PROF
+      gen_t0 = __builtin_readcyclecounter(); gen = true;
+#endif
       de.y = __builtin_amdgcn_readlane(dblk.y, li);
       de.z = __builtin_amdgcn_readlane(dblk.z, li);
       de.w = __builtin_amdgcn_readlane(dblk.w, li);
@@ -1057,8 +1073,15 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
         for (int cc = 0; cc < CB; ++cc) if (lo + lane * CB + cc == Q) GP(int, c.hend().ptr())[r] = __builtin_amdgcn_sbfe(hcur[cc], 2, 14);
       }
     }
+#ifdef C3_PHASE_PROF
+    if (gen) { const bool pm1 = (de.y & 0xffff) == (unsigned)(r - 1); pf_d0 += (1ull << 32) + (two && pm1); pf_d1 += 1 + ((unsigned long long)!two << 32);
+      const unsigned long long dt_ = __builtin_readcyclecounter() - gen_t0; if (!two) pf_c2 += dt_; else if (pm1) pf_c4 += dt_; else pf_c3 += dt_; }
+#endif
   }
   }
+#ifdef C3_PHASE_PROF
+  dbg[0] += pf_d0; dbg[1] += pf_d1 + pf_fast; dbg[2] += pf_c2; dbg[3] += pf_c3; dbg[4] += pf_c4;
+#endif
   WSYNC();
   return 0;
 }
@@ -1119,7 +1142,16 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
   const int span = end - begin + 1;
   int cb = R * 4 < span * 5 ? 2 : R * 2 < span * 3 ? 3 : 4;
   if (!*cb_io || cpl == 0 || need <= cb || span < 1 || max(P.pol_match, P.pol_mismatch) <= 0 || ring_off + wb_lds_dwords(Q, cb) > lds_ints) cb = 0;
+#ifdef C3_BAND_OFF
+  cb = 0;
+#endif
+#ifdef C3_PHASE_PROF
+  const unsigned long long bd_t0 = __builtin_readcyclecounter();
+#endif
   if (cb && !win_build_desc_band(c, R, Q, begin, end, blen, cb, lane, m2, ma, nblocks)) cb = 0;
+#ifdef C3_PHASE_PROF
+  dbg[5] += __builtin_readcyclecounter() - bd_t0;
+#endif
   *cb_io = cb;
   if (cb) {
     *cpl_out = cb; *rs_out = 256;
@@ -1130,7 +1162,13 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
     }
   }
   *cpl_out = cpl; *rs_out = cpl ? 64 * ((cpl + 3) & ~3) : need * 64;    // D row stride in bytes
+#ifdef C3_PHASE_PROF
+  const unsigned long long bd_t1 = __builtin_readcyclecounter();
+#endif
   win_build_desc(c, R, lane, m2, ma, cpl != 0);
+#ifdef C3_PHASE_PROF
+  dbg[5] += __builtin_readcyclecounter() - bd_t1;
+#endif
   switch (cpl) {
     case 2: return win_rows<2>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
     case 4: return win_rows<4>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
@@ -1374,7 +1412,7 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
           int nblocks = 0;
           if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, ring_off, lds_ints, l.begin, l.end, blen, &cb, &nblocks) < 0) { fail = 1; break; }
 #ifdef C3_PHASE_PROF
-          ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1]; ph_acc_[12] += dbg_[2]; ph_acc_[13] += dbg_[3]; ph_acc_[14] += dbg_[4]; ph_acc_[15] += dbg_[5];
+          ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1]; ph_acc_[15] += dbg_[5];
 #endif
           PH_MARK(3)
           cells_done += (long long)(R + 1) * (cb ? 64 * cb : Q + 1);
@@ -1385,6 +1423,9 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
           gbr = wave_min(bs == gbs ? br : INT32_MAX / 2);
           if (!cb) break;
           // banded rows: accepted only with the certificate that no path outside the band reaches the banded optimum
+#ifdef C3_EXP_NOCERT
+          if (cb) { ++n_band; break; }
+#endif
           if (gbs != INT32_MIN && win_band_cert(c, R, Q, cb, max(P.pol_match, P.pol_mismatch), P.pol_gap, gbs, nblocks, lane)) { ++n_band; break; }
           ++n_fallback; cb = 0;                                                // redo the layer with the full matrix
         }
@@ -1401,6 +1442,9 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
         // Banded rows (cb != 0) keep their cells by band OFFSET (column - lo(row)): cb cells per lane, one byte per lane in a
         // 2-bit row, 2 or 4 tag bytes per lane otherwise, rows 256 bytes apart.
         const WArr<int> rq = c.opq(), tq = c.opn();
+#ifdef C3_PHASE_PROF
+        unsigned long long tbc_[3] = {0, 0, 0};
+#endif
         {
           unsigned* WD = (unsigned*)(mabits + ((a.Ncap + 64) >> 6) + 1);       // [64][4] dwords, behind the row-type bitmasks
           const int cdiv = cpl ? (65536 + cpl - 1) / cpl : 0;                   // j / cpl == (j * cdiv) >> 16 for j < 2^13
@@ -1408,9 +1452,16 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
           const int dsb = cb ? (cb == 2 ? 2 : 4) : ((cpl + 3) & ~3);             // bytes per lane of a byte row
           const int ncol = cb ? 64 * cb : 1 << 20;                               // cells of a row
           int r = (gbs == INT32_MIN) ? 0 : gbr, j = Q;
+#ifdef C3_EXP_NOTB
+          for (int q = lane; q < Q; q += 64) rq[q] = min(q + 1, R);
+          r = 0; j = 0;
+#endif
           while (r > 0 || j > 0) {
             if (r == 0) { for (int q = lane; q < j; q += 64) rq[q] = 0; break; }
             if (j == 0) break;                                   // only vertical moves remain
+#ifdef C3_PHASE_PROF
+            tbc_[0]++;
+#endif
             const int rt = r, jt = j;
             const int rk = rt - lane;
             const bool rowv = rk >= 1;
@@ -1435,6 +1486,9 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
             }
             WSYNC();
             for (;;) {
+#ifdef C3_PHASE_PROF
+              tbc_[1]++;
+#endif
               const int s = rt - r;                               // lane s holds the current row
               const int jk = j - (lane - s);
               const int ok_ = jk - lok;                           // cell index inside the row
@@ -1463,6 +1517,9 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
               int db, pb;
               if (wave_bcast((int)hit, cl)) { db = wave_bcast(d, cl); pb = wave_bcast(prow, cl); }
               else {
+#ifdef C3_PHASE_PROF
+                tbc_[2]++;
+#endif
                 // outside the window (the path drifted off this block's diagonal): direct loads of the one cell
                 const bool two0 = (m2bits[(r - 1) >> 6] >> ((r - 1) & 63)) & 1;
                 const int o0 = cb ? min(max(j - (int)(c.rdesc[r].w & 0xffff), 0), ncol - 1) : j;
@@ -1492,6 +1549,9 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
         }
         WSYNC();
         PH_MARK(5)
+#ifdef C3_PHASE_PROF
+        ph_acc_[12] += tbc_[0]; ph_acc_[13] += tbc_[1]; ph_acc_[14] += tbc_[2];       // traceback census: blocks, steps, window misses (overrides the row-kind cycles)
+#endif
         // ---- fusion, parallel over the query bases (every graph node is touched by at most one base)
         const int n_old = c.n;
         int carry_anchor = -1, carry_new = 0;

@@ -195,3 +195,190 @@ def test_polish_layers_outvote_a_wrong_draft():
     out = O.determine_consensus([truth, truth, bad, truth, truth], [q, q, "5" * len(bad), q, q])
     assert out == truth
     assert synth.identity(O.determine_consensus([bad, truth, truth], ["5" * len(bad), q, q]), truth) > 0.995
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Window polish (racon / spoa semantics): independent brute force of the window DP.
+# The oracle's capture hook (oracle_py.win_capture) reports, per window alignment, the backbone, the layer (codes, begin,
+# end), the end score and the alignment path.  Everything else is rebuilt HERE, from the spec: the graph (fusing the
+# reported paths: match -> same node, mismatch -> the aligned sibling with that base or a new one, insertion -> new node),
+# spoa's sub-graph rule (depth-first from the end node over in-edges and aligned nodes, ids >= begin), and a textbook
+# UNBANDED global linear-gap sequence-to-DAG alignment (match 3, mismatch -5, gap -4).  The oracle's DP score must equal
+# the brute-force optimum, its path must be a walk of the graph that re-scores to that optimum, and the two graphs must
+# stay identical layer after layer.
+
+PM, PX, PG = 3, -5, -4
+
+
+class WinGraph:
+    def __init__(self, backbone):
+        self.base = [int(b) for b in backbone]
+        n = len(self.base)
+        self.preds = [[i - 1] if i else [] for i in range(n)]       # in first-traversal order
+        self.aligned = [[] for _ in range(n)]                        # mismatch siblings (one MSA column)
+
+    def add_node(self, b):
+        self.base.append(int(b)); self.preds.append([]); self.aligned.append([])
+        return len(self.base) - 1
+
+    def fuse(self, ops, query):
+        prev = None
+        for node, q in ops:
+            if q < 0:
+                continue
+            b = int(query[q])
+            if node >= 0:
+                col = [node] + self.aligned[node]
+                tgt = next((x for x in ([node] if self.base[node] == b else []) + [y for y in col if self.base[y] == b]), None)
+                if tgt is None:
+                    tgt = self.add_node(b)
+                    for y in col:
+                        self.aligned[y].append(tgt)
+                    self.aligned[tgt] = list(col)
+            else:
+                tgt = self.add_node(b)
+            if prev is not None and prev not in self.preds[tgt]:
+                self.preds[tgt].append(prev)
+            prev = tgt
+
+    def subgraph(self, begin, end):
+        """spoa Graph::Subgraph: depth-first from `end` over in-edges and aligned nodes, node ids >= begin"""
+        inside, stack = set(), [end]
+        while stack:
+            v = stack.pop()
+            if v in inside or v < begin:
+                continue
+            inside.add(v)
+            stack.extend(self.preds[v]); stack.extend(self.aligned[v])
+        return inside
+
+    def topo(self, nodes):
+        """any topological order of the induced sub-graph in which aligned nodes do not matter (Kahn)"""
+        nodes = set(nodes)
+        indeg = {v: sum(1 for u in self.preds[v] if u in nodes) for v in nodes}
+        succ = {v: [] for v in nodes}
+        for v in nodes:
+            for u in self.preds[v]:
+                if u in nodes:
+                    succ[u].append(v)
+        ready = sorted(v for v in nodes if indeg[v] == 0)
+        out = []
+        while ready:
+            v = ready.pop()
+            out.append(v)
+            for w in succ[v]:
+                indeg[w] -= 1
+                if indeg[w] == 0:
+                    ready.append(w)
+        assert len(out) == len(nodes)
+        return out, succ
+
+    def best_score(self, nodes, query):
+        """unbanded optimum of the global alignment of `query` against the induced sub-graph: the path may start at any node
+        without predecessor inside and must end at a node without successor inside"""
+        order, succ = self.topo(nodes)
+        nodes = set(nodes)
+        Q = len(query)
+        qa = np.asarray(query)
+        j = np.arange(Q + 1)
+        start = j * PG
+        H = {}
+        for v in order:
+            ps = [H[u] for u in self.preds[v] if u in nodes] or [start]
+            sub = np.where(qa == self.base[v], PM, PX)
+            key = np.full(Q + 1, NEG, dtype=np.int64)
+            for hp in ps:
+                key[1:] = np.maximum(key[1:], hp[:-1] + sub)
+                key = np.maximum(key, hp + PG)
+            H[v] = np.maximum.accumulate(key - PG * j) + PG * j
+        return max(int(H[v][Q]) for v in order if not succ[v])
+
+    def path_score(self, nodes, ops, query):
+        """re-score a reported path; checks that it is a walk of the sub-graph that consumes the whole query"""
+        nodes = set(nodes)
+        score, prev, nq = 0, None, 0
+        for node, q in ops:
+            if node >= 0:
+                assert node in nodes
+                if prev is None:
+                    assert not [u for u in self.preds[node] if u in nodes], "path does not start at a source"
+                else:
+                    assert prev in self.preds[node], "path uses an edge that does not exist"
+                prev = node
+            if q >= 0:
+                assert q == nq
+                nq += 1
+            score += (PM if self.base[node] == int(query[q]) else PX) if (node >= 0 and q >= 0) else PG
+        assert nq == len(query)
+        return score, prev
+
+
+def _check_windows(subs_quals, min_windows, front=None, tail=None):
+    O.win_capture(True)
+    try:
+        for subs, quals in subs_quals:
+            O.determine_consensus(subs, quals, front=front, tail=tail)
+        als = O.win_captured()
+    finally:
+        O.win_capture(False)
+    graphs, n_full, n_sub = {}, 0, 0
+    for a in als:
+        if a["layer"] == 0:
+            g = graphs[a["win"]] = WinGraph(a["base"][:a["blen"]])
+        g = graphs[a["win"]]
+        # the graph rebuilt from the reported paths is the graph the oracle aligned against
+        assert len(g.base) == a["n"] and g.base == [int(b) for b in a["base"]]
+        assert [sorted(p) for p in g.preds] == [sorted(p) for p in a["preds"]]
+        nodes = set(range(len(g.base))) if a["full"] else g.subgraph(a["begin"], a["end"])
+        assert nodes == set(int(v) for v in np.nonzero(a["mask"])[0]), "sub-graph rule"
+        q = a["query"]
+        opt = g.best_score(nodes, q)
+        assert a["score"] == opt, (a["win"], a["layer"], a["score"], opt)
+        ps, last = g.path_score(nodes, [(int(x), int(y)) for x, y in a["ops"]], q)
+        assert ps == opt and last == a["end_node"]
+        g.fuse([(int(x), int(y)) for x, y in a["ops"]], q)
+        n_full += a["full"]; n_sub += not a["full"]
+    assert n_full + n_sub >= min_windows
+    return n_full, n_sub
+
+
+def test_window_dp_against_an_unbanded_brute_force():
+    """full-span layers and sub-graph layers (dangling pieces, ragged subreads) of >= 30 window alignments: the oracle's score
+    is the unbanded optimum of an independently rebuilt graph, its path re-scores to it, spoa's sub-graph rule holds"""
+    rng = np.random.default_rng(77)
+    jobs = []
+    truth = "".join("ACGT"[i] for i in rng.integers(0, 4, 1080))
+    for n in (3, 4, 5):
+        subs = [_mut(rng, truth) for _ in range(n)]
+        jobs.append((subs, ["".join(chr(33 + int(x)) for x in rng.integers(6, 30, len(s))) for s in subs]))
+    n_full, n_sub = _check_windows(jobs, 12)
+    # dangling pieces and a subread that misses a chunk: layers that do not span their window -> sub-graph alignments
+    t2 = "".join("ACGT"[i] for i in rng.integers(0, 4, 560))
+    subs = [_mut(rng, t2), _mut(rng, t2[:200] + t2[260:]), _mut(rng, t2), _mut(rng, t2)]
+    quals = ["".join(chr(33 + int(x)) for x in rng.integers(6, 30, len(s))) for s in subs]
+    fr, tl = _mut(rng, t2[330:]), _mut(rng, t2[:240])
+    f2, s2 = _check_windows([(subs, quals)], 10, front=(fr, "5" * len(fr)), tail=(tl, "5" * len(tl)))
+    assert n_full + f2 >= 12 and n_sub + s2 >= 10, (n_full, n_sub, f2, s2)
+    assert n_full + n_sub + f2 + s2 >= 30
+
+
+def test_window_rules_copy_and_tgs_trim():
+    """racon's window rules on constructed cases: fewer than 3 sequences -> the window is copied and, with no
+    polished window at all, the target is dropped; TGS windows (mean layer length > 1000) are trimmed to the span covered by
+    at least (n-1)/2 layers"""
+    rng = np.random.default_rng(9)
+    t = "".join("ACGT"[i] for i in rng.integers(0, 4, 700))
+    q = "I" * len(t)
+    # one subread: backbone + 1 layer = 2 sequences per window -> nothing polished -> no consensus (racon without -u)
+    assert O.determine_consensus([t], [q]) == ""
+    # two subreads: 3 sequences per window -> polished
+    assert O.determine_consensus([t, t], [q, q]) == t
+    # TGS trim: five long layers (mean > 1000) of which only two reach the last 150 bases: the consensus ends where the
+    # coverage drops below (6 - 1) / 2 = 2 ... both still reach, so nothing is lost; with one reaching, the tail is trimmed
+    long_t = "".join("ACGT"[i] for i in rng.integers(0, 4, 1400))
+    ql = "I" * len(long_t)
+    full = O.determine_consensus([long_t] * 5, [ql] * 5)
+    assert full == long_t
+    short = long_t[:1250]
+    out = O.determine_consensus([long_t] + [short] * 4, [ql] + ["I" * len(short)] * 4)
+    assert out.startswith(long_t[:1000]) and len(out) < len(long_t) and synth.identity(out, short) > 0.98

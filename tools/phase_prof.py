@@ -35,5 +35,7 @@ for which, kn in ((0, "k_poa"), (1, "k_window")):
         far = gen - kept - multi
         print("   cycles per general row: several predecessors %.0f, one far predecessor %.0f, r-1 kept %.0f; all DP-row cycles / all rows = %.0f" % (
             out[12] / max(multi, 1), out[13] / max(far, 1), out[14] / max(kept, 1), out[3] / max(rows, 1)))
+    if which == 1:
+        print("   traceback census: blocks %d, steps %d, window misses %d; descriptor build = %.1f%% of the wave time (inside 'DP rows')" % (out[12], out[13], out[14], 100.0 * out[15] / tot))
     if which == 0 and out[1]:
         print("   DP rows by kind (cycles): fast %.1f%%, near %.1f%%, general %.1f%% of the row loop" % tuple(100.0 * out[i] / max(out[8] + out[10] + out[11], 1) for i in (8, 10, 11)))
