@@ -739,388 +739,15 @@ __device__ int win_rows_lin(WCtx& c, const C3Params& P, const uint32_t* pk, int 
   return 0;
 }
 
-// ------------------------------------------------------------------------------------------
-// BANDED rows (round 3).  A layer of ~500 bases against a window graph never leaves a narrow diagonal (measured on the
-// synthetic configs: +-8 columns around the column predicted from the backbone position), but the rows above fill all
-// Q + 1 columns.  Here a row computes only BW = 64 * CB columns [lo(r), lo(r) + BW) around its expected column
-//     c(r) = (bb(r) - begin + 1) * Q / (end - begin + 1),   bb(r) = highest backbone node among the rows <= r,
-// lane owns band offsets CB*lane .. CB*lane + CB - 1 (column = lo(r) + offset), and the band slides right as the rows go down.
-// EXACTNESS: cells outside the band count as -infinity, so the banded optimum S_b is the best score of the paths that stay
-// inside.  After the rows, win_band_cert proves (or fails to prove) that EVERY path with a cell outside the band scores
-// strictly less than S_b: such a path leaves the band for the first time at a band-edge cell X whose banded value bounds its
-// prefix, and the rest is bounded by the moves that are left (every remaining column scores at most `match`, a path that
-// is behind / ahead of the rows that remain must pay gaps).  Then the unbanded traceback path lies inside the band, the
-// banded values along it equal the unbanded ones and every tie is broken the same way -- the result is
-// bit-identical to the full matrix, which the oracle keeps filling.  A layer whose certificate fails is simply redone
-// by the unbanded rows above.
-//
-// Layout: hcur = row r-1 in ITS band coordinates; the fast row (one predecessor = the row above, band shift 0 or 1)
-// takes its diagonal / vertical neighbours from registers with one DPP move; every other predecessor comes from an LDS
-// ring of the last eight rows (slot r & 7, each slot carries its lo) or, further back, from 16-bit rows in global memory.
-// The per-column substitution table sits in LDS (the columns of a lane change from row to row).
-#define WB_PADL 4            /* shorts in front of cell 0 of a ring slot: [0..1] lo, [3] = -inf (offset -1) */
-#define WB_PADR 36           /* -inf shorts behind the last cell: a predecessor is read at offsets up to BW - 1 + WB_MAXSHIFT + CB */
-#define WB_MAXSHIFT 32       /* lo(row) - lo(predecessor) beyond this: the layer is not banded */
-#define WB_RING 8
-#define WB_EROW 16           /* shorts per row of band-edge cells kept for the certificate */
-__host__ __device__ __forceinline__ int wb_slot_shorts(int cb) { return WB_PADL + 64 * cb + WB_PADR; }
-__host__ __device__ __forceinline__ int wb_lds_dwords(int Q, int cb) { return ((Q + 2) & ~1) + WB_RING * wb_slot_shorts(cb) / 2; }
-// dynamic LDS of k_window: the consensus sweep arrays (Lcap scores + 16-bit predecessors) share it with the row-type bitmasks
-// followed by either the H ring of the unbanded rows (the traceback windows reuse it) or the banded rows' substitution table
-// (up to 640 columns) and ring (sized for the widest band)
+// dynamic LDS of k_window: the consensus sweep arrays (Lcap scores + 16-bit predecessors) share it with four row bitmasks
+// (row kinds, band shifts) followed by either the H ring of the unbanded rows (the traceback windows reuse it) or the banded
+// rows' substitution table (up to 640 columns), ring and edge cells (sized for the widest band)
+#include "k_polish_band.h"
+__host__ __device__ __forceinline__ int win_mask_words(int Ncap) { return ((Ncap + 64) >> 6) + 1; }
 __host__ __device__ __forceinline__ size_t win_lds_bytes(int Lcap, int Ncap) {
-  const size_t masks = (size_t)16 * (((Ncap + 64) >> 6) + 1);
+  const size_t masks = (size_t)32 * win_mask_words(Ncap);
   const size_t a = (size_t)Lcap * 6 + 16, b = masks + 4 * 5 * 64 * 4 + 64, c = masks + 4 * (size_t)wb_lds_dwords(639, 4);
   return (a > b ? (a > c ? a : c) : (b > c ? b : c));
-}
-__device__ __forceinline__ int wb_left(int cb) { return cb == 2 ? 70 : cb == 3 ? 105 : 140; }     // columns left of the centre (the rest, 57 / 86 / 115, right)
-
-// descriptors of the banded rows.  x = base | np<<8 | ovf<<16 | far<<17 | isend<<18 | two<<19 | fast<<20 | shift<<22 (fast rows: 0/1)
-// | wr<<23 | virt<<24;  y, z = predecessor rows as above;  w = lo | leftspan<<16.
-//   far:  some successor is more than WB_RING rows ahead -> the H row also goes to global memory
-//   wr:   some successor will read the row from the LDS ring (i.e. is not the fast row right below)
-//   virt: no masked predecessor (the row hangs off the virtual start row)
-//   leftspan = max over successors of lo(successor) - lo(row): the row's first `leftspan` cells have successors whose band
-//              starts to their right (a path can leave the band there)
-// lob[r] = lo | (number of aligned blocks among rows 1..r) << 16.  Returns 0 when the layer cannot be banded.
-__device__ int win_build_desc_band(WCtx& c, int R, int Q, int begin, int end, int blen, int CB, int lane,
-                                   unsigned long long* m2, unsigned long long* ma, int* nblocks) {
-  const int BW = 64 * CB, WLf = wb_left(CB), span = end - begin + 1, lomax = Q + 1 - BW;
-  const WArr<int> lob = c.lob();
-  int bbc = begin - 1, loc = 0, nbc = 0, gprev = -1;
-  for (int r0 = 1; r0 <= R; r0 += 64) {
-    const int r = r0 + lane;
-    const bool live = r <= R;
-    const int v = live ? c.rows()[r] : 0;
-    // backbone position reached so far -> band start (non-decreasing)
-    const int bbs = max(wave_scan_max(live && v < blen ? v : -1), bbc);
-    bbc = wave_bcast(bbs, 63);
-    const int cen = (int)(((long long)(bbs - begin + 1) * Q + span / 2) / span);
-    const int lo = min(max(cen - WLf, 0), lomax);
-    const int lop = wave_shr1(lo, loc);                               // lo of the row above
-    loc = wave_bcast(lo, 63);
-    // aligned blocks: runs of equal group ids in the row order
-    const int gr = live ? c.grp()[v] : -2;
-    const int grp_ = wave_shr1(gr, gprev);
-    gprev = wave_bcast(gr, 63);
-    const unsigned long long bs = __ballot(live && gr != grp_);
-    const int bidx = nbc + __popcll(bs & ((2ull << lane) - 1));
-    nbc += __popcll(bs);
-    bool two = false, adj = false;
-    if (live) {
-      const int nin = c.n_in()[v];
-      unsigned p[4] = {0, 0, 0, 0};
-      int np = 0;
-      for (int k = 0; k < nin; ++k) {
-        const int pr = c.rowof()[c.in_from()[EI(v, k)]];
-        if (pr < 0) continue;
-        if (np < 4) p[np] = (unsigned)pr;
-        ++np;
-      }
-      unsigned has = 0, far = 0;
-      for (int k = 0; k < c.n_out()[v]; ++k) {
-        const int sr = c.rowof()[c.out_to()[EI(v, k)]];
-        if (sr >= 0) { has = 1; if (sr - r > WB_RING) far = 1; }
-      }
-      const unsigned ovf = np > 4, virt = np == 0;
-      if (np == 0) np = 1;
-      two = np == 1;
-      adj = two && (int)p[0] == r - 1;
-      const int dl = lo - lop;
-      const unsigned fast = adj && !far && has && dl <= 1;
-      uint4 d; d.x = (unsigned)c.base()[v] | ((unsigned)min(np, 255) << 8) | (ovf << 16) | (far << 17) | ((has ^ 1u) << 18) | ((unsigned)two << 19) | (fast << 20)
-                     | ((unsigned)(fast ? dl : 0) << 22) | (virt << 24);
-      d.y = p[0] | (p[1] << 16); d.z = p[2] | (p[3] << 16); d.w = (unsigned)lo;
-      c.rdesc[r] = d;
-      c.hend()[r] = INT32_MIN;
-      lob[r] = lo | (bidx << 16);
-    }
-    const unsigned long long b2 = __ballot(two), ba = __ballot(adj);
-    if (lane == 0) { m2[r0 >> 6] = b2; ma[r0 >> 6] = ba; }
-  }
-  if (lane == 0) lob[0] = 0;
-  *nblocks = nbc;
-  WSYNC();
-  // second pass: what depends on the neighbours' band starts and row kinds
-  int bad = 0;
-  for (int r = 1 + lane; r <= R; r += 64) {
-    const unsigned dx = ((const unsigned*)(c.rdesc + r))[0];
-    const int v = c.rows()[r], lo = lob[r] & 0xffff;
-    int ls = 0; unsigned wr = 0;
-    for (int k = 0; k < c.n_out()[v]; ++k) {
-      const int sr = c.rowof()[c.out_to()[EI(v, k)]];
-      if (sr < 0) continue;
-      ls = max(ls, (lob[sr] & 0xffff) - lo);
-      const unsigned sx = ((const unsigned*)(c.rdesc + sr))[0];
-      if (!(((sx >> 20) & 1) && sr == r + 1)) wr = 1;
-    }
-    for (int k = 0; k < c.n_in()[v]; ++k) {
-      const int pr = c.rowof()[c.in_from()[EI(v, k)]];
-      if (pr >= 0 && lo - (lob[pr] & 0xffff) > WB_MAXSHIFT) bad = 1;
-    }
-    if (ls > 2 * CB || ls > 255) bad = 1;                             // only the first 2*CB cells of a row are kept for the certificate
-    ((unsigned*)(c.rdesc + r))[0] = dx | (wr << 23);
-    ((unsigned*)(c.rdesc + r))[3] = (unsigned)lo | ((unsigned)min(ls, 255) << 16);
-  }
-  bad = __ballot(bad) != 0;
-  WSYNC();
-  return !bad;
-}
-
-template <int CB>
-__device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t* cH, uint8_t* cD, uint4* crdesc, int cK, int cn, int cNcap, long long chcap,
-                                                       int mt_, int mm_, int g_, const uint32_t* pk_, int qbeg_, int Q_, int R_, unsigned long long* dbg_, int lds_off_) {
-  WCtx c;
-  c.I = uni_ptr(cI); c.E = uni_ptr(cE); c.B8 = nullptr; c.score = nullptr; c.H = uni_ptr(cH); c.D = uni_ptr(cD);
-  c.rdesc = uni_ptr(crdesc); c.K = uni32(cK); c.n = uni32(cn); c.Ncap = uni32(cNcap);
-  c.hcap = ((long long)uni32((int)(chcap >> 32)) << 32) | (unsigned)uni32((int)chcap);
-  const uint32_t* pk = uni_ptr(pk_);
-  unsigned long long* dbg = uni_ptr(dbg_);
-  const int qbeg = uni32(qbeg_), Q = uni32(Q_), R = uni32(R_);
-  const int lane = wave_lane();
-  extern __shared__ int lds_dyn[];
-  constexpr int BW = 64 * CB, SLOT = WB_PADL + BW + WB_PADR /* shorts */, HS = BW + 8 /* shorts of a global H row: [0..1] lo, [4..] cells */;
-  unsigned* tbl = (unsigned*)lds_dyn + uni32(lds_off_);                      // [Q + 1] substitution bytes per column
-  unsigned short* ring = (unsigned short*)(tbl + ((Q + 2) & ~1));
-  struct { int pol_match, pol_mismatch, pol_gap; } P = {uni32(mt_), uni32(mm_), uni32(g_)};
-  const int K = c.K;
-  // D rows are 256 bytes apart (one byte per lane for 2-bit rows, CB <= 4 tag bytes per lane otherwise); H rows and the
-  // edge cells share the H scratch
-  if ((long long)(R + 1) * 256 > c.hcap || (long long)(R + 1) * (HS * 2 + WB_EROW * 2) + 64 > c.hcap * 4 || R >= 65535) return -1;
-  unsigned short* const H16 = (unsigned short*)c.H;
-  unsigned short* const E16 = (unsigned short*)((char*)c.H + (((size_t)(R + 1) * HS * 2 + 31) & ~(size_t)31));
-  const int mt3 = P.pol_match * 4 + 3, mm3 = P.pol_mismatch * 4 + 3, g4 = P.pol_gap * 4;
-  const int mm3x4 = (mm3 & 255) * 0x01010101;
-  for (int j = lane; j <= Q; j += 64) {
-    const int qc = j >= 1 ? c3_code_at(pk, qbeg + j - 1) : 7;
-    tbl[j] = qc < 4 ? (mm3x4 & ~(255 << (8 * qc))) | ((mt3 & 255) << (8 * qc)) : mm3x4;
-  }
-  for (int i = lane; i < WB_RING * (WB_PADR + 1); i += 64) {               // the -inf cells around every ring slot
-    const int sl = i / (WB_PADR + 1), k = i % (WB_PADR + 1);
-    ring[sl * SLOT + (k == 0 ? WB_PADL - 1 : WB_PADL + BW + k - 1)] = (unsigned short)W_NEG16;
-  }
-  int hcur[CB], g41[CB];
-#pragma unroll
-  for (int cc = 0; cc < CB; ++cc) {
-    const int b = lane * CB + cc;
-    hcur[cc] = b * g4;                                                      // virtual row 0, lo = 0
-    g41[cc] = b * g4 + 1;                                                   // horizontal candidate = 4 * (best y + g * offset) + 1 (the band start cancels inside a row)
-  }
-  int cV = g4 + 2;
-  VREG(cV);
-  WSYNC();
-  const unsigned* tp = tbl + CB * lane;
-  int lo = 0;                                                               // band start of the row in hcur
-  unsigned doff = (unsigned)lane;                                           // byte offset of this lane's 2-bit cells in D row r (+ 256 per row)
-  const unsigned eidx = lane < 2 ? (unsigned)(lane * CB) : (unsigned)(WB_EROW - CB);
-  const bool elane = lane < 2 || lane == 63;
-  if (elane) {                                                               // edge cells of the virtual row
-#pragma unroll
-    for (int cc = 0; cc < CB; ++cc) E16[eidx + cc] = (unsigned short)hcur[cc];
-  }
-#ifdef C3_EXP_NOROWS
-  if (R > 0) return 0;
-#endif
-#ifdef C3_PHASE_PROF
-  unsigned long long pf_fast = 0, pf_d0 = 0, pf_d1 = 0, pf_c2 = 0, pf_c3 = 0, pf_c4 = 0;
-#endif
-  for (int rb = 1; rb <= R; rb += 64) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  const u32x4 dv = GP(const u32x4, c.rdesc)[min(rb + lane, R)];
-  uint4 dblk = make_uint4(dv.x, dv.y, dv.z, dv.w);
-  asm volatile("" : "+v"(dblk.x), "+v"(dblk.y), "+v"(dblk.z), "+v"(dblk.w));
-  const int cnt = min(64, R - rb + 1);
-  for (int li = 0; li < cnt; ++li) {
-    const int r = rb + li;
-    uint4 de;
-    de.x = __builtin_amdgcn_readlane(dblk.x, li);
-    doff += 256;
-    int key[CB];
-    bool two;
-#ifdef C3_PHASE_PROF
-    unsigned long long gen_t0 = 0; bool gen = false;
-#endif
-    if (de.x & (1u << 20)) {
-      // FAST ROW: the row above, band shift 0 or 1
-      int vb8 = (de.x & 3) * 8;
-      VREG(vb8);
-      two = true;
-#ifdef C3_PHASE_PROF
-      ++pf_fast;
-#endif
-      if (de.x & (1u << 22)) {
-        lo += 1;
-        const int hnext = wave_shl1(hcur[0], W_NEG16);                      // offset CB*lane + CB of the row above
-#pragma unroll
-        for (int cc = 0; cc < CB; ++cc) {
-          const int hv = cc + 1 < CB ? hcur[cc + 1 < CB ? cc + 1 : cc] : hnext;
-          key[cc] = max16(hcur[cc] + __builtin_amdgcn_sbfe((int)tp[lo + cc], vb8, 8), hv + cV);
-        }
-      } else {
-        const int hleft = wave_shr1(hcur[CB - 1], W_NEG16);
-#pragma unroll
-        for (int cc = 0; cc < CB; ++cc) {
-          const int hd = cc == 0 ? hleft : hcur[cc > 0 ? cc - 1 : 0];
-          key[cc] = max16(hd + __builtin_amdgcn_sbfe((int)tp[lo + cc], vb8, 8), hcur[cc] + cV);
-        }
-      }
-    } else {
-#ifdef C3_PHASE_PROF
-      gen_t0 = __builtin_readcyclecounter(); gen = true;
-#endif
-      de.y = __builtin_amdgcn_readlane(dblk.y, li);
-      de.z = __builtin_amdgcn_readlane(dblk.z, li);
-      de.w = __builtin_amdgcn_readlane(dblk.w, li);
-      const int np = (de.x >> 8) & 0xff;
-      const bool ovf = (de.x >> 16) & 1;
-      two = (de.x >> 19) & 1;
-      if (np > 64) return -1;
-      lo = (int)(de.w & 0xffff);
-      int vb8 = (de.x & 3) * 8;
-      VREG(vb8);
-      int tv[CB];
-#pragma unroll
-      for (int cc = 0; cc < CB; ++cc) tv[cc] = __builtin_amdgcn_sbfe((int)tp[lo + cc], vb8, 8);
-      int kedge = 0;
-      for (int t = 0; t < np; ++t) {
-        int prow;
-        if ((de.x >> 24) & 1) prow = 0;
-        else if (!ovf) prow = (t == 0) ? (de.y & 0xffff) : (t == 1) ? (de.y >> 16) : (t == 2) ? (de.z & 0xffff) : (de.z >> 16);
-        else {
-          const int v = GP(const int, c.rows().ptr())[r];
-          prow = -1;
-          while (kedge < GP(const int, c.n_in().ptr())[v]) { int pr = GP(const int, c.rowof().ptr())[GP(const int, c.in_from().ptr())[EI(v, kedge)]]; ++kedge; if (pr >= 0) { prow = pr; break; } }
-          if (prow < 0) break;
-        }
-        int hpv[CB + 1];                                                     // H[prow][lo + CB*lane - 1 + k]
-        if (prow == 0) {                                                     // the virtual start row: H[0][j] = j * gap
-          const int b0 = (lo + CB * lane - 1) * g4;
-#pragma unroll
-          for (int k = 0; k <= CB; ++k) hpv[k] = b0 + k * g4;
-          if (lo + CB * lane == 0) hpv[0] = W_NEG16;
-        } else if (r - prow <= WB_RING) {
-          const unsigned short* sp_ = ring + (prow & (WB_RING - 1)) * SLOT;
-          const int sh = lo - *(const int*)sp_;
-          const unsigned short* cp = sp_ + (WB_PADL - 1) + CB * lane + sh;
-#pragma unroll
-          for (int k = 0; k <= CB; ++k) hpv[k] = (int)cp[k];
-        } else {
-          const auto* hp_ = GP(const unsigned short, H16) + (size_t)prow * HS;
-          const int sh = lo - (int)((unsigned)hp_[0] | ((unsigned)hp_[1] << 16));
-#pragma unroll
-          for (int k = 0; k <= CB; ++k) { const int ix = CB * lane + sh - 1 + k; hpv[k] = (ix >= 0 && ix < BW) ? (int)hp_[WB_PADL + ix] : W_NEG16; }
-        }
-        if (t == 0) {
-#pragma unroll
-          for (int cc = 0; cc < CB; ++cc) key[cc] = max16(hpv[cc] + tv[cc], hpv[cc + 1] + cV);
-        } else {
-          const int tmark = t << 16;
-#pragma unroll
-          for (int cc = 0; cc < CB; ++cc) {
-            const int nk = max16(key[cc], max16(hpv[cc] + tv[cc], hpv[cc + 1] + cV));
-            key[cc] = nk != (key[cc] & 0xffff) ? (nk | tmark) : key[cc];
-          }
-        }
-      }
-    }
-    // horizontal gap inside the band: in-lane prefix + one cross-lane max-scan over y = H - g * offset
-    int run = W_NEG16;
-#pragma unroll
-    for (int cc = 0; cc < CB; ++cc) run = max16(run, key[cc] - g41[cc]);
-    int ex = wave_shr1(wave_scan_max(__builtin_amdgcn_sbfe(run, 0, 16)), W_NEG16);
-    if (two) {
-      unsigned w2 = 0;
-#pragma unroll
-      for (int cc = 0; cc < CB; ++cc) {
-        const int k2 = max16(key[cc], (ex & ~3) + g41[cc]);
-        ex = max16(ex, key[cc] - g41[cc]);
-        hcur[cc] = k2 & ~3;
-        w2 |= ((unsigned)k2 & 3u) << (2 * cc);
-      }
-      *GP(unsigned char, c.D + doff) = (unsigned char)w2;
-    } else {
-      unsigned dpk = 0;
-#pragma unroll
-      for (int cc = 0; cc < CB; ++cc) {
-        const int k2 = max16(key[cc], (ex & ~3) + g41[cc]);
-        ex = max16(ex, key[cc] - g41[cc]);
-        hcur[cc] = k2 & ~3;
-        const unsigned tag = (((unsigned)k2 & 3u) << 6) + 63u - (((unsigned)key[cc] >> 16) & 63u);
-        dpk |= tag << (8 * cc);
-      }
-      if (CB == 2) GP(unsigned short, c.D + (size_t)r * 256)[lane] = (unsigned short)dpk;
-      else GP(unsigned, c.D + (size_t)r * 256)[lane] = dpk;
-    }
-    if (elane) {
-#pragma unroll
-      for (int cc = 0; cc < CB; ++cc) GP(unsigned short, E16)[(unsigned)r * WB_EROW + eidx + cc] = (unsigned short)hcur[cc];
-    }
-    if (de.x & (1u << 23)) {                                                 // a later row reads this one from the ring
-      unsigned short* sp_ = ring + (r & (WB_RING - 1)) * SLOT;
-      *(int*)sp_ = lo;
-#pragma unroll
-      for (int cc = 0; cc < CB; ++cc) sp_[WB_PADL + CB * lane + cc] = (unsigned short)hcur[cc];
-    }
-    if (de.x & ((1u << 17) | (1u << 18))) {
-      if ((de.x >> 17) & 1) {
-        auto* hrow = GP(unsigned short, H16) + (size_t)r * HS;
-        hrow[0] = (unsigned short)lo; hrow[1] = (unsigned short)((unsigned)lo >> 16);
-#pragma unroll
-        for (int cc = 0; cc < CB; ++cc) hrow[WB_PADL + CB * lane + cc] = (unsigned short)hcur[cc];
-      }
-      if ((de.x >> 18) & 1) {
-#pragma unroll
-        for (int cc = 0; cc < CB; ++cc) if (lo + lane * CB + cc == Q) GP(int, c.hend().ptr())[r] = __builtin_amdgcn_sbfe(hcur[cc], 2, 14);
-      }
-    }
-#ifdef C3_PHASE_PROF
-    if (gen) { const bool pm1 = (de.y & 0xffff) == (unsigned)(r - 1); pf_d0 += (1ull << 32) + (two && pm1); pf_d1 += 1 + ((unsigned long long)!two << 32);
-      const unsigned long long dt_ = __builtin_readcyclecounter() - gen_t0; if (!two) pf_c2 += dt_; else if (pm1) pf_c4 += dt_; else pf_c3 += dt_; }
-#endif
-  }
-  }
-#ifdef C3_PHASE_PROF
-  dbg[0] += pf_d0; dbg[1] += pf_d1 + pf_fast; dbg[2] += pf_c2; dbg[3] += pf_c3; dbg[4] += pf_c4;
-#endif
-  WSYNC();
-  return 0;
-}
-
-// The certificate of a banded layer (see above): true when every path with a cell outside the band scores strictly below
-// the banded optimum `sb`.  E = the band-edge cells the rows kept: per row the first 2*CB cells and the last one.
-//   right exit (any row whose band ends before column Q; the path moves right out of the last cell):
-//       H[r][hi] + ups * (Q - hi)                                     -- every remaining column scores at most ups
-//   left exit (rows with a successor whose band starts further right; cells lo .. lo + leftspan - 1):
-//       H[r][j] + ups * min(rem, nb) + gap * max(0, rem - nb),  rem = Q - j, nb = aligned blocks behind the row's block
-//       -- a path visits at most one node per aligned block, so at most nb more diagonal moves; the other columns are gaps
-//   rows hanging off the virtual start row whose band does not start at column 0: the same bound from cell (0, 0).
-__device__ bool win_band_cert(WCtx& c, int R, int Q, int CB, int ups, int gap, int sb, int nblocks, int lane) {
-  const int BW = 64 * CB, HS = BW + 8;
-  const unsigned short* E16 = (const unsigned short*)((const char*)c.H + (((size_t)(R + 1) * HS * 2 + 31) & ~(size_t)31));
-  const WArr<int> lob = c.lob();
-  int best = INT32_MIN;
-  for (int r = lane; r <= R; r += 64) {
-    const unsigned short* e = E16 + (size_t)r * WB_EROW;
-    unsigned dx = 0, dw = 0;
-    int lo = 0, nb = nblocks, ls = 0;
-    bool has = true;
-    if (r > 0) {
-      dx = ((const unsigned*)(c.rdesc + r))[0]; dw = ((const unsigned*)(c.rdesc + r))[3];
-      lo = (int)(dw & 0xffff); ls = (int)((dw >> 16) & 0xff); nb = nblocks - (lob[r] >> 16);
-      has = !((dx >> 18) & 1);
-      if (((dx >> 24) & 1) && lo > 0) best = max(best, ups * min(Q, nb + 1) + gap * max(0, Q - nb - 1));      // entered from (0, j), j < lo
-    }
-    const int hi = lo + BW - 1;
-    if (hi < Q) best = max(best, ((int)(short)e[WB_EROW - 1] >> 2) + ups * (Q - hi));
-    if (has && r > 0) {
-      for (int b = 0; b < ls; ++b) {
-        const int rem = Q - lo - b;
-        best = max(best, ((int)(short)e[b] >> 2) + ups * min(rem, nb) + gap * max(0, rem - nb));
-      }
-    }
-  }
-  best = wave_max(best);
-  return best < sb;
 }
 
 // byte index of column j inside a D row for the layout chosen by win_rows_dispatch
@@ -1128,27 +755,35 @@ __device__ __forceinline__ int win_idx(int j, int cpl) { return cpl ? (j / cpl) 
 
 // cb_io: in = banding allowed, out = cells per lane of the band chosen (0 = the unbanded rows ran)
 __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane, int* cpl_out, int* rs_out, unsigned long long* dbg,
-                                 unsigned long long* m2, unsigned long long* ma, int ring_off, int lds_ints, int begin, int end, int blen, int* cb_io, int* nblocks) {
+                                 unsigned long long* m2, unsigned long long* ma, unsigned long long* d0, unsigned long long* d1, int ring_off, int lds_ints, int begin, int end, int blen, int* cb_io, int* nblocks) {
   const int need = (Q + 1 + 63) / 64;
   int cpl;
   // 16-bit keys (score * 4 + type) of the register-blocked rows: |score| <= pm * max(R, Q), |score - g * j| <= (match + |g|) * Q,
   // and the substitution scores live in signed bytes
   const int pm = max(max(abs(P.pol_match), abs(P.pol_mismatch)), abs(P.pol_gap));
-  if (4 * pm * (max(R, Q) + 4) >= 31000 || 4 * (abs(P.pol_match) + abs(P.pol_gap)) * (Q + 4) >= 31000 || pm > 30 || P.pol_gap >= 0) cpl = 0;
+  const bool ok16 = !(4 * pm * (max(R, Q) + 4) >= 31000 || 4 * (abs(P.pol_match) + abs(P.pol_gap)) * (Q + 4) >= 31000 || pm > 30 || P.pol_gap >= 0);
+  if (!ok16) cpl = 0;
+#ifdef C3_EXP_NOWIDE
+  else if (need <= 2) cpl = 2; else if (need <= 4) cpl = 4; else cpl = 0;
+#else
   else if (need <= 2) cpl = 2; else if (need <= 4) cpl = 4; else if (need <= 6) cpl = 6; else if (need <= 8) cpl = 8;
   else if (need <= 10) cpl = 10; else cpl = 0;
+#endif
   // band width by the inflation of the graph (rows per backbone position of the layer): the more alternative nodes, the
   // weaker the certificate's bounds and the wider the band it needs (tools/band_model.py)
   const int span = end - begin + 1;
   int cb = R * 4 < span * 5 ? 2 : R * 2 < span * 3 ? 3 : 4;
-  if (!*cb_io || cpl == 0 || need <= cb || span < 1 || max(P.pol_match, P.pol_mismatch) <= 0 || ring_off + wb_lds_dwords(Q, cb) > lds_ints) cb = 0;
+  if (!*cb_io || !ok16 || need > 10 || need <= cb || span < 1 || max(P.pol_match, P.pol_mismatch) <= 0 || ring_off + wb_lds_dwords(Q, cb) > lds_ints) cb = 0;
 #ifdef C3_BAND_OFF
   cb = 0;
 #endif
 #ifdef C3_PHASE_PROF
   const unsigned long long bd_t0 = __builtin_readcyclecounter();
 #endif
-  if (cb && !win_build_desc_band(c, R, Q, begin, end, blen, cb, lane, m2, ma, nblocks)) cb = 0;
+  if (cb && !win_build_desc_band(c, R, Q, begin, end, blen, cb, lane, m2, ma, d0, d1, nblocks)) cb = 0;
+#ifdef C3_EXP_X2_DESC
+  if (cb && !win_build_desc_band(c, R, Q, begin, end, blen, cb, lane, m2, ma, d0, d1, nblocks)) cb = 0;
+#endif
 #ifdef C3_PHASE_PROF
   dbg[5] += __builtin_readcyclecounter() - bd_t0;
 #endif
@@ -1156,9 +791,21 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
   if (cb) {
     *cpl_out = cb; *rs_out = 256;
     switch (cb) {
-      case 2: return win_rows_band<2>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
-      case 3: return win_rows_band<3>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
-      default: return win_rows_band<4>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+      case 2: {
+#ifdef C3_EXP_X2_ROWS
+        win_rows_band<2>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks);
+#endif
+        return win_rows_band<2>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); }
+      case 3: {
+#ifdef C3_EXP_X2_ROWS
+        win_rows_band<3>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks);
+#endif
+        return win_rows_band<3>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); }
+      default: {
+#ifdef C3_EXP_X2_ROWS
+        win_rows_band<4>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks);
+#endif
+        return win_rows_band<4>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); }
     }
   }
   *cpl_out = cpl; *rs_out = cpl ? 64 * ((cpl + 3) & ~3) : need * 64;    // D row stride in bytes
@@ -1172,9 +819,11 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
   switch (cpl) {
     case 2: return win_rows<2>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
     case 4: return win_rows<4>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+#ifndef C3_EXP_NOWIDE
     case 6: return win_rows<6>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
     case 8: return win_rows<8>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
     case 10: return win_rows<10>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+#endif
     default: return win_rows_lin(c, P, pk, qbeg, Q, R, lane);
   }
 }
@@ -1302,7 +951,10 @@ __device__ __forceinline__ int win_consensus(WCtx& c, int* s_score, unsigned sho
 // 38 spilled outside the row loops) 86.9 ms per 32768 cfg2 reads; with the LDS sweep sized for 2*WL+30*NL nodes (6.9 KB
 // per wave, larger graphs fall back to global scratch) 5 waves/SIMD run 65.5 ms against 72.2 ms; 6 waves spill into the
 // row loops (76 ms).
-__global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
+#ifndef C3_WIN_WAVES
+#define C3_WIN_WAVES 5
+#endif
+__global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
   const int lane = wave_lane();
   const int slot = blockIdx.x;
   WCtx c;
@@ -1315,7 +967,9 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
   extern __shared__ int lds_dyn[];                      // [Ncap] scores + [Ncap] u16 predecessors
   int* s_score = lds_dyn; unsigned short* s_pred = (unsigned short*)(lds_dyn + a.Lcap);
   // the same LDS holds the row-type bitmasks of the layer being aligned (DP rows + traceback; the consensus sweep comes later)
-  unsigned long long* m2bits = (unsigned long long*)lds_dyn; unsigned long long* mabits = m2bits + ((a.Ncap + 64) >> 6) + 1;
+  const int MW = win_mask_words(a.Ncap);
+  unsigned long long* m2bits = (unsigned long long*)lds_dyn; unsigned long long* mabits = m2bits + MW;
+  unsigned long long* d0bits = mabits + MW; unsigned long long* d1bits = d0bits + MW;         // band shift bits of every DP row (banded layers)
   const int lds_ints = (int)(win_lds_bytes(a.Lcap, a.Ncap) / 4);    // = the launch's dynamic LDS
   PH_DECL
 
@@ -1406,11 +1060,11 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
         WSYNC();
         PH_MARK(2)
         int cpl = 0, RS = 0, cb = 1, gbs = INT32_MIN, gbr = 0;
-        const int ring_off = 4 * (((a.Ncap + 64) >> 6) + 1);                  // LDS behind the two row-type bitmasks, in dwords
+        const int ring_off = 8 * MW;                                          // LDS behind the four row bitmasks, in dwords
         for (int attempt = 0; attempt < 2; ++attempt) {
           unsigned long long dbg_[6] = {0, 0, 0, 0, 0, 0};
           int nblocks = 0;
-          if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, ring_off, lds_ints, l.begin, l.end, blen, &cb, &nblocks) < 0) { fail = 1; break; }
+          if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, d0bits, d1bits, ring_off, lds_ints, l.begin, l.end, blen, &cb, &nblocks) < 0) { fail = 1; break; }
 #ifdef C3_PHASE_PROF
           ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1]; ph_acc_[15] += dbg_[5];
 #endif
@@ -1423,10 +1077,11 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
           gbr = wave_min(bs == gbs ? br : INT32_MAX / 2);
           if (!cb) break;
           // banded rows: accepted only with the certificate that no path outside the band reaches the banded optimum
+          // (the rows left the bound of every such path in hend[0])
 #ifdef C3_EXP_NOCERT
           if (cb) { ++n_band; break; }
 #endif
-          if (gbs != INT32_MIN && win_band_cert(c, R, Q, cb, max(P.pol_match, P.pol_mismatch), P.pol_gap, gbs, nblocks, lane)) { ++n_band; break; }
+          if (gbs != INT32_MIN && c.hend()[0] < gbs) { ++n_band; break; }
           ++n_fallback; cb = 0;                                                // redo the layer with the full matrix
         }
         if (fail) break;
@@ -1439,29 +1094,23 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
         // LDS read: the wave checks 64 cells down the diagonal at once ("diagonal move from the row above"?), consumes the
         // run, and resolves the cell that breaks it.  One memory round trip per 64 rows instead of one per break -- and
         // the traceback no longer fetches about as many bytes as the fill wrote.
-        // Banded rows (cb != 0) keep their cells by band OFFSET (column - lo(row)): cb cells per lane, one byte per lane in a
-        // 2-bit row, 2 or 4 tag bytes per lane otherwise, rows 256 bytes apart.
         const WArr<int> rq = c.opq(), tq = c.opn();
 #ifdef C3_PHASE_PROF
         unsigned long long tbc_[3] = {0, 0, 0};
 #endif
-        {
-          unsigned* WD = (unsigned*)(mabits + ((a.Ncap + 64) >> 6) + 1);       // [64][4] dwords, behind the row-type bitmasks
-          const int cdiv = cpl ? (65536 + cpl - 1) / cpl : 0;                   // j / cpl == (j * cdiv) >> 16 for j < 2^13
-          const int tb = cb ? 1 : cpl <= 8 ? 2 : 4;                              // bytes per lane of a 2-bit row
-          const int dsb = cb ? (cb == 2 ? 2 : 4) : ((cpl + 3) & ~3);             // bytes per lane of a byte row
-          const int ncol = cb ? 64 * cb : 1 << 20;                               // cells of a row
-          int r = (gbs == INT32_MIN) ? 0 : gbr, j = Q;
-#ifdef C3_EXP_NOTB
-          for (int q = lane; q < Q; q += 64) rq[q] = min(q + 1, R);
-          r = 0; j = 0;
+#ifdef C3_EXP_X2_TB
+        for (int tbrep = 0; tbrep < 2; ++tbrep)
 #endif
+        if (cb) win_traceback_band(c, cb, R, Q, (gbs == INT32_MIN) ? 0 : gbr, m2bits, mabits, d0bits, d1bits, (unsigned*)lds_dyn + ring_off, rq, lane);
+        else
+        {
+          unsigned* WD = (unsigned*)lds_dyn + ring_off;       // [64][4] dwords, behind the row-type bitmasks
+          const int cdiv = cpl ? (65536 + cpl - 1) / cpl : 0;                   // j / cpl == (j * cdiv) >> 16 for j < 2^13
+          const int tb = cpl <= 8 ? 2 : 4;                                       // bytes per lane of a 2-bit row
+          int r = (gbs == INT32_MIN) ? 0 : gbr, j = Q;
           while (r > 0 || j > 0) {
             if (r == 0) { for (int q = lane; q < j; q += 64) rq[q] = 0; break; }
             if (j == 0) break;                                   // only vertical moves remain
-#ifdef C3_PHASE_PROF
-            tbc_[0]++;
-#endif
             const int rt = r, jt = j;
             const int rk = rt - lane;
             const bool rowv = rk >= 1;
@@ -1469,14 +1118,13 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
             const bool two = rowv && ((m2bits[rb >> 6] >> (rb & 63)) & 1);
             const bool adj = two && ((mabits[rb >> 6] >> (rb & 63)) & 1);
             const uint4 de = c.rdesc[max(rk, 1)];
-            const int lok = cb ? (int)(de.w & 0xffff) : 0;                       // band start of this lane's row
-            // byte offset of cell `col` inside a D row: two-bit rows keep one word per lane (lane = col / cpl), byte rows
-            // dsb bytes per lane; the window starts 4-byte aligned a little left of the expected column
-            const int ce = min(max(jt - lane - lok, 0), ncol - 1);
+            // byte offset of cell `col` inside a D row: two-bit rows keep one dword per lane (lane = col / cpl), byte rows
+            // ds_ bytes per lane; the window starts 4-byte aligned a little left of the expected column
+            const int ce = max(jt - lane, 0);
             const int le = cpl ? (ce * cdiv) >> 16 : 0;
             int wb;                                                             // window start (byte offset in the row)
-            if (two) wb = (max(le - (tb == 1 ? 5 : 2), 0) * tb) & ~3;
-            else wb = max((cpl ? le * dsb + (ce - le * cpl) : ce) - 6, 0) & ~3;
+            if (two) wb = (max(le - 2, 0) * tb) & ~3;
+            else wb = max((cpl ? le * (((cpl + 3) & ~3)) + (ce - le * cpl) : ce) - 6, 0) & ~3;
             wb = min(wb, max(RS - 16, 0));
             {
               const unsigned* src = (const unsigned*)(c.D + (size_t)max(rk, 1) * RS + wb);
@@ -1486,23 +1134,17 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
             }
             WSYNC();
             for (;;) {
-#ifdef C3_PHASE_PROF
-              tbc_[1]++;
-#endif
               const int s = rt - r;                               // lane s holds the current row
               const int jk = j - (lane - s);
-              const int ok_ = jk - lok;                           // cell index inside the row
-              const bool val = rowv && lane >= s && jk >= 0 && ok_ >= 0 && ok_ < ncol;
-              const int jc = min(max(ok_, 0), ncol - 1);
+              const bool val = rowv && lane >= s && jk >= 0;
+              const int jc = max(jk, 0);
               const int lq = cpl ? (jc * cdiv) >> 16 : 0, cw = jc - lq * cpl;
-              const int bo = (two ? lq * tb : (cpl ? lq * dsb + cw : jc)) - wb;      // byte offset in the window
+              const int bo = (two ? lq * tb : (cpl ? lq * ((cpl + 3) & ~3) + cw : jc)) - wb;      // byte offset in the window
               const bool hit = val && bo >= 0 && bo + (two ? tb : 1) <= 16;
               const unsigned wv = WD[lane * 4 + (min(max(bo, 0), 15) >> 2)];
               int d, prow = -1;
-              if (two) {
-                const unsigned cellw = tb == 1 ? (wv >> (8 * (bo & 3))) & 0xffu : tb == 2 ? (wv >> (8 * (bo & 2))) & 0xffffu : wv;
-                d = 63 + 64 * (int)((cellw >> (2 * cw)) & 3u); prow = adj ? rk - 1 : -3;
-              } else {
+              if (two) { const unsigned cellw = tb == 2 ? (wv >> (8 * (bo & 2))) & 0xffffu : wv; d = 63 + 64 * (int)((cellw >> (2 * cw)) & 3u); prow = adj ? rk - 1 : -3; }
+              else {
                 d = (int)((wv >> (8 * (bo & 3))) & 0xffu);
                 if (win_d_type(d) != 2) prow = ((de.x >> 16) & 1) ? -2 : win_pred_row(c, de, rk, win_d_pred(d));
               }
@@ -1517,19 +1159,14 @@ __global__ __launch_bounds__(64, 5) void k_window(WinArgs a) {
               int db, pb;
               if (wave_bcast((int)hit, cl)) { db = wave_bcast(d, cl); pb = wave_bcast(prow, cl); }
               else {
-#ifdef C3_PHASE_PROF
-                tbc_[2]++;
-#endif
                 // outside the window (the path drifted off this block's diagonal): direct loads of the one cell
                 const bool two0 = (m2bits[(r - 1) >> 6] >> ((r - 1) & 63)) & 1;
-                const int o0 = cb ? min(max(j - (int)(c.rdesc[r].w & 0xffff), 0), ncol - 1) : j;
                 if (two0) {
-                  const uint8_t* drow = c.D + (size_t)r * RS;
-                  const unsigned w0 = tb == 1 ? (unsigned)drow[o0 / cpl] : tb == 2 ? (unsigned)((const unsigned short*)drow)[o0 / cpl] : ((const unsigned*)drow)[o0 / cpl];
-                  db = 63 + 64 * (int)((w0 >> (2 * (o0 % cpl))) & 3u);
+                  const unsigned w0 = tb == 2 ? (unsigned)((const unsigned short*)(c.D + (size_t)r * RS))[j / cpl] : ((const unsigned*)(c.D + (size_t)r * RS))[j / cpl];
+                  db = 63 + 64 * (int)((w0 >> (2 * (j % cpl))) & 3u);
                   pb = ((mabits[(r - 1) >> 6] >> ((r - 1) & 63)) & 1) ? r - 1 : -3;
                 } else {
-                  db = c.D[(size_t)r * RS + (cpl ? (o0 / cpl) * dsb + o0 % cpl : o0)];
+                  db = c.D[(size_t)r * RS + win_idx(j, cpl)];
                   pb = -2;
                 }
               }

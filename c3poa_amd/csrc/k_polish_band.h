@@ -1,0 +1,546 @@
+// k_polish_band.h -- the BANDED rows of k_window (included by k_polish.hip; round 3).
+//
+// A layer of ~500 bases against a window graph never leaves a narrow diagonal (measured on the synthetic configs: +-8 columns
+// around the column predicted from the backbone position), but the unbanded rows fill all Q + 1 columns.  Here a row
+// computes only BW = 64 * CB columns [lo(r), lo(r) + BW) around its expected column
+//     c(r) = (bb(r) - begin + 1) * Q / (end - begin + 1),   bb(r) = highest backbone node among the rows <= r,
+// lane owns band offsets CB*lane .. CB*lane + CB - 1 (column = lo(r) + offset), and the band slides right as the rows go down.
+//
+// EXACTNESS.  Cells outside the band count as -infinity, so the banded optimum S_b is the best score of the
+// paths that stay inside.  While the rows run, a certificate bound is accumulated: an upper bound of the score of EVERY path
+// with a cell outside the band.  Such a path leaves the band for the first time at a band-edge cell X whose banded value
+// bounds its prefix, and the rest is bounded by the moves that are left (every remaining column scores at most `ups` = the
+// best substitution score; a path that is behind the rows that remain must pay gaps for the columns it cannot match):
+//   right exit (any row whose band ends before column Q; the path moves right out of the last cell):
+//       H[r][hi] + ups * (Q - hi)
+//   left exit (rows with a successor whose band starts further right; cells lo .. lo + leftspan - 1):
+//       H[r][j] + ups * min(rem, nb) + gap * max(0, rem - nb),  rem = Q - j, nb = aligned blocks behind the row's block
+//       (a path visits at most one node per aligned block, so at most nb more diagonal moves; the other columns are gaps)
+//   rows hanging off the virtual start row whose band does not start at column 0: the same bound from cell (0, 0).
+// If bound < S_b (strictly), the unbanded traceback path lies inside the band, the banded values along it equal the unbanded
+// ones and every tie is broken the same way -- the result is bit-identical to the full matrix, which the oracle keeps
+// filling.  A layer whose certificate fails is simply redone by the unbanded rows.
+//
+// Row loop.  hcur = row r-1 in ITS band coordinates.  The fast row (one predecessor = the row above, band shift 0 or 1,
+// nothing to keep) is straight-line code, one variant per shift: neighbours from registers with one DPP move, substitution
+// bytes of its columns prefetched from an LDS table during the row before, 2 bits of direction per cell appended to a
+// per-lane accumulator that goes to memory once per RPW rows (ONE vector store per 4-8 rows: the row loop is bound by
+// instruction issue, and a store costs the memory pipeline as much as sixteen ALU instructions cost the SIMD).  Every other
+// predecessor comes from an LDS ring of the last WB_RING rows or, further back, from 16-bit rows in global memory.  The
+// band-edge cells of a row (first 2*CB, last) are parked in LDS by three lanes and turned into the certificate bound
+// once per 64 rows by the lane that holds the row's descriptor.
+#pragma once
+
+#define WB_PADL 4            /* shorts in front of cell 0 of a ring slot: [0..1] lo, [3] = -inf (offset -1) */
+#define WB_PADR 36           /* -inf shorts behind the last cell: a predecessor is read at offsets up to BW - 1 + WB_MAXSHIFT + CB */
+#define WB_MAXSHIFT 32       /* lo(row) - lo(predecessor) beyond this: the layer is not banded */
+#ifndef WB_RING
+#define WB_RING 4            /* rows kept in the LDS ring (power of two) */
+#endif
+#define WB_EROW 16           /* shorts per row of band-edge cells parked for the certificate */
+__host__ __device__ __forceinline__ int wb_slot_shorts(int cb) { return WB_PADL + 64 * cb + WB_PADR; }
+// LDS of the banded rows behind the row-type bitmasks, in dwords: substitution table, ring, edge cells of 64 rows
+__host__ __device__ __forceinline__ int wb_lds_dwords(int Q, int cb) { return ((Q + 2) & ~1) + WB_RING * wb_slot_shorts(cb) / 2 + 64 * WB_EROW / 2; }
+__device__ __forceinline__ int wb_left(int cb) { return cb == 2 ? 70 : cb == 3 ? 105 : 140; }     // columns left of the centre (the rest, 57 / 86 / 115, right)
+__host__ __device__ __forceinline__ int wb_rpw(int cb) { return cb == 2 ? 8 : 4; }                 // rows per packed direction word (2*cb bits per row and lane)
+__host__ __device__ __forceinline__ int wb_bit0(int cb) { return 32 - 2 * cb * wb_rpw(cb); }       // first used bit of a direction word (cb == 3: 8)
+
+// Direction stream of a banded layer in the slot's D scratch, as dwords:
+//   word g (rows g*RPW + 1 .. g*RPW + RPW) of lane l at  [g * 64 + l]:  row k of the word, cell cc of the lane -> 2 bits at
+//   bit0 + 2*CB*k + 2*cc  (3 diagonal, 2 vertical, 1 horizontal)
+//   predecessor index bytes of the rows with several predecessors (cell cc -> byte cc) at [(G + 1 + r) * 64 + l], G = words
+__device__ __forceinline__ int wb_words(int R, int cb) { return (R + wb_rpw(cb) - 1) / wb_rpw(cb); }
+
+// descriptors of the banded rows.  x = base*8 | np<<8 | ovf<<16 | far<<17 | isend<<18 | two<<19 | fast<<20 | shift<<22 (fast rows: 0/1)
+// | wr<<23 | virt<<24;  y, z = predecessor rows (as the unbanded descriptors);  w = lo | leftspan<<16.
+//   far:  some successor is more than WB_RING rows ahead -> the H row also goes to global memory
+//   wr:   some successor will read the row from the LDS ring (i.e. is not the fast row right below)
+//   virt: no masked predecessor (the row hangs off the virtual start row)
+//   leftspan = max over successors of lo(successor) - lo(row): the row's first `leftspan` cells have successors whose band
+//              starts to their right (a path can leave the band there)
+// lob[r] = lo | (number of aligned blocks among rows 1..r) << 16;  d0 / d1: bit r-1 = bit 0 / 1 of lo(r) - lo(r-1).
+// Returns 0 when the layer cannot be banded.
+__device__ int win_build_desc_band(WCtx& c, int R, int Q, int begin, int end, int blen, int CB, int lane,
+                                   unsigned long long* m2, unsigned long long* ma, unsigned long long* d0, unsigned long long* d1, int* nblocks) {
+  const int BW = 64 * CB, WLf = wb_left(CB), span = end - begin + 1, lomax = Q + 1 - BW;
+  const WArr<int> lob = c.lob();
+  int bbc = begin - 1, loc = 0, nbc = 0, gprev = -1, bad = 0;
+  for (int r0 = 1; r0 <= R; r0 += 64) {
+    const int r = r0 + lane;
+    const bool live = r <= R;
+    const int v = live ? c.rows()[r] : 0;
+    // backbone position reached so far -> band start (non-decreasing)
+    const int bbs = max(wave_scan_max(live && v < blen ? v : -1), bbc);
+    bbc = wave_bcast(bbs, 63);
+    const int cen = (int)(((long long)(bbs - begin + 1) * Q + span / 2) / span);
+    const int lo = min(max(cen - WLf, 0), lomax);
+    const int lop = wave_shr1(lo, loc);                               // lo of the row above
+    loc = wave_bcast(lo, 63);
+    const int dl = live ? lo - lop : 0;
+    if (dl > 3) bad = 1;
+    // aligned blocks: runs of equal group ids in the row order
+    const int gr = live ? c.grp()[v] : -2;
+    const int grp_ = wave_shr1(gr, gprev);
+    gprev = wave_bcast(gr, 63);
+    const unsigned long long bs = __ballot(live && gr != grp_);
+    const int bidx = nbc + __popcll(bs & ((2ull << lane) - 1));
+    nbc += __popcll(bs);
+    bool two = false, adj = false;
+    if (live) {
+      const int nin = c.n_in()[v], nout = c.n_out()[v];
+      // the first four in- / out-edges are fetched together (slot-major adjacency: independent loads), then their rows
+      int pe[4], se[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { pe[k] = k < nin ? c.in_from()[EI(v, k)] : -1; se[k] = k < nout ? c.out_to()[EI(v, k)] : -1; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { pe[k] = pe[k] >= 0 ? c.rowof()[pe[k]] : -1; se[k] = se[k] >= 0 ? c.rowof()[se[k]] : -1; }
+      unsigned p[4] = {0, 0, 0, 0};
+      int np = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (pe[k] >= 0) { p[np < 4 ? np : 3] = (unsigned)pe[k]; ++np; }
+      for (int k = 4; k < nin; ++k) { const int pr = c.rowof()[c.in_from()[EI(v, k)]]; if (pr >= 0) ++np; }
+      unsigned has = 0, far = 0;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) if (se[k] >= 0) { has = 1; if (se[k] - r > WB_RING) far = 1; }
+      for (int k = 4; k < nout; ++k) { const int sr = c.rowof()[c.out_to()[EI(v, k)]]; if (sr >= 0) { has = 1; if (sr - r > WB_RING) far = 1; } }
+      const unsigned ovf = np > 4, virt = np == 0;
+      if (np == 0) np = 1;
+      two = np == 1;
+      adj = two && (int)p[0] == r - 1;
+      const unsigned fast = adj && !far && has && dl <= 1;
+      uint4 d; d.x = ((unsigned)c.base()[v] & 3u) * 8u | ((unsigned)min(np, 255) << 8) | (ovf << 16) | (far << 17) | ((has ^ 1u) << 18) | ((unsigned)two << 19) | (fast << 20)
+                     | ((unsigned)(fast ? dl : 0) << 22) | (virt << 24);
+      d.y = p[0] | (p[1] << 16); d.z = p[2] | (p[3] << 16); d.w = (unsigned)lo;
+      c.rdesc[r] = d;
+      c.hend()[r] = INT32_MIN;
+      lob[r] = lo | (bidx << 16);
+    }
+    const unsigned long long b2 = __ballot(two), ba = __ballot(adj), bd0 = __ballot(dl & 1), bd1 = __ballot((dl & 2) != 0);
+    if (lane == 0) { m2[r0 >> 6] = b2; ma[r0 >> 6] = ba; d0[r0 >> 6] = bd0; d1[r0 >> 6] = bd1; }
+  }
+  if (lane == 0) lob[0] = 0;
+  *nblocks = nbc;
+  WSYNC();
+  // second pass: what depends on the neighbours' band starts and row kinds
+  for (int r = 1 + lane; r <= R; r += 64) {
+    const unsigned dx = ((const unsigned*)(c.rdesc + r))[0];
+    const int v = c.rows()[r], lo = lob[r] & 0xffff;
+    const int nin = c.n_in()[v], nout = c.n_out()[v];
+    int pe[4], se[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { pe[k] = k < nin ? c.in_from()[EI(v, k)] : -1; se[k] = k < nout ? c.out_to()[EI(v, k)] : -1; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { pe[k] = pe[k] >= 0 ? c.rowof()[pe[k]] : -1; se[k] = se[k] >= 0 ? c.rowof()[se[k]] : -1; }
+    int plo[4], slo[4]; unsigned sx[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      plo[k] = pe[k] >= 0 ? lob[pe[k]] & 0xffff : lo;
+      slo[k] = se[k] >= 0 ? lob[se[k]] & 0xffff : lo;
+      sx[k] = se[k] >= 0 ? ((const unsigned*)(c.rdesc + se[k]))[0] : 0u;
+    }
+    int ls = 0; unsigned wr = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (se[k] >= 0) { ls = max(ls, slo[k] - lo); if (!(((sx[k] >> 20) & 1) && se[k] == r + 1)) wr = 1; }
+      if (pe[k] >= 0 && lo - plo[k] > WB_MAXSHIFT) bad = 1;
+    }
+    for (int k = 4; k < nout; ++k) {
+      const int sr = c.rowof()[c.out_to()[EI(v, k)]];
+      if (sr < 0) continue;
+      ls = max(ls, (lob[sr] & 0xffff) - lo); wr = 1;                   // (a fast row has one predecessor: it cannot be a fifth successor's only one ... but it can; keep it simple)
+    }
+    for (int k = 4; k < nin; ++k) {
+      const int pr = c.rowof()[c.in_from()[EI(v, k)]];
+      if (pr >= 0 && lo - (lob[pr] & 0xffff) > WB_MAXSHIFT) bad = 1;
+    }
+    if (ls > 2 * CB || ls > 255) bad = 1;                             // only the first 2*CB cells of a row are kept for the certificate
+    ((unsigned*)(c.rdesc + r))[0] = dx | (wr << 23);
+    ((unsigned*)(c.rdesc + r))[3] = (unsigned)lo | ((unsigned)min(ls, 255) << 16);
+  }
+  bad = __ballot(bad) != 0;
+  WSYNC();
+  return !bad;
+}
+
+// three lanes (0, 1, 63) park their cells of the row in LDS: EXEC is narrowed by hand (the compiler's version of the same
+// `if` costs two compares and an and/or dance per row)
+template <int CB>
+__device__ __forceinline__ void wb_park_edge(unsigned eaddr, const int (&h)[CB]) {
+  const unsigned long long emask = 0x8000000000000003ull;
+  if (CB == 2)
+    asm volatile("s_mov_b64 exec, %0\n\tds_write_b16 %1, %2\n\tds_write_b16 %1, %3 offset:2\n\ts_mov_b64 exec, -1"
+                 :: "s"(emask), "v"(eaddr), "v"(h[0]), "v"(h[CB > 1 ? 1 : 0]) : "memory");
+  else if (CB == 3)
+    asm volatile("s_mov_b64 exec, %0\n\tds_write_b16 %1, %2\n\tds_write_b16 %1, %3 offset:2\n\tds_write_b16 %1, %4 offset:4\n\ts_mov_b64 exec, -1"
+                 :: "s"(emask), "v"(eaddr), "v"(h[0]), "v"(h[CB > 1 ? 1 : 0]), "v"(h[CB > 2 ? 2 : 0]) : "memory");
+  else
+    asm volatile("s_mov_b64 exec, %0\n\tds_write_b16 %1, %2\n\tds_write_b16 %1, %3 offset:2\n\tds_write_b16 %1, %4 offset:4\n\tds_write_b16 %1, %5 offset:6\n\ts_mov_b64 exec, -1"
+                 :: "s"(emask), "v"(eaddr), "v"(h[0]), "v"(h[CB > 1 ? 1 : 0]), "v"(h[CB > 2 ? 2 : 0]), "v"(h[CB > 3 ? 3 : 0]) : "memory");
+}
+
+// All banded rows of one layer.  Returns 0 (or -1: scratch too small); the certificate bound goes to hend[0].
+template <int CB>
+__device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t* cH, uint8_t* cD, uint4* crdesc, int cK, int cn, int cNcap, long long chcap,
+                                                       int mt_, int mm_, int g_, const uint32_t* pk_, int qbeg_, int Q_, int R_, unsigned long long* dbg_, int lds_off_, int nblocks_) {
+  WCtx c;
+  c.I = uni_ptr(cI); c.E = uni_ptr(cE); c.B8 = nullptr; c.score = nullptr; c.H = uni_ptr(cH); c.D = uni_ptr(cD);
+  c.rdesc = uni_ptr(crdesc); c.K = uni32(cK); c.n = uni32(cn); c.Ncap = uni32(cNcap);
+  c.hcap = ((long long)uni32((int)(chcap >> 32)) << 32) | (unsigned)uni32((int)chcap);
+  const uint32_t* pk = uni_ptr(pk_);
+  unsigned long long* dbg = uni_ptr(dbg_);
+  const int qbeg = uni32(qbeg_), Q = uni32(Q_), R = uni32(R_), NB = uni32(nblocks_);
+  const int lane = wave_lane();
+  extern __shared__ int lds_dyn[];
+  constexpr int BW = 64 * CB, SLOT = WB_PADL + BW + WB_PADR /* shorts */, HS = BW + 8 /* shorts of a global H row: [0..1] lo, [4..] cells */;
+  constexpr int RPW = CB == 2 ? 8 : 4, BPR = 2 * CB, BIT0 = 32 - BPR * RPW;
+  unsigned* tbl = (unsigned*)lds_dyn + uni32(lds_off_);                      // [Q + 1] substitution bytes per column
+  unsigned short* ring = (unsigned short*)(tbl + ((Q + 2) & ~1));
+  unsigned short* ebuf = ring + WB_RING * SLOT;                              // [64][WB_EROW] band-edge cells of the current 64 rows
+  struct { int pol_match, pol_mismatch, pol_gap; } P = {uni32(mt_), uni32(mm_), uni32(g_)};
+  const int K = c.K;
+  const int G = (R + RPW - 1) / RPW;
+  // direction words + predecessor-index rows in the D scratch (bytes: hcap * 2), far H rows in the H scratch
+  if ((long long)(G + 2 + R) * 256 > c.hcap * 2 || (long long)(R + 1) * HS * 2 + 64 > c.hcap * 4 || R >= 65535) return -1;
+  unsigned short* const H16 = (unsigned short*)c.H;
+  unsigned* const DW = (unsigned*)c.D;
+  unsigned* const PX = DW + (size_t)(G + 1) * 64;
+  const int ups = max(P.pol_match, P.pol_mismatch), gap = P.pol_gap;
+  const int mt3 = P.pol_match * 4 + 3, mm3 = P.pol_mismatch * 4 + 3, g4 = P.pol_gap * 4;
+  const int mm3x4 = (mm3 & 255) * 0x01010101;
+  for (int j = lane; j <= Q; j += 64) {
+    const int qc = j >= 1 ? c3_code_at(pk, qbeg + j - 1) : 7;
+    tbl[j] = qc < 4 ? (mm3x4 & ~(255 << (8 * qc))) | ((mt3 & 255) << (8 * qc)) : mm3x4;
+  }
+  if (lane == 0) tbl[Q + 1] = mm3x4;                                        // (prefetched past the last column, never used)
+  for (int i = lane; i < WB_RING * (WB_PADR + 1); i += 64) {               // the -inf cells around every ring slot
+    const int sl = i / (WB_PADR + 1), k = i % (WB_PADR + 1);
+    ring[sl * SLOT + (k == 0 ? WB_PADL - 1 : WB_PADL + BW + k - 1)] = (unsigned short)W_NEG16;
+  }
+  int hcur[CB], g41[CB];
+#pragma unroll
+  for (int cc = 0; cc < CB; ++cc) {
+    const int b = lane * CB + cc;
+    hcur[cc] = b * g4;                                                      // virtual row 0, lo = 0
+    g41[cc] = b * g4 + 1;                                                   // horizontal candidate = 4 * (best y + g * offset) + 1 (the band start cancels inside a row)
+  }
+  int cV = g4 + 2;
+  VREG(cV);
+  WSYNC();
+  const unsigned* tp = tbl + CB * lane;
+  int lo = 0;                                                               // band start of the row in hcur
+  unsigned tn[CB + 1];                                                      // substitution bytes of columns lo + CB*lane + 0..CB (the next row needs CB of them)
+#pragma unroll
+  for (int k = 0; k <= CB; ++k) tn[k] = tp[k];
+  unsigned dacc = 0;                                                        // direction bits of the rows of the current word
+  unsigned dwoff = (unsigned)lane;                                          // dword index of this lane's next direction word
+  const unsigned ebase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short*)ebuf + 2u * (lane < 2 ? (unsigned)(lane * CB) : (unsigned)(WB_EROW - CB));
+  int best = (BW - 1) * gap + ups * (Q - BW + 1);                           // certificate: right exit of the virtual row (its band ends at BW - 1 < Q)
+#ifdef C3_PHASE_PROF
+  unsigned long long pf_fast = 0, pf_d0 = 0, pf_d1 = 0, pf_c2 = 0, pf_c3 = 0, pf_c4 = 0;
+#endif
+
+  // one row ends: horizontal gap inside the band (in-lane prefix + one cross-lane max-scan over y = H - g * offset), new
+  // hcur, 2 direction bits per cell on top of the accumulator.  PIDX: the predecessor that set the cell sits in bits 16..21
+  // of key (rows with several predecessors) and goes to the row's index bytes.
+#define WB_ROW_TAIL(PIDX)                                                                                        \
+    {                                                                                                            \
+      int run = W_NEG16;                                                                                         \
+      _Pragma("unroll") for (int cc = 0; cc < CB; ++cc) run = max16(run, key[cc] - g41[cc]);                    \
+      int ex = wave_shr1(wave_scan_max(__builtin_amdgcn_sbfe(run, 0, 16)), W_NEG16);                             \
+      unsigned w2 = 0, pidx = 0;                                                                                 \
+      _Pragma("unroll") for (int cc = 0; cc < CB; ++cc) {                                                       \
+        const int k2 = max16(key[cc], (ex & ~3) + g41[cc]);                                                      \
+        ex = max16(ex, key[cc] - g41[cc]);                                                                       \
+        hcur[cc] = k2 & ~3;                                                                                      \
+        w2 |= ((unsigned)k2 & 3u) << (32 - BPR + 2 * cc);                                                        \
+        if (PIDX) pidx |= (((unsigned)key[cc] >> 16) & 63u) << (8 * cc);                                         \
+      }                                                                                                          \
+      dacc = (dacc >> BPR) | w2;                                                                                 \
+      if (PIDX) GP(unsigned, PX)[(unsigned)r * 64u + (unsigned)lane] = pidx;                                     \
+      wb_park_edge<CB>(ebase + (unsigned)li * (2u * WB_EROW), hcur);                                             \
+    }
+#define WB_RING_WRITE()                                                                                          \
+    {                                                                                                            \
+      unsigned short* sp_ = ring + (r & (WB_RING - 1)) * SLOT;                                                   \
+      *(int*)sp_ = lo;                                                                                           \
+      _Pragma("unroll") for (int cc = 0; cc < CB; ++cc) sp_[WB_PADL + CB * lane + cc] = (unsigned short)hcur[cc]; \
+    }
+
+  for (int rb = 1; rb <= R; rb += 64) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 dv = GP(const u32x4, c.rdesc)[min(rb + lane, R)];
+    uint4 dblk = make_uint4(dv.x, dv.y, dv.z, dv.w);
+    unsigned lobv = (unsigned)GP(const int, c.lob().ptr())[min(rb + lane, R)];
+    asm volatile("" : "+v"(dblk.x), "+v"(dblk.y), "+v"(dblk.z), "+v"(dblk.w), "+v"(lobv));
+    const int cnt = min(64, R - rb + 1);
+    for (int li = 0; li < cnt; ++li) {
+      const int r = rb + li;
+      const unsigned dx = (unsigned)__builtin_amdgcn_readlane((int)dblk.x, li);
+      int key[CB];
+      if (dx & (1u << 20)) {
+        // FAST ROW: the row above, band shift 0 or 1
+        const int vb8 = (int)(dx & 24u);
+#ifdef C3_PHASE_PROF
+        ++pf_fast;
+#endif
+        if (dx & (1u << 22)) {
+          int tv[CB];
+#pragma unroll
+          for (int cc = 0; cc < CB; ++cc) tv[cc] = __builtin_amdgcn_sbfe((int)tn[cc + 1], vb8, 8);
+          lo += 1;
+#pragma unroll
+          for (int k = 0; k <= CB; ++k) tn[k] = tp[lo + k];
+          const int hnext = wave_shl1(hcur[0], W_NEG16);                    // offset CB*lane + CB of the row above
+#pragma unroll
+          for (int cc = 0; cc < CB; ++cc) {
+            const int hv = cc + 1 < CB ? hcur[cc + 1 < CB ? cc + 1 : cc] : hnext;
+            key[cc] = max16(hcur[cc] + tv[cc], hv + cV);
+          }
+          WB_ROW_TAIL(false)
+        } else {
+          int tv[CB];
+#pragma unroll
+          for (int cc = 0; cc < CB; ++cc) tv[cc] = __builtin_amdgcn_sbfe((int)tn[cc], vb8, 8);
+          const int hleft = wave_shr1(hcur[CB - 1], W_NEG16);
+#pragma unroll
+          for (int cc = 0; cc < CB; ++cc) {
+            const int hd = cc == 0 ? hleft : hcur[cc > 0 ? cc - 1 : 0];
+            key[cc] = max16(hd + tv[cc], hcur[cc] + cV);
+          }
+          WB_ROW_TAIL(false)
+        }
+        if (dx & (1u << 23)) WB_RING_WRITE()
+      } else {
+#ifdef C3_PHASE_PROF
+        const unsigned long long gen_t0 = __builtin_readcyclecounter();
+#endif
+        uint4 de;
+        de.x = dx;
+        de.y = __builtin_amdgcn_readlane(dblk.y, li);
+        de.z = __builtin_amdgcn_readlane(dblk.z, li);
+        de.w = __builtin_amdgcn_readlane(dblk.w, li);
+        const int np = (de.x >> 8) & 0xff;
+        const bool ovf = (de.x >> 16) & 1, two = (de.x >> 19) & 1;
+        if (np > 64) return -1;
+        lo = (int)(de.w & 0xffff);
+        const int vb8 = (int)(dx & 24u);
+        int tv[CB];
+#pragma unroll
+        for (int cc = 0; cc < CB; ++cc) tv[cc] = __builtin_amdgcn_sbfe((int)tp[lo + cc], vb8, 8);
+#pragma unroll
+        for (int k = 0; k <= CB; ++k) tn[k] = tp[lo + k];                   // for the row below
+        int kedge = 0;
+        for (int t = 0; t < np; ++t) {
+          int prow;
+          if ((de.x >> 24) & 1) prow = 0;
+          else if (!ovf) prow = (t == 0) ? (de.y & 0xffff) : (t == 1) ? (de.y >> 16) : (t == 2) ? (de.z & 0xffff) : (de.z >> 16);
+          else {
+            const int v = GP(const int, c.rows().ptr())[r];
+            prow = -1;
+            while (kedge < GP(const int, c.n_in().ptr())[v]) { int pr = GP(const int, c.rowof().ptr())[GP(const int, c.in_from().ptr())[EI(v, kedge)]]; ++kedge; if (pr >= 0) { prow = pr; break; } }
+            if (prow < 0) break;
+          }
+          int hpv[CB + 1];                                                   // H[prow][lo + CB*lane - 1 + k]
+          if (prow == 0) {                                                   // the virtual start row: H[0][j] = j * gap
+            const int b0 = (lo + CB * lane - 1) * g4;
+#pragma unroll
+            for (int k = 0; k <= CB; ++k) hpv[k] = b0 + k * g4;
+            if (lo + CB * lane == 0) hpv[0] = W_NEG16;
+          } else if (r - prow <= WB_RING) {
+            const unsigned short* sp_ = ring + (prow & (WB_RING - 1)) * SLOT;
+            const int sh = lo - *(const int*)sp_;
+            const unsigned short* cp = sp_ + (WB_PADL - 1) + CB * lane + sh;
+#pragma unroll
+            for (int k = 0; k <= CB; ++k) hpv[k] = (int)cp[k];
+          } else {
+            const auto* hp_ = GP(const unsigned short, H16) + (size_t)prow * HS;
+            const int sh = lo - (int)((unsigned)hp_[0] | ((unsigned)hp_[1] << 16));
+#pragma unroll
+            for (int k = 0; k <= CB; ++k) { const int ix = CB * lane + sh - 1 + k; hpv[k] = (ix >= 0 && ix < BW) ? (int)hp_[WB_PADL + ix] : W_NEG16; }
+          }
+          if (t == 0) {
+#pragma unroll
+            for (int cc = 0; cc < CB; ++cc) key[cc] = max16(hpv[cc] + tv[cc], hpv[cc + 1] + cV);
+          } else {
+            const int tmark = t << 16;
+#pragma unroll
+            for (int cc = 0; cc < CB; ++cc) {
+              const int nk = max16(key[cc], max16(hpv[cc] + tv[cc], hpv[cc + 1] + cV));
+              key[cc] = nk != (key[cc] & 0xffff) ? (nk | tmark) : key[cc];
+            }
+          }
+        }
+        if (two) WB_ROW_TAIL(false) else WB_ROW_TAIL(true)
+        if (de.x & (1u << 23)) WB_RING_WRITE()
+        if ((de.x >> 17) & 1) {
+          auto* hrow = GP(unsigned short, H16) + (size_t)r * HS;
+          hrow[0] = (unsigned short)lo; hrow[1] = (unsigned short)((unsigned)lo >> 16);
+#pragma unroll
+          for (int cc = 0; cc < CB; ++cc) hrow[WB_PADL + CB * lane + cc] = (unsigned short)hcur[cc];
+        }
+        if ((de.x >> 18) & 1) {
+#pragma unroll
+          for (int cc = 0; cc < CB; ++cc) if (lo + lane * CB + cc == Q) GP(int, c.hend().ptr())[r] = __builtin_amdgcn_sbfe(hcur[cc], 2, 14);
+        }
+#ifdef C3_PHASE_PROF
+        { const bool pm1 = (de.y & 0xffff) == (unsigned)(r - 1); pf_d0 += (1ull << 32) + (two && pm1); pf_d1 += 1 + ((unsigned long long)!two << 32);
+          const unsigned long long dt_ = __builtin_readcyclecounter() - gen_t0; if (!two) pf_c2 += dt_; else if (pm1) pf_c4 += dt_; else pf_c3 += dt_; }
+#endif
+      }
+      if ((li & (RPW - 1)) == RPW - 1) { GP(unsigned, DW)[dwoff] = dacc; dwoff += 64; dacc = 0; }
+    }
+    if (cnt & (RPW - 1)) {                                                   // the last, partial word of the layer
+      const int miss = RPW - (cnt & (RPW - 1));
+      GP(unsigned, DW)[dwoff] = dacc >> (BPR * miss); dwoff += 64; dacc = 0;
+    }
+    // certificate bound of these rows: lane li holds the descriptor of row rb + li, the edge cells sit in ebuf[li]
+    if (lane < cnt) {
+      const unsigned short* e = ebuf + lane * WB_EROW;
+      const int lo_r = (int)(dblk.w & 0xffff), ls = (int)((dblk.w >> 16) & 0xff), nb = NB - (int)(lobv >> 16);
+      const int hi = lo_r + BW - 1;
+      if (hi < Q) best = max(best, ((int)(short)e[WB_EROW - 1] >> 2) + ups * (Q - hi));
+      if (((dblk.x >> 24) & 1) && lo_r > 0) best = max(best, ups * min(Q, nb + 1) + gap * max(0, Q - nb - 1));      // entered from (0, j), j < lo
+      if (!((dblk.x >> 18) & 1)) {
+        for (int b = 0; b < ls; ++b) {
+          const int rem = Q - lo_r - b;
+          best = max(best, ((int)(short)e[b] >> 2) + ups * min(rem, nb) + gap * max(0, rem - nb));
+        }
+      }
+    }
+  }
+#undef WB_ROW_TAIL
+#undef WB_RING_WRITE
+  best = wave_max(best);
+  if (lane == 0) GP(int, c.hend().ptr())[0] = best;
+#ifdef C3_PHASE_PROF
+  dbg[0] += pf_d0; dbg[1] += pf_d1 + pf_fast; dbg[2] += pf_c2; dbg[3] += pf_c3; dbg[4] += pf_c4;
+#endif
+  WSYNC();
+  return 0;
+}
+
+// Traceback through a banded layer, 64 rows at a time (same scheme as the unbanded one in k_window: lane k owns row rt - k,
+// every step inside a block is an LDS read).  A block costs ONE memory round trip: the descriptors of its 64 rows, the
+// direction words of its rows around the path (NW words x LW lanes) and -- for rows with several predecessors -- four
+// dwords of predecessor-index bytes are all fetched at once; the band start of every row comes from the shift bitmasks
+// in LDS, not from memory.  rq[q] = DP row aligned to query base q, 0 = insertion.
+__device__ void win_traceback_band(WCtx& c, int CB, int R, int Q, int r, const unsigned long long* m2bits, const unsigned long long* mabits,
+                                   const unsigned long long* d0bits, const unsigned long long* d1bits, unsigned* lds, const WArr<int>& rq, int lane) {
+  const int RPW = wb_rpw(CB), BPR = 2 * CB, BIT0 = wb_bit0(CB), BW = 64 * CB;
+  const int NW = 64 / RPW + 1, LW = CB == 2 ? 14 : 7;                       // direction words of a block, lanes fetched per word
+  const int cdiv = (65536 + CB - 1) / CB;                                    // o / CB == (o * cdiv) >> 16 for o < 2^13
+  const int G = wb_words(R, CB);
+  const unsigned* DW = (const unsigned*)c.D;
+  const unsigned* PX = DW + (size_t)(G + 1) * 64;
+  unsigned* WD = lds;                                                        // [NW * LW] direction words (<= 128)
+  int* WL0 = (int*)(lds + 128);                                              // [NW] first lane of every word's window
+  unsigned* WP = lds + 160;                                                  // [64][4] predecessor-index dwords
+  int j = Q;
+  int lo_t = r > 0 ? (c.lob()[r] & 0xffff) : 0;                              // band start of the current row
+  while (r > 0 || j > 0) {
+    if (r == 0) { for (int q = lane; q < j; q += 64) rq[q] = 0; break; }
+    if (j == 0) break;                                   // only vertical moves remain
+    const int rt = r, jt = j;
+    // band shifts of the 64 rows above rt: bit 63 - x of sd0 / sd1 = shift bit of row rt - x
+    unsigned long long sd0, sd1;
+    {
+      const int wh = (rt - 1) >> 6, sh = (rt - 1) & 63;
+      sd0 = d0bits[wh] << (63 - sh); sd1 = d1bits[wh] << (63 - sh);
+      if (sh != 63 && wh > 0) { sd0 |= d0bits[wh - 1] >> (sh + 1); sd1 |= d1bits[wh - 1] >> (sh + 1); }
+    }
+    const int rk = rt - lane;
+    const bool rowv = rk >= 1;
+    const int rbx = max(rk, 1) - 1;
+    const bool two = rowv && ((m2bits[rbx >> 6] >> (rbx & 63)) & 1);
+    const bool adj = two && ((mabits[rbx >> 6] >> (rbx & 63)) & 1);
+    // lo(rt - k) = lo(rt) - sum of the shifts of rows rt - k + 1 .. rt
+    const int lok = lane == 0 ? lo_t : lo_t - (__popcll(sd0 >> (64 - lane)) + 2 * __popcll(sd1 >> (64 - lane)));
+    const uint4 de = c.rdesc[max(rk, 1)];
+    // ---- direction words: slot s of the block = word (ghi - s / LW), lane window position s % LW
+    const int ghi = (rt - 1) / RPW;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int s = lane * 2 + h;
+      const int wi = s / LW, ln = s - wi * LW;
+      const int g = ghi - wi;
+      if (wi < NW && g >= 0) {
+        // expected cell of the word's middle row on the diagonal through (rt, jt)
+        const int rm = min(g * RPW + RPW / 2 + 1, rt);
+        const int km = min(rt - rm, 63);
+        const int lom = km == 0 ? lo_t : lo_t - (__popcll(sd0 >> (64 - km)) + 2 * __popcll(sd1 >> (64 - km)));
+        const int om = min(max(jt - km - lom, 0), BW - 1);
+        const int l0 = min(max(((om * cdiv) >> 16) - LW / 2, 0), 64 - LW);
+        WD[s] = DW[(size_t)g * 64 + l0 + ln];
+        if (ln == 0) WL0[wi] = l0;
+      }
+    }
+    // ---- predecessor-index bytes of this lane's row (rows with several predecessors only)
+    const int oe = min(max(jt - lane - lok, 0), BW - 1);
+    const int pl0 = min(max(((oe * cdiv) >> 16) - 1, 0), 60);
+    if (rowv && !two) {
+      const unsigned* src = PX + (size_t)rk * 64 + pl0;
+      *(uint4*)(WP + lane * 4) = make_uint4(src[0], src[1], src[2], src[3]);
+    }
+    WSYNC();
+    const int wik = ghi - (max(rk, 1) - 1) / RPW;                            // this lane's word in the block
+    const int kin = (max(rk, 1) - 1) % RPW;                                  // ... and its row inside the word
+    const int wl0 = (wik >= 0 && wik < NW) ? WL0[wik] : 0;
+    for (;;) {
+      const int s = rt - r;                               // lane s holds the current row
+      const int jk = j - (lane - s);
+      const int ok_ = jk - lok;                           // band offset of the cell
+      const bool val = rowv && lane >= s && jk >= 0 && ok_ >= 0 && ok_ < BW && wik < NW;
+      const int oc = min(max(ok_, 0), BW - 1);
+      const int lq = (oc * cdiv) >> 16, cw = oc - lq * CB;
+      const int ix = lq - wl0;
+      bool hit = val && ix >= 0 && ix < LW;
+      const unsigned wv = WD[min(max(wik, 0), NW - 1) * LW + min(max(ix, 0), LW - 1)];
+      const unsigned cell = (wv >> (BIT0 + BPR * kin + 2 * cw)) & 3u;
+      int d = 63 + 64 * (int)cell, prow = -1;
+      if (two) prow = adj ? rk - 1 : -3;
+      else {
+        const int px = lq - pl0;
+        if (px < 0 || px > 3) hit = false;
+        const unsigned pv = WP[lane * 4 + min(max(px, 0), 3)];
+        d -= (int)((pv >> (8 * cw)) & 63u);
+        if (win_d_type(d) != 2) prow = ((de.x >> 16) & 1) ? -2 : win_pred_row(c, de, rk, win_d_pred(d));
+      }
+      const bool diag1 = hit && jk >= 1 && win_d_type(d) == 0 && prow == rk - 1;
+      const unsigned long long bal = __ballot(diag1) >> s;
+      const int m = (~bal) ? __builtin_ctzll(~bal) : 64;  // length of the diagonal run
+      if (lane >= s && lane < s + m) rq[jk - 1] = rk;
+      r -= m; j -= m;
+      if (s + m >= 64 || r <= 0 || j <= 0) break;
+      // the breaking cell (r, j) sits in lane cl
+      const int cl = rt - r;
+      int db, pb;
+      if (wave_bcast((int)hit, cl)) { db = wave_bcast(d, cl); pb = wave_bcast(prow, cl); }
+      else {
+        // outside the windows (the path drifted off this block's diagonal): direct loads of the one cell
+        const int lor = wave_bcast(lok, cl);
+        const int o0 = min(max(j - lor, 0), BW - 1), l0_ = o0 / CB, c0 = o0 % CB;
+        const unsigned w0 = DW[(size_t)((r - 1) / RPW) * 64 + l0_];
+        db = 63 + 64 * (int)((w0 >> (BIT0 + BPR * ((r - 1) % RPW) + 2 * c0)) & 3u);
+        const bool two0 = (m2bits[(r - 1) >> 6] >> ((r - 1) & 63)) & 1;
+        if (two0) pb = ((mabits[(r - 1) >> 6] >> ((r - 1) & 63)) & 1) ? r - 1 : -3;
+        else { db -= (int)((PX[(size_t)r * 64 + l0_] >> (8 * c0)) & 63u); pb = -2; }
+      }
+      const int ty = win_d_type(db);
+      if (ty == 2) { if (lane == 0) rq[j - 1] = 0; --j; }
+      else {
+        if (pb <= -2) pb = win_pred_row(c, c.rdesc[r], r, win_d_pred(db));   // > 4 predecessors, a 2-bit row whose predecessor is not r-1, or a window miss
+        if (ty == 0) { if (lane == 0) rq[j - 1] = r; --j; }
+        r = pb;
+      }
+      if (r <= 0 || j <= 0) break;
+      const int drift = (jt - j) - (rt - r);
+      if (rt - r >= 64 || drift > 5 || drift < -5) break;
+    }
+    // band start of the row the next block starts at
+    if (r > 0) {
+      const int back = rt - r;
+      lo_t = back < 64 ? wave_bcast(lok, back) : (c.lob()[r] & 0xffff);
+    }
+    WSYNC();
+  }
+}
