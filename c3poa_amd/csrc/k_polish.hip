@@ -348,6 +348,11 @@ __device__ void w_reorder(WCtx& c, int n_old, int lane, int* lds, int lds_cap) {
     for (int k = lane; k < n_new; k += 64) c.order2()[c.anchor()[k] + 1 + k] = n_old + k;
     WSYNC();
   }
+#ifdef C3_EXP_X2_RFIN
+  for (int i = lane; i < c.n; i += 64) { int v = c.order2()[i]; c.order()[i] = v; c.index()[v] = i; }
+  WSYNC();
+  w_blocks(c, lane);
+#endif
   for (int i = lane; i < c.n; i += 64) { int v = c.order2()[i]; c.order()[i] = v; c.index()[v] = i; }
   WSYNC();
   w_blocks(c, lane);
@@ -790,23 +795,18 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
   *cb_io = cb;
   if (cb) {
     *cpl_out = cb; *rs_out = 256;
+    int rc = 0;
+#ifdef C3_EXP_X2_ROWS
+    for (int rep_ = 0; rep_ < 2; ++rep_)
+#endif
     switch (cb) {
-      case 2: {
-#ifdef C3_EXP_X2_ROWS
-        win_rows_band<2>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks);
-#endif
-        return win_rows_band<2>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); }
-      case 3: {
-#ifdef C3_EXP_X2_ROWS
-        win_rows_band<3>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks);
-#endif
-        return win_rows_band<3>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); }
-      default: {
-#ifdef C3_EXP_X2_ROWS
-        win_rows_band<4>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks);
-#endif
-        return win_rows_band<4>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); }
+      case 2: rc = win_rows_band<2>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); break;
+      case 3: rc = win_rows_band<3>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); break;
+      default: rc = win_rows_band<4>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); break;
     }
+    if (rc < 0) return rc;
+    if (rc > 0) c.lob()[0] = INT32_MAX;        // a band that cannot hold a predecessor: the certificate fails by definition
+    return 0;
   }
   *cpl_out = cpl; *rs_out = cpl ? 64 * ((cpl + 3) & ~3) : need * 64;    // D row stride in bytes
 #ifdef C3_PHASE_PROF
@@ -1046,6 +1046,9 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         }
         PH_MARK(1)
         int R = 0;
+#ifdef C3_EXP_X2_COMP
+        for (int rep_ = 0; rep_ < 2; ++rep_) { R = 0;
+#endif
         for (int i0 = 0; i0 < c.n; i0 += 64) {        // order-preserving compaction
           const int i = i0 + lane;
           const int v = i < c.n ? c.order()[i] : 0;
@@ -1057,6 +1060,9 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
           }
           R += __popcll(bal);
         }
+#ifdef C3_EXP_X2_COMP
+        WSYNC(); }
+#endif
         WSYNC();
         PH_MARK(2)
         int cpl = 0, RS = 0, cb = 1, gbs = INT32_MIN, gbr = 0;
@@ -1071,17 +1077,23 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
           PH_MARK(3)
           cells_done += (long long)(R + 1) * (cb ? 64 * cb : Q + 1);
           // ---- end row: candidate rows (no masked successor) left H[r][Q] in hend; first maximum in order
-          int bs = INT32_MIN, br = INT32_MAX / 2;
-          for (int r = 1 + lane; r <= R; r += 64) { const int sc = c.hend()[r]; if (sc > bs) { bs = sc; br = r; } }
-          gbs = wave_max(bs);
-          gbr = wave_min(bs == gbs ? br : INT32_MAX / 2);
-          if (!cb) break;
-          // banded rows: accepted only with the certificate that no path outside the band reaches the banded optimum
-          // (the rows left the bound of every such path in hend[0])
+          if (cb) {
+            // banded rows: the row loop kept the best end row itself and left the certificate bound of every path outside the
+            // band; the band result is accepted only if that bound stays strictly below the banded optimum
+            WSYNC();
+            const int bound = c.lob()[0];
+            gbs = c.lob()[1]; gbr = c.lob()[2];
 #ifdef C3_EXP_NOCERT
-          if (cb) { ++n_band; break; }
+            if (cb) { ++n_band; break; }
 #endif
-          if (gbs != INT32_MIN && c.hend()[0] < gbs) { ++n_band; break; }
+            if (gbs != INT32_MIN && bound < gbs) { ++n_band; break; }
+          } else {
+            int bs = INT32_MIN, br = INT32_MAX / 2;
+            for (int r = 1 + lane; r <= R; r += 64) { const int sc = c.hend()[r]; if (sc > bs) { bs = sc; br = r; } }
+            gbs = wave_max(bs);
+            gbr = wave_min(bs == gbs ? br : INT32_MAX / 2);
+            break;
+          }
           ++n_fallback; cb = 0;                                                // redo the layer with the full matrix
         }
         if (fail) break;

@@ -51,19 +51,26 @@ __host__ __device__ __forceinline__ int wb_bit0(int cb) { return 32 - 2 * cb * w
 //   predecessor index bytes of the rows with several predecessors (cell cc -> byte cc) at [(G + 1 + r) * 64 + l], G = words
 __device__ __forceinline__ int wb_words(int R, int cb) { return (R + wb_rpw(cb) - 1) / wb_rpw(cb); }
 
-// descriptors of the banded rows.  x = base*8 | np<<8 | ovf<<16 | far<<17 | isend<<18 | two<<19 | fast<<20 | shift<<22 (fast rows: 0/1)
-// | wr<<23 | virt<<24;  y, z = predecessor rows (as the unbanded descriptors);  w = lo | leftspan<<16.
+// descriptors of the banded rows, built in ONE pass over the rows (64 per step; no second pass, no side arrays: every
+// vector memory instruction of the graph phases costs the kernel about as much as twenty ALU instructions).
+//   x = base*8 | np<<8 | ovf<<16 | far<<17 | isend<<18 | two<<19 | fast<<20 | shift<<22 (fast rows: 0/1) | wr<<23 | virt<<24
+//   y, z = predecessor rows (as the unbanded descriptors)
+//   w = lo | dist<<10 | bidx<<18
 //   far:  some successor is more than WB_RING rows ahead -> the H row also goes to global memory
 //   wr:   some successor will read the row from the LDS ring (i.e. is not the fast row right below)
 //   virt: no masked predecessor (the row hangs off the virtual start row)
-//   leftspan = max over successors of lo(successor) - lo(row): the row's first `leftspan` cells have successors whose band
-//              starts to their right (a path can leave the band there)
-// lob[r] = lo | (number of aligned blocks among rows 1..r) << 16;  d0 / d1: bit r-1 = bit 0 / 1 of lo(r) - lo(r-1).
-// Returns 0 when the layer cannot be banded.
+//   dist: rows to the farthest successor (0 = none).  lo is non-decreasing along the rows, so the band of that successor starts
+//         furthest right: leftspan(r) = lo(r + dist) - lo(r) = sum of the shifts of rows r+1 .. r+dist, taken from the shift
+//         bitmasks when the certificate is evaluated -- the row's first `leftspan` cells are where a path can leave the band
+//   bidx: number of aligned blocks among rows 1..r
+// d0 / d1: bit r-1 = bit 0 / 1 of lo(r) - lo(r-1).  Returns 0 when the layer cannot be banded.
+#define WB_W_LO(w) ((int)((w) & 0x3ffu))
+#define WB_W_DIST(w) ((int)(((w) >> 10) & 0xffu))
+#define WB_W_BIDX(w) ((int)((w) >> 18))
 __device__ int win_build_desc_band(WCtx& c, int R, int Q, int begin, int end, int blen, int CB, int lane,
                                    unsigned long long* m2, unsigned long long* ma, unsigned long long* d0, unsigned long long* d1, int* nblocks) {
   const int BW = 64 * CB, WLf = wb_left(CB), span = end - begin + 1, lomax = Q + 1 - BW;
-  const WArr<int> lob = c.lob();
+  if (R >= 16000 || Q > 1000) return 0;
   int bbc = begin - 1, loc = 0, nbc = 0, gprev = -1, bad = 0;
   for (int r0 = 1; r0 <= R; r0 += 64) {
     const int r = r0 + lane;
@@ -86,77 +93,45 @@ __device__ int win_build_desc_band(WCtx& c, int R, int Q, int begin, int end, in
     const int bidx = nbc + __popcll(bs & ((2ull << lane) - 1));
     nbc += __popcll(bs);
     bool two = false, adj = false;
+    unsigned p[4] = {0, 0, 0, 0}, has = 0, far = 0, fast = 0, other = 0, next = 0, virt = 0, ovf = 0, vb = 0;
+    int np = 0, dist = 0;
     if (live) {
       const int nin = c.n_in()[v], nout = c.n_out()[v];
-      // the first four in- / out-edges are fetched together (slot-major adjacency: independent loads), then their rows
-      int pe[4], se[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { pe[k] = k < nin ? c.in_from()[EI(v, k)] : -1; se[k] = k < nout ? c.out_to()[EI(v, k)] : -1; }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) { pe[k] = pe[k] >= 0 ? c.rowof()[pe[k]] : -1; se[k] = se[k] >= 0 ? c.rowof()[se[k]] : -1; }
-      unsigned p[4] = {0, 0, 0, 0};
-      int np = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) if (pe[k] >= 0) { p[np < 4 ? np : 3] = (unsigned)pe[k]; ++np; }
-      for (int k = 4; k < nin; ++k) { const int pr = c.rowof()[c.in_from()[EI(v, k)]]; if (pr >= 0) ++np; }
-      unsigned has = 0, far = 0;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) if (se[k] >= 0) { has = 1; if (se[k] - r > WB_RING) far = 1; }
-      for (int k = 4; k < nout; ++k) { const int sr = c.rowof()[c.out_to()[EI(v, k)]]; if (sr >= 0) { has = 1; if (sr - r > WB_RING) far = 1; } }
-      const unsigned ovf = np > 4, virt = np == 0;
+      vb = (unsigned)c.base()[v] & 3u;
+      for (int k = 0; k < nin; ++k) {
+        const int pr = c.rowof()[c.in_from()[EI(v, k)]];
+        if (pr < 0) continue;
+        if (np < 4) p[np] = (unsigned)pr;
+        ++np;
+      }
+      for (int k = 0; k < nout; ++k) {
+        const int sr = c.rowof()[c.out_to()[EI(v, k)]];
+        if (sr < 0) continue;
+        has = 1; dist = max(dist, sr - r);
+        if (sr == r + 1) next = 1; else other = 1;
+      }
+      far = dist > WB_RING;
+      if (dist > 64) bad = 1;                                          // (the certificate reads the shifts of at most 64 rows)
+      ovf = np > 4; virt = np == 0;
       if (np == 0) np = 1;
       two = np == 1;
       adj = two && (int)p[0] == r - 1;
-      const unsigned fast = adj && !far && has && dl <= 1;
-      uint4 d; d.x = ((unsigned)c.base()[v] & 3u) * 8u | ((unsigned)min(np, 255) << 8) | (ovf << 16) | (far << 17) | ((has ^ 1u) << 18) | ((unsigned)two << 19) | (fast << 20)
-                     | ((unsigned)(fast ? dl : 0) << 22) | (virt << 24);
-      d.y = p[0] | (p[1] << 16); d.z = p[2] | (p[3] << 16); d.w = (unsigned)lo;
+      fast = adj && !far && has && dl <= 1;
+    }
+    // wr: a successor other than the row below, or the row below is not a fast row (its kind sits one lane up; the last
+    // lane of a step does not see it and writes the ring to be safe)
+    const unsigned fastn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)fast, 0x130, 0xf, 0xf, false);       // wave_shl:1
+    if (live) {
+      const unsigned wr = other | (next & (fastn ^ 1u));
+      uint4 d; d.x = vb * 8u | ((unsigned)min(np, 255) << 8) | (ovf << 16) | (far << 17) | ((has ^ 1u) << 18) | ((unsigned)two << 19) | (fast << 20)
+                     | ((unsigned)(fast ? dl : 0) << 22) | (wr << 23) | (virt << 24);
+      d.y = p[0] | (p[1] << 16); d.z = p[2] | (p[3] << 16); d.w = (unsigned)lo | ((unsigned)min(dist, 255) << 10) | ((unsigned)bidx << 18);
       c.rdesc[r] = d;
-      c.hend()[r] = INT32_MIN;
-      lob[r] = lo | (bidx << 16);
     }
     const unsigned long long b2 = __ballot(two), ba = __ballot(adj), bd0 = __ballot(dl & 1), bd1 = __ballot((dl & 2) != 0);
     if (lane == 0) { m2[r0 >> 6] = b2; ma[r0 >> 6] = ba; d0[r0 >> 6] = bd0; d1[r0 >> 6] = bd1; }
   }
-  if (lane == 0) lob[0] = 0;
   *nblocks = nbc;
-  WSYNC();
-  // second pass: what depends on the neighbours' band starts and row kinds
-  for (int r = 1 + lane; r <= R; r += 64) {
-    const unsigned dx = ((const unsigned*)(c.rdesc + r))[0];
-    const int v = c.rows()[r], lo = lob[r] & 0xffff;
-    const int nin = c.n_in()[v], nout = c.n_out()[v];
-    int pe[4], se[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { pe[k] = k < nin ? c.in_from()[EI(v, k)] : -1; se[k] = k < nout ? c.out_to()[EI(v, k)] : -1; }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { pe[k] = pe[k] >= 0 ? c.rowof()[pe[k]] : -1; se[k] = se[k] >= 0 ? c.rowof()[se[k]] : -1; }
-    int plo[4], slo[4]; unsigned sx[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      plo[k] = pe[k] >= 0 ? lob[pe[k]] & 0xffff : lo;
-      slo[k] = se[k] >= 0 ? lob[se[k]] & 0xffff : lo;
-      sx[k] = se[k] >= 0 ? ((const unsigned*)(c.rdesc + se[k]))[0] : 0u;
-    }
-    int ls = 0; unsigned wr = 0;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      if (se[k] >= 0) { ls = max(ls, slo[k] - lo); if (!(((sx[k] >> 20) & 1) && se[k] == r + 1)) wr = 1; }
-      if (pe[k] >= 0 && lo - plo[k] > WB_MAXSHIFT) bad = 1;
-    }
-    for (int k = 4; k < nout; ++k) {
-      const int sr = c.rowof()[c.out_to()[EI(v, k)]];
-      if (sr < 0) continue;
-      ls = max(ls, (lob[sr] & 0xffff) - lo); wr = 1;                   // (a fast row has one predecessor: it cannot be a fifth successor's only one ... but it can; keep it simple)
-    }
-    for (int k = 4; k < nin; ++k) {
-      const int pr = c.rowof()[c.in_from()[EI(v, k)]];
-      if (pr >= 0 && lo - (lob[pr] & 0xffff) > WB_MAXSHIFT) bad = 1;
-    }
-    if (ls > 2 * CB || ls > 255) bad = 1;                             // only the first 2*CB cells of a row are kept for the certificate
-    ((unsigned*)(c.rdesc + r))[0] = dx | (wr << 23);
-    ((unsigned*)(c.rdesc + r))[3] = (unsigned)lo | ((unsigned)min(ls, 255) << 16);
-  }
   bad = __ballot(bad) != 0;
   WSYNC();
   return !bad;
@@ -178,7 +153,8 @@ __device__ __forceinline__ void wb_park_edge(unsigned eaddr, const int (&h)[CB])
                  :: "s"(emask), "v"(eaddr), "v"(h[0]), "v"(h[CB > 1 ? 1 : 0]), "v"(h[CB > 2 ? 2 : 0]), "v"(h[CB > 3 ? 3 : 0]) : "memory");
 }
 
-// All banded rows of one layer.  Returns 0 (or -1: scratch too small); the certificate bound goes to hend[0].
+// All banded rows of one layer.  Returns 0, 1 (a predecessor's band lies too far left: not banded) or -1 (scratch too small).
+// Results in lob[0..2]: the certificate bound, the best end-row score H[r][Q] (INT32_MIN: none inside the band), its row.
 template <int CB>
 __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t* cH, uint8_t* cD, uint4* crdesc, int cK, int cn, int cNcap, long long chcap,
                                                        int mt_, int mm_, int g_, const uint32_t* pk_, int qbeg_, int Q_, int R_, unsigned long long* dbg_, int lds_off_, int nblocks_) {
@@ -196,6 +172,8 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
   unsigned* tbl = (unsigned*)lds_dyn + uni32(lds_off_);                      // [Q + 1] substitution bytes per column
   unsigned short* ring = (unsigned short*)(tbl + ((Q + 2) & ~1));
   unsigned short* ebuf = ring + WB_RING * SLOT;                              // [64][WB_EROW] band-edge cells of the current 64 rows
+  const unsigned long long* d0bits = (const unsigned long long*)(lds_dyn + uni32(lds_off_) / 2);      // the four bitmask arrays fill [0, lds_off)
+  const unsigned long long* d1bits = (const unsigned long long*)(lds_dyn + uni32(lds_off_) / 4 * 3);
   struct { int pol_match, pol_mismatch, pol_gap; } P = {uni32(mt_), uni32(mm_), uni32(g_)};
   const int K = c.K;
   const int G = (R + RPW - 1) / RPW;
@@ -235,6 +213,7 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
   unsigned dwoff = (unsigned)lane;                                          // dword index of this lane's next direction word
   const unsigned ebase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short*)ebuf + 2u * (lane < 2 ? (unsigned)(lane * CB) : (unsigned)(WB_EROW - CB));
   int best = (BW - 1) * gap + ups * (Q - BW + 1);                           // certificate: right exit of the virtual row (its band ends at BW - 1 < Q)
+  int ebs = INT32_MIN, ebr = INT32_MAX / 2, bandbad = 0;                    // best end row seen by this lane
 #ifdef C3_PHASE_PROF
   unsigned long long pf_fast = 0, pf_d0 = 0, pf_d1 = 0, pf_c2 = 0, pf_c3 = 0, pf_c4 = 0;
 #endif
@@ -270,8 +249,7 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 dv = GP(const u32x4, c.rdesc)[min(rb + lane, R)];
     uint4 dblk = make_uint4(dv.x, dv.y, dv.z, dv.w);
-    unsigned lobv = (unsigned)GP(const int, c.lob().ptr())[min(rb + lane, R)];
-    asm volatile("" : "+v"(dblk.x), "+v"(dblk.y), "+v"(dblk.z), "+v"(dblk.w), "+v"(lobv));
+    asm volatile("" : "+v"(dblk.x), "+v"(dblk.y), "+v"(dblk.z), "+v"(dblk.w));
     const int cnt = min(64, R - rb + 1);
     for (int li = 0; li < cnt; ++li) {
       const int r = rb + li;
@@ -322,7 +300,7 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
         const int np = (de.x >> 8) & 0xff;
         const bool ovf = (de.x >> 16) & 1, two = (de.x >> 19) & 1;
         if (np > 64) return -1;
-        lo = (int)(de.w & 0xffff);
+        lo = WB_W_LO(de.w);
         const int vb8 = (int)(dx & 24u);
         int tv[CB];
 #pragma unroll
@@ -349,12 +327,14 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
           } else if (r - prow <= WB_RING) {
             const unsigned short* sp_ = ring + (prow & (WB_RING - 1)) * SLOT;
             const int sh = lo - *(const int*)sp_;
-            const unsigned short* cp = sp_ + (WB_PADL - 1) + CB * lane + sh;
+            if (sh > WB_MAXSHIFT) bandbad = 1;
+            const unsigned short* cp = sp_ + (WB_PADL - 1) + CB * lane + min(sh, WB_MAXSHIFT);
 #pragma unroll
             for (int k = 0; k <= CB; ++k) hpv[k] = (int)cp[k];
           } else {
             const auto* hp_ = GP(const unsigned short, H16) + (size_t)prow * HS;
             const int sh = lo - (int)((unsigned)hp_[0] | ((unsigned)hp_[1] << 16));
+            if (sh > WB_MAXSHIFT) bandbad = 1;
 #pragma unroll
             for (int k = 0; k <= CB; ++k) { const int ix = CB * lane + sh - 1 + k; hpv[k] = (ix >= 0 && ix < BW) ? (int)hp_[WB_PADL + ix] : W_NEG16; }
           }
@@ -378,9 +358,9 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
 #pragma unroll
           for (int cc = 0; cc < CB; ++cc) hrow[WB_PADL + CB * lane + cc] = (unsigned short)hcur[cc];
         }
-        if ((de.x >> 18) & 1) {
+        if ((de.x >> 18) & 1) {                                             // an end row: H[r][Q] is a candidate end of the alignment (first maximum in row order)
 #pragma unroll
-          for (int cc = 0; cc < CB; ++cc) if (lo + lane * CB + cc == Q) GP(int, c.hend().ptr())[r] = __builtin_amdgcn_sbfe(hcur[cc], 2, 14);
+          for (int cc = 0; cc < CB; ++cc) { const int sc = __builtin_amdgcn_sbfe(hcur[cc], 2, 14); if (lo + lane * CB + cc == Q && sc > ebs) { ebs = sc; ebr = r; } }
         }
 #ifdef C3_PHASE_PROF
         { const bool pm1 = (de.y & 0xffff) == (unsigned)(r - 1); pf_d0 += (1ull << 32) + (two && pm1); pf_d1 += 1 + ((unsigned long long)!two << 32);
@@ -396,12 +376,20 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
     // certificate bound of these rows: lane li holds the descriptor of row rb + li, the edge cells sit in ebuf[li]
     if (lane < cnt) {
       const unsigned short* e = ebuf + lane * WB_EROW;
-      const int lo_r = (int)(dblk.w & 0xffff), ls = (int)((dblk.w >> 16) & 0xff), nb = NB - (int)(lobv >> 16);
+      const int r = rb + lane;
+      const int lo_r = WB_W_LO(dblk.w), dist = WB_W_DIST(dblk.w), nb = NB - WB_W_BIDX(dblk.w);
       const int hi = lo_r + BW - 1;
       if (hi < Q) best = max(best, ((int)(short)e[WB_EROW - 1] >> 2) + ups * (Q - hi));
       if (((dblk.x >> 24) & 1) && lo_r > 0) best = max(best, ups * min(Q, nb + 1) + gap * max(0, Q - nb - 1));      // entered from (0, j), j < lo
-      if (!((dblk.x >> 18) & 1)) {
-        for (int b = 0; b < ls; ++b) {
+      if (dist > 0) {
+        // leftspan = lo(r + dist) - lo(r): shift bits of rows r+1 .. r+dist = bit indices r .. r+dist-1
+        const int w0 = r >> 6, off = r & 63;
+        unsigned long long a0 = d0bits[w0] >> off, a1 = d1bits[w0] >> off;
+        if (off) { a0 |= d0bits[w0 + 1] << (64 - off); a1 |= d1bits[w0 + 1] << (64 - off); }
+        const unsigned long long dm = dist >= 64 ? ~0ull : ((1ull << dist) - 1ull);
+        const int ls = __popcll(a0 & dm) + 2 * __popcll(a1 & dm);
+        if (ls > 2 * CB) bandbad = 1;                                        // only the first 2*CB cells of a row are parked
+        for (int b = 0; b < min(ls, 2 * CB); ++b) {
           const int rem = Q - lo_r - b;
           best = max(best, ((int)(short)e[b] >> 2) + ups * min(rem, nb) + gap * max(0, rem - nb));
         }
@@ -411,12 +399,15 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
 #undef WB_ROW_TAIL
 #undef WB_RING_WRITE
   best = wave_max(best);
-  if (lane == 0) GP(int, c.hend().ptr())[0] = best;
+  const int gbs = wave_max(ebs);
+  const int gbr = wave_min(ebs == gbs ? ebr : INT32_MAX / 2);
+  if (lane == 0) { auto* res = GP(int, c.lob().ptr()); res[0] = best; res[1] = gbs; res[2] = gbr; }
+  bandbad = __ballot(bandbad) != 0;
 #ifdef C3_PHASE_PROF
   dbg[0] += pf_d0; dbg[1] += pf_d1 + pf_fast; dbg[2] += pf_c2; dbg[3] += pf_c3; dbg[4] += pf_c4;
 #endif
   WSYNC();
-  return 0;
+  return bandbad ? 1 : 0;
 }
 
 // Traceback through a banded layer, 64 rows at a time (same scheme as the unbanded one in k_window: lane k owns row rt - k,
@@ -436,7 +427,7 @@ __device__ void win_traceback_band(WCtx& c, int CB, int R, int Q, int r, const u
   int* WL0 = (int*)(lds + 128);                                              // [NW] first lane of every word's window
   unsigned* WP = lds + 160;                                                  // [64][4] predecessor-index dwords
   int j = Q;
-  int lo_t = r > 0 ? (c.lob()[r] & 0xffff) : 0;                              // band start of the current row
+  int lo_t = r > 0 ? WB_W_LO(c.rdesc[r].w) : 0;                             // band start of the current row
   while (r > 0 || j > 0) {
     if (r == 0) { for (int q = lane; q < j; q += 64) rq[q] = 0; break; }
     if (j == 0) break;                                   // only vertical moves remain
@@ -539,7 +530,7 @@ __device__ void win_traceback_band(WCtx& c, int CB, int R, int Q, int r, const u
     // band start of the row the next block starts at
     if (r > 0) {
       const int back = rt - r;
-      lo_t = back < 64 ? wave_bcast(lok, back) : (c.lob()[r] & 0xffff);
+      lo_t = back < 64 ? wave_bcast(lok, back) : WB_W_LO(c.rdesc[r].w);
     }
     WSYNC();
   }
