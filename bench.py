@@ -108,6 +108,9 @@ def parse_args(argv=None):
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic reads generated per rank (0 = all)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--other-configs", default="auto",
+                    help="comma list of further configs run for 3 steps after the headline (rank 0, N=1): 'auto' = cfg3,cfg4 "
+                         "when the headline is cfg2 at full size, 'none' = skip")
     a = ap.parse_args(argv)
     if a.reads <= 0:
         a.reads = DEFAULT_READS.get(a.cfg, 100000)
@@ -131,6 +134,15 @@ def main():
     t_gen = time.time()
     recs = make_reads(a.cfg, n_unique, rank * a.reads, max(1, effective_cores() // max(world, 1)))
     t_gen = time.time() - t_gen
+    # inputs of the other configs too (rank 0, N=1): the fork pool must run before anything touches the GPU
+    others = a.other_configs
+    if others == "auto":
+        others = "cfg3,cfg4" if (a.cfg == "cfg2" and a.reads >= 100000) else "none"
+    other_recs = {}
+    if rank == 0 and world == 1 and others != "none":
+        for c in [x for x in others.split(",") if x]:
+            t_ = time.time()
+            other_recs[c] = (make_reads(c, min(OTHER_UNIQUE, DEFAULT_READS[c]), 0, effective_cores()), time.time() - t_)
 
     import torch
     if world > 1:
@@ -185,7 +197,7 @@ def main():
             for k, v in h.last_timing.items():
                 if k in KERNEL_MS:
                     stage_ms.setdefault(k, []).append(v)
-                elif k in ("ms_wall", "ms_host_worklist", "ms_alloc"):
+                elif k in ("ms_wall", "ms_host_worklist", "ms_alloc", "ms_host_gap"):
                     host_ms.setdefault(k, []).append(v)
         return out
 
@@ -224,7 +236,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the number
         # comes from the committed rocprofv3 passes of THIS command when the workload matches
         traffic, tsrc = None, None
-        for tag in ("r02", "r01"):
+        for tag in ("r03", "r02", "r01"):
             try:
                 name = "%s_pmc_traffic_%s_%dk.json" % (tag, a.cfg, a.reads // 1000)
                 pm = json.load(open(os.path.join(ROOT, "profiles", name)))
@@ -254,11 +266,15 @@ def main():
                          "kernel_ms": {k: round(v, 3) for k, v in avg.items()},
                          "run_host_ms": {k: round(float(np.mean(v)), 3) for k, v in host_ms.items()},
                          "cells_per_step": int(cells),
+                         "cells_polish_full_matrix": int(tm["cells_polish"]), "cells_polish_computed": int(tm["cells_polish_computed"]),
+                         "band_layers": int(tm["n_band_layers"]), "band_fallback_layers": int(tm["n_band_fallback"]),
                          "gcups": round(cells / (sum(avg.values()) * 1e-3) / 1e9, 2)},
             "gen_s": round(t_gen, 1),
         }
     h.close()
     host.close()
+    if rank == 0 and world == 1 and other_recs:
+        out["other_configs"] = {c: run_other_config(c, local_rank, *other_recs[c]) for c in other_recs}
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(recs, md, a.cpu_seconds)
     if dist is not None:
@@ -266,6 +282,57 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+OTHER_UNIQUE = 20000
+
+
+def run_other_config(cfg, device, recs, gen_s, steps=3):
+    """the same pipelined step (stage || run -> results -> commit) on another BASELINE config, per-GPU size, `unique` distinct
+    reads tiled: driver-clocked rates for cfg3 / cfg4 next to the cfg2 headline (parity of these shapes: tests/test_gpu_configs.py)"""
+    import torch
+    from c3poa_amd import _lib, synth
+    n = DEFAULT_READS[cfg]
+    nu = len(recs)
+    reps = (n + nu - 1) // nu
+    seqs = ([r[0] for r in recs] * reps)[:n]; quals = ([r[1] for r in recs] * reps)[:n]; strands = ([r[2] for r in recs] * reps)[:n]
+    lens = np.array([len(s) for s in seqs], dtype=np.int64)
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=off[1:])
+    host = _lib.PinnedBatch("".join(seqs).encode(), "".join(quals).encode(), off, "".join(strands))
+    del seqs, quals
+    h = _lib.Handle(device=device, mdistcutoff=synth.CONFIGS[cfg]["mdist"])
+    h.set_splints([synth.SPLINT1])
+    h.upload_pinned(host)
+    kms = {}
+
+    def step(timed):
+        h.stage_pinned(host); h.run(); res = h.results_raw(); h.commit()
+        if timed:
+            for k, v in h.last_timing.items():
+                if k.startswith("ms_") and k not in ("ms_pack", "ms_total", "ms_wall", "ms_alloc", "ms_host_worklist", "ms_host_gap"):
+                    kms.setdefault(k, []).append(v)
+        return res
+    step(False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res_raw = step(True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tm = h.last_timing
+    res, cbuf, coff = res_raw
+    raw = cbuf.tobytes()
+    n_id = min(100, nu)
+    idents = [synth.identity(raw[coff[i]:coff[i + 1]].decode(), recs[i][3]) if coff[i + 1] > coff[i] else 0.0 for i in range(n_id)]
+    o = {"value": round(n * steps / dt, 1), "unit": "reads/s", "reads_per_step": n, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2),
+         "kernel_ms": {k: round(float(np.mean(v)), 2) for k, v in kms.items()},
+         "cells": int(tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish"]), "cells_polish_computed": int(tm["cells_polish_computed"]),
+         "band_fallback_layers": int(tm["n_band_fallback"]), "band_layers": int(tm["n_band_layers"]),
+         "consensus_ok": int((res["status"] == 0).sum()), "identity_vs_truth_mean": round(float(np.mean(idents)), 5),
+         "data": "synthetic %s, %d distinct reads tiled x%d" % (cfg, nu, reps), "gen_s": round(gen_s, 1)}
+    h.close(); host.close()
+    return o
 
 
 def effective_cores():
