@@ -72,9 +72,25 @@ def make_reads(cfg, n, start, procs):
 
 def visible_gpus():
     """GPUs visible to this process WITHOUT initialising the HIP runtime (the launcher must stay GPU-free: its children
-    are separate processes, and a process that has touched the GPU must never exec)."""
-    import torch
-    return int(torch.cuda.device_count())
+    are separate processes, and a process that has touched the GPU must never exec).  Counted from the KFD topology (nodes
+    with SIMDs), honouring HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES; torch.cuda.device_count() can fall back to
+    hipGetDeviceCount, which does initialise the runtime."""
+    n = 0
+    try:
+        base = "/sys/class/kfd/kfd/topology/nodes"
+        for d in os.listdir(base):
+            try:
+                props = dict(l.split(None, 1) for l in open(os.path.join(base, d, "properties")).read().splitlines() if " " in l)
+                n += int(props.get("simd_count", "0")) > 0
+            except OSError:
+                continue
+    except OSError:
+        n = 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def launch_workers(n_gpus, argv, have=None):

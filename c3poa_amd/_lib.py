@@ -19,7 +19,7 @@ EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_create", "c
            "c3_batch_upload", "c3_batch_stage", "c3_batch_commit", "c3_batch_assign", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_timing",
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
            "c3_call_peaks", "c3_poa_msa", "c3_pairwise_consensus", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
-           "c3_reader_open", "c3_reader_open_range", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_reader_next_set", "c3_write_group",
+           "c3_reader_open", "c3_reader_open_range", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_reader_next_set", "c3_reader_noqual", "c3_reader_reserved_bytes", "c3_reader_range_lost", "c3_write_group",
            "c3_scan_adapters", "c3_match_index", "c3_match_index_batch",
            "c3_assign_open", "c3_assign_close", "c3_assign_batch", "c3_assign_seen", "c3_write_splint_psl",
            "c3_host_alloc", "c3_host_free", "c3_writer_reset"]
@@ -121,6 +121,9 @@ def load():
     lib.c3_reader_names_only.argtypes = [vp, C.c_int]
     lib.c3_reader_names_only.restype = None
     lib.c3_reader_error.restype = C.c_char_p
+    for fn in (lib.c3_reader_noqual, lib.c3_reader_reserved_bytes):
+        fn.argtypes = [vp]; fn.restype = C.c_int64
+    lib.c3_reader_range_lost.argtypes = [vp]
     lib.c3_reader_next.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.POINTER(HostBatchStruct)]
     lib.c3_reader_next_set.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(HostBatchStruct)]
     lib.c3_write_group.argtypes = [C.POINTER(HostBatchStruct), vp, vp, vp, vp, C.c_int, C.POINTER(cp), C.POINTER(cp), C.c_int]
@@ -517,6 +520,17 @@ class Reader:
         hb = HostBatch(c, self)
         hb.set_index = set_index
         return hb
+
+    def noqual(self):
+        """records without a quality line read so far (FASTA)"""
+        return int(self.lib.c3_reader_noqual(self.r))
+
+    def reserved_bytes(self):
+        return int(self.lib.c3_reader_reserved_bytes(self.r))
+
+    def range_lost(self):
+        """a byte-range reader whose range holds bytes but no record start (multi-line FASTQ): read the file with one reader"""
+        return bool(self.lib.c3_reader_range_lost(self.r))
 
     def close(self):
         if self.r:

@@ -21,6 +21,7 @@
 #include <string>
 #include <mutex>
 #include <thread>
+#include <sys/stat.h>
 #include <unordered_map>
 #include <vector>
 
@@ -70,8 +71,9 @@ struct c3_reader {
   std::vector<BatchSet> sets; int cur = -1;
   std::string err;
   bool have_line = false; const char* lp = nullptr; size_t ll = 0;   // one line of look-ahead
-  int64_t n_records = 0;
+  int64_t n_records = 0, n_noqual = 0;
   bool names_only = false;
+  bool range_lost = false;      // a byte range with bytes in it held no recognisable record start (e.g. multi-line FASTQ)
   size_t file_bytes = 0, hint_bases = 0;
   int64_t buf_off = 0;          // file offset of buf[0] (plain files)
   int64_t range_end = -1;       // byte range readers stop at the first record that starts at or after this offset
@@ -162,14 +164,17 @@ namespace {
 // Is `p` (a line start inside [buf, buf+n)) the header of a record?  FASTA: '>' is unambiguous.  FASTQ: '@' also opens
 // quality lines, so the 4-line shape is checked: '@' line, sequence, '+' line, quality of the same length as the sequence.
 // Returns 1 yes, 0 no, -1 cannot tell (window too short).
-int record_starts_at(const char* buf, size_t n, size_t p, bool fastq) {
+int record_starts_at(const char* buf, size_t n, size_t p, bool fastq, bool at_eof = false) {
   if (p >= n) return -1;
   if (!fastq) return buf[p] == '>' ? 1 : 0;            // ('>' is also a quality character: the file's first byte decides)
   if (buf[p] != '@') return 0;
   size_t ls[5]; ls[0] = p;
   for (int k = 1; k < 5; ++k) {
     const char* nl = (const char*)memchr(buf + ls[k - 1], '\n', n - ls[k - 1]);
-    if (!nl) return -1;
+    if (!nl) {
+      if (k == 4 && at_eof && ls[3] < n) { ls[4] = n + 1; break; }        // the file's last record without a trailing newline
+      return -1;
+    }
     ls[k] = (size_t)(nl - buf) + 1;
     if (k < 4 && ls[k] >= n) return -1;
   }
@@ -208,7 +213,7 @@ extern "C" int c3_reader_open_range(const char* path, int n_sets, int64_t beg, i
       if (!nl) break;
       p = (size_t)(nl - win.data()) + 1;
       if (p >= got) break;
-      const int st = record_starts_at(win.data(), got, p, fastq);
+      const int st = record_starts_at(win.data(), got, p, fastq, got < win.size());
       if (st == 1) { found = true; break; }
       if (st < 0) { grow = got == win.size(); break; }
     }
@@ -220,7 +225,10 @@ extern "C" int c3_reader_open_range(const char* path, int n_sets, int64_t beg, i
       return C3_E_OK;
     }
     if (grow && win.size() < ((size_t)1 << 30)) { win.resize(win.size() * 4); continue; }     // a record longer than the window
-    if (got < win.size()) { r->eof = true; r->buf_off = at; return C3_E_OK; }      // reached the end of the file without a record
+    if (got < win.size()) {                                                         // reached the end of the file without a record start
+      // bytes but no record: not a 4-line FASTQ (multi-line records?) -- the caller must fall back to one whole-file reader
+      r->eof = true; r->buf_off = at; r->range_lost = (int64_t)beg < (int64_t)r->file_bytes - 1 && got > 1; return C3_E_OK;
+    }
     at += (int64_t)got - 1;                                                         // no line start decided: keep scanning
   }
 }
@@ -237,6 +245,20 @@ extern "C" void c3_reader_close(c3_reader* r) {
 extern "C" void c3_reader_names_only(c3_reader* r, int names_only) { if (r) r->names_only = names_only != 0; }
 
 extern "C" const char* c3_reader_error(const c3_reader* r) { return r ? r->err.c_str() : "null reader"; }
+
+// records without a quality line seen so far (FASTA): the reference cannot process them (C3POa.py:167 takes ord() of every
+// quality character) and racon's -q 5 filter would drop every layer, so the CLI refuses such input
+extern "C" int64_t c3_reader_noqual(const c3_reader* r) { return r ? r->n_noqual : 0; }
+// bytes of host buffers this reader holds (diagnostic: tests/test_host_io.py checks that a tiny input stays tiny)
+extern "C" int64_t c3_reader_reserved_bytes(const c3_reader* r) {
+  if (!r) return 0;
+  int64_t tot = 0;
+  for (const BatchSet& b : r->sets) tot += (int64_t)(b.names.cap + b.seqs.cap + b.quals.cap);
+  return tot;
+}
+// 1 when c3_reader_open_range found bytes but no record start in its range (multi-line FASTQ cannot be entered in the middle):
+// the records of that range would be lost, so the caller has to read the file with ONE reader instead
+extern "C" int c3_reader_range_lost(const c3_reader* r) { return r && r->range_lost ? 1 : 0; }
 
 // One group of reads.  Records shorter than min_len are skipped and counted in out->n_short (C3POa.py:202-204,240-241).
 // Stops after max_reads kept reads or once max_bases kept bases are exceeded (0 = no limit).  out->n == 0 at end of file.
@@ -289,8 +311,9 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
         ql += l;
       }
       if (ql != sl) return fail(r, "truncated quality string");
-    } else if (!r->names_only) {
-      memset(s.quals.p + sb, '!', sl);           // FASTA record: no qualities -> Phred 0
+    } else {
+      ++r->n_noqual;
+      if (!r->names_only) memset(s.quals.p + sb, '!', sl);       // FASTA record: no qualities -> Phred 0
     }
     ++r->n_records;
     if ((int64_t)sl < (int64_t)min_len) { ++n_short; continue; }     // dropped: buffers are simply overwritten
@@ -300,10 +323,26 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
       size_t want = (size_t)max_reads * (sl + sl / 4) + 4096;
       if (max_bases > 0) want = std::min(want, (size_t)max_bases + sl + 4096);
       want = std::min(want, (size_t)2 << 30);
+      // ... but never more than this reader can still deliver: sequence bytes are at most half of the bytes left in its
+      // file / byte range (the other half are qualities), and only as many buffer sets as those bytes can fill are page-locked
+      // now (a 100-read input used to pin ten buffers of max_reads reads each)
+      size_t deliver = (size_t)-1;
+      if (!r->gz && r->file_bytes) {
+        const int64_t stop = r->range_end >= 0 ? std::min<int64_t>(r->range_end + (int64_t)(4 * sl + 4096), (int64_t)r->file_bytes) : (int64_t)r->file_bytes;
+        const int64_t here = r->buf_off + (int64_t)r->beg;
+        deliver = (size_t)std::max<int64_t>(0, stop - here) / 2 + sb + sl + 4096;
+      } else if (r->gz && r->file_bytes) deliver = r->file_bytes * 16 + sb + sl + 4096;        // (compressed size: a generous bound)
+      want = std::min(want, std::max(deliver, sb + sl + 4096));
       if (!s.seqs.reserve(want, sb + sl) || !s.quals.reserve(want, sb + sl)) return C3_E_NOMEM;
       // ... and the other buffer sets of this reader right away: a page-lock issued later, while the GPU is busy, stalls the
       // running kernels for its whole duration (some 50 ms per 400 MiB)
-      for (BatchSet& o : r->sets) if (&o != &s) { if (!o.seqs.reserve(want, 0) || !o.quals.reserve(want, 0)) return C3_E_NOMEM; }
+      size_t left = deliver > want ? deliver - want : 0;
+      for (BatchSet& o : r->sets) if (&o != &s) {
+        if (left == 0) break;                                              // nothing left to fill it with: grows lazily if ever needed
+        const size_t w2 = std::min(want, left + 4096);
+        if (!o.seqs.reserve(w2, 0) || !o.quals.reserve(w2, 0)) return C3_E_NOMEM;
+        left -= std::min(left, w2);
+      }
     }
     nn += name_len; nb += sl; ++n;
     s.name_off.push_back((int64_t)nn); s.off.push_back((int64_t)nb);
@@ -401,18 +440,34 @@ namespace {
 // lock, so the writer threads of several GPU workers can format and pwrite into ONE file concurrently (no part files, no
 // merge pass).  c3_writer_reset forgets the table (the caller truncates its files at the start of a run).
 std::mutex g_res_mu;
-std::unordered_map<std::string, off_t> g_res_next;
-off_t reserve_append(const char* path, int fd, size_t total) {
+struct ResEntry { off_t next = 0; int inflight = 0; };
+struct ResKey { dev_t dev; ino_t ino; bool operator==(const ResKey& o) const { return dev == o.dev && ino == o.ino; } };
+struct ResKeyHash { size_t operator()(const ResKey& k) const { return std::hash<unsigned long long>()((unsigned long long)k.dev * 1000003ull ^ (unsigned long long)k.ino); } };
+// keyed by the FILE (device, inode), not by the path string: two spellings of one path share one entry, a replaced file
+// gets a new one.  An entry only lives while reservations are in flight: once the last writer of a file has finished, the
+// next group starts again from the file's real end, so a file truncated between calls is not extended with a hole.
+std::unordered_map<ResKey, ResEntry, ResKeyHash> g_res;
+bool res_key(int fd, ResKey* k) { struct stat st; if (fstat(fd, &st) != 0) return false; k->dev = st.st_dev; k->ino = st.st_ino; return true; }
+off_t reserve_append(int fd, size_t total) {
   std::lock_guard<std::mutex> lk(g_res_mu);
   const off_t end = lseek(fd, 0, SEEK_END);
-  auto it = g_res_next.find(path);
-  off_t at = (it == g_res_next.end()) ? end : std::max(end, it->second);
-  g_res_next[path] = at + (off_t)total;
+  ResKey k;
+  if (!res_key(fd, &k)) return end;
+  ResEntry& e = g_res[k];
+  const off_t at = e.inflight > 0 ? std::max(end, e.next) : end;
+  e.next = at + (off_t)total; e.inflight++;
   return at;
+}
+void release_append(int fd) {
+  std::lock_guard<std::mutex> lk(g_res_mu);
+  ResKey k;
+  if (!res_key(fd, &k)) return;
+  auto it = g_res.find(k);
+  if (it != g_res.end() && --it->second.inflight <= 0) g_res.erase(it);
 }
 }  // namespace
 
-extern "C" void c3_writer_reset(void) { std::lock_guard<std::mutex> lk(g_res_mu); g_res_next.clear(); }
+extern "C" void c3_writer_reset(void) { std::lock_guard<std::mutex> lk(g_res_mu); g_res.clear(); }
 
 extern "C" int c3_write_group(const c3_host_batch* b, const c3_read_result* res, const char* cons, const int64_t* cons_off,
                               const int16_t* splint_id, int n_splints, const char* const* cons_paths,
@@ -446,7 +501,7 @@ extern "C" int c3_write_group(const c3_host_batch* b, const c3_read_result* res,
       int fd = open(path, O_WRONLY | O_CREAT, 0644);
       if (fd < 0) { ok = false; break; }
       fds.push_back(fd);
-      off_t at = reserve_append(path, fd, total);           // several writer threads (one per GPU worker) append to one file
+      off_t at = reserve_append(fd, total);                 // several writer threads (one per GPU worker) append to one file
       for (int k = 0; k < T; ++k) {
         const std::string& x = (kind ? os : oc)[(size_t)k][(size_t)s];
         if (!x.empty()) { jobs[(size_t)k].push_back({fd, &x, at}); at += (off_t)x.size(); }
@@ -463,7 +518,7 @@ extern "C" int c3_write_group(const c3_host_batch* b, const c3_read_result* res,
     for (auto& x : th) x.join();
     for (char g : good) ok = ok && g;
   }
-  for (int fd : fds) if (close(fd) != 0) ok = false;
+  for (int fd : fds) { release_append(fd); if (close(fd) != 0) ok = false; }
   return ok ? C3_E_OK : C3_E_ARG;
 }
 

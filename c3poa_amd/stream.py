@@ -113,6 +113,13 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
     N_SETS = 5
     readers = [_lib.Reader(args.reads, n_sets=N_SETS, byte_range=(cuts[k], cuts[k + 1])) if n_ranges > 1
                else _lib.Reader(args.reads, n_sets=N_SETS) for k in range(n_ranges)]
+    if n_ranges > 1 and any(r.range_lost() for r in readers):
+        # a range with bytes but no 4-line record start (multi-line FASTQ, which mm.fastx_read accepts): such a file cannot be
+        # entered in the middle -- its records would be dropped silently -- so ONE reader takes the whole file
+        for r in readers:
+            r.close()
+        n_ranges, cuts = 1, [0, -1]
+        readers = [_lib.Reader(args.reads, n_sets=N_SETS)]
     free_sets = [queue.Queue() for _ in range(n_ranges)]
     for fs in free_sets:
         for j in range(N_SETS):
@@ -135,6 +142,10 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                 t0 = time.perf_counter()
                 hb = rd.next(batch_reads, args.lencutoff, GPU_BATCH_BASES, set_index=ks)
                 t1 = time.perf_counter()
+                if rd.noqual():
+                    # C3POa.py:167 averages ord(q) - 33 over the read's quality string and racon is run with -q 5: records
+                    # without qualities cannot go through the reference either (it raises on qual = None)
+                    raise SystemExit("C3POa: %s holds records without base qualities (FASTA); the consensus caller needs FASTQ" % args.reads)
                 if hb.n == 0:
                     with lock:
                         t["short"] += hb.n_short

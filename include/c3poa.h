@@ -71,6 +71,9 @@ typedef struct {
   int32_t peaks[C3_MAX_PEAKS];
   int32_t sub_beg[C3_MAX_PEAKS], sub_end[C3_MAX_PEAKS];   /* pure slices of the read (C3POa.py:141-144) */
 } c3_read_result;
+/* ARRAY TAILS ARE UNSPECIFIED: c3_batch_results copies only the used prefix of peaks / sub_beg / sub_end across PCIe, so in the
+ * caller's records peaks[k] for k >= n_peaks and sub_beg[k] / sub_end[k] for k >= n_sub hold whatever the buffer held before
+ * (never read them; set C3_FULL_RESULTS=1 in the environment to get whole records, e.g. when diffing raw buffers). */
 
 /* kernel time of the last c3_batch_run, measured with hipEvents on the library's own stream */
 typedef struct {
@@ -225,6 +228,14 @@ int c3_reader_open(const char* path, int n_sets, c3_reader** out);
 int c3_reader_open_range(const char* path, int n_sets, int64_t beg, int64_t end, c3_reader** out);
 void c3_reader_close(c3_reader* r);
 const char* c3_reader_error(const c3_reader* r);
+/* records without a quality line seen so far (FASTA).  The reference cannot process them (C3POa.py:167 takes ord() of every
+ * quality character; racon runs with -q 5), so the CLI refuses such input */
+int64_t c3_reader_noqual(const c3_reader* r);
+/* bytes of (page-locked) host buffers the reader holds: sized by what its file / byte range can still deliver, never by max_reads alone */
+int64_t c3_reader_reserved_bytes(const c3_reader* r);
+/* 1 when c3_reader_open_range found bytes but no 4-line FASTQ / FASTA record start in its range (multi-line FASTQ): the caller
+ * must read the file with ONE reader (c3_reader_open), or the records of that range are lost */
+int c3_reader_range_lost(const c3_reader* r);
 /* names_only != 0: parse but do not store sequences/qualities (first pass of C3POa.py:200-207: names + counts) */
 void c3_reader_names_only(c3_reader* r, int names_only);
 /* next group: at most max_reads reads of length >= min_len (C3POa.py:202-204,240-241), stops early once max_bases
@@ -242,8 +253,9 @@ int c3_write_group(const c3_host_batch* b, const c3_read_result* res, const char
                    const char* const* sub_paths, int zero);
 
 /* c3_write_group may be called from several threads on the same files (one writer per GPU worker): every call reserves its
- * byte range at the end of each file under a lock.  c3_writer_reset forgets the reservations; call it after truncating the
- * output files at the start of a run. */
+ * byte range at the end of each file under a lock.  Reservations are keyed by the file itself (device, inode) and live only
+ * while a writer of that file is in flight: a file truncated or replaced between two calls is appended to from its real end.
+ * c3_writer_reset forgets all reservations (start of a run; never while c3_write_group calls are in flight). */
 void c3_writer_reset(void);
 
 /* splint assignment from the PSL (bin/preprocess.py:22-45) without per-read host objects: rows with qBaseInsert < 50 and

@@ -308,3 +308,83 @@ def test_byte_range_readers_tile_the_file(tmp_path):
                     got += [hb.read(i) for i in range(hb.n)]
                 rr.close()
             assert got == whole, (name, cuts)
+
+
+def test_tiny_input_does_not_pin_gigabytes(tmp_path):
+    """the reader's (page-locked) buffers are sized by what the file can deliver, not by max_reads: a 100-read input asked
+    for 131072-read batches with five buffer sets used to reserve ten buffers of that size"""
+    recs = [(r[0], r[1], r[2]) for r in synth.generate("cfg1", n_reads=100)]
+    p = str(tmp_path / "tiny.fastq")
+    _write_fastq(p, recs)
+    rd = _lib.Reader(p, n_sets=5)
+    hb = rd.next(131072, 0, 1 << 30, set_index=0)
+    assert hb.n == 100
+    assert rd.reserved_bytes() < 8 * os.path.getsize(p) + (4 << 20), rd.reserved_bytes()
+    assert [hb.read(i) for i in range(3)] == recs[:3]
+    # a byte-range reader is bounded by its range, not by the file
+    size = os.path.getsize(p)
+    rr = _lib.Reader(p, n_sets=5, byte_range=(size // 2, size))
+    hb2 = rr.next(131072, 0, 1 << 30, set_index=0)
+    assert 0 < hb2.n < 100 and rr.reserved_bytes() < 6 * size + (4 << 20)
+    rd.close(); rr.close()
+
+
+def test_writer_appends_at_the_real_end_after_a_truncate(tmp_path):
+    """reservations are keyed by the file and live only while a writer is in flight: truncating (or replacing) an output file
+    between two c3_write_group calls -- without c3_writer_reset -- must not leave a NUL-filled hole"""
+    rng = np.random.default_rng(4)
+    recs = [(r[0], r[1], r[2]) for r in synth.generate("cfg1", n_reads=20)]
+    p = str(tmp_path / "a.fastq")
+    _write_fastq(p, recs)
+    hb = _lib.Reader(p).next(100)
+    res, cons = _fake_results(rng, hb)
+    sid = np.zeros(hb.n, dtype=np.int16)
+    raw = "".join(cons).encode()
+    coff = np.zeros(hb.n + 1, dtype=np.int64)
+    np.cumsum([len(c) for c in cons], out=coff[1:])
+    cp, sp = [str(tmp_path / "c.fa")], [str(tmp_path / "s.fq")]
+    link = str(tmp_path / "alias.fa")
+    os.symlink(cp[0], link)                                               # a second spelling of the same file
+    _lib.write_group(hb, res, np.frombuffer(raw, dtype=np.uint8), coff, sid, cp, sp, True)
+    once_c, once_s = open(cp[0], "rb").read(), open(sp[0], "rb").read()
+    assert once_c and once_s and b"\0" not in once_c
+    open(cp[0], "w").close()                                              # truncate one file, replace the other
+    os.remove(sp[0])
+    _lib.write_group(hb, res, np.frombuffer(raw, dtype=np.uint8), coff, sid, [link], sp, True)
+    assert open(cp[0], "rb").read() == once_c and open(sp[0], "rb").read() == once_s
+    _lib.write_group(hb, res, np.frombuffer(raw, dtype=np.uint8), coff, sid, cp, sp, True)
+    assert open(cp[0], "rb").read() == once_c * 2 and open(sp[0], "rb").read() == once_s * 2
+
+
+def test_multi_line_fastq_ranges_are_reported_and_last_record_without_newline(tmp_path):
+    """mm.fastx_read accepts multi-line FASTQ; a byte-range reader cannot resync inside one and must SAY so instead of returning
+    an empty range (the records would be dropped silently).  The file's last record may lack its trailing newline."""
+    rng = np.random.default_rng(8)
+    recs = []
+    for i in range(60):
+        L = int(rng.integers(130, 300))
+        recs.append(("m%d" % i, "".join("ACGT"[k] for k in rng.integers(0, 4, L)), "".join(chr(40 + int(v)) for v in rng.integers(0, 30, L))))
+    wrap = lambda s: "\n".join(s[k:k + 60] for k in range(0, len(s), 60))      # noqa: E731
+    p = str(tmp_path / "multi.fastq")
+    open(p, "w").write("".join("@%s\n%s\n+\n%s\n" % (n, wrap(s), wrap(q)) for n, s, q in recs))
+    size = os.path.getsize(p)
+    whole = _lib.Reader(p, n_sets=1)
+    hb = whole.next(1000)
+    assert [hb.read(i) for i in range(hb.n)] == recs                         # the whole-file reader takes multi-line records
+    mid = _lib.Reader(p, n_sets=1, byte_range=(size // 2, size))
+    assert mid.range_lost()                                                  # ... a range reader reports that it cannot
+    # 4-line FASTQ whose last record has no trailing newline: the range that starts at that record still finds it
+    p2 = str(tmp_path / "nonl.fastq")
+    text = "".join("@%s\n%s\n+\n%s\n" % r for r in recs)
+    open(p2, "w").write(text[:-1])
+    last_start = text.rindex("@m59")
+    rr = _lib.Reader(p2, n_sets=1, byte_range=(last_start, -1))
+    hb2 = rr.next(10)
+    assert not rr.range_lost() and hb2.n == 1 and hb2.read(0) == recs[-1]
+    rr2 = _lib.Reader(p2, n_sets=1, byte_range=(last_start - 5, -1))
+    assert rr2.next(10).n == 1
+    assert _lib.Reader(p2, n_sets=1).noqual() == 0
+    pf = str(tmp_path / "x.fasta")
+    open(pf, "w").write(">a\nACGT\n>b\nGGCC\n")
+    rf = _lib.Reader(pf, n_sets=1)
+    assert rf.next(10).n == 2 and rf.noqual() == 2
