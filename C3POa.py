@@ -88,6 +88,8 @@ def main(args):
     for splint in fastx_read(args.splint_file):
         splint_dict[splint[0]] = [splint[1], revcomp(splint[1])]
     n_dev = max(1, min(max(1, args.numThreads), _lib.device_count()))        # -n = GPUs that share the groups
+    if os.environ.get("C3_DEVICE_MAP"):                                      # test hook: worker w -> device map[w] (e.g. "0,0": the -n 2
+        n_dev = max(1, min(max(1, args.numThreads), len(os.environ["C3_DEVICE_MAP"].split(","))))      # plumbing on a one-GPU box)
     align_psl = tmp_dir + "splint_to_read_alignments.psl"
     have_psl = os.path.exists(align_psl) and os.stat(align_psl).st_size > 0
     if not have_psl and getattr(args, "splint_finder", "gpu") == "gpu":

@@ -161,13 +161,22 @@ def main():
             other_recs[c] = (make_reads(c, min(OTHER_UNIQUE, DEFAULT_READS[c]), 0, effective_cores()), time.time() - t_)
 
     import torch
+    # test hook (tests/test_gpu_two_ranks.py): C3_BENCH_DEVICE_MAP="0,0" puts every rank on GPU 0 and the barrier / MAX go over
+    # gloo (RCCL refuses two ranks on one device) -- the rank / shard / device plumbing of the real worker path on a one-GPU box
+    dmap = os.environ.get("C3_BENCH_DEVICE_MAP")
+    device = int(dmap.split(",")[local_rank % len(dmap.split(","))]) if dmap else local_rank
+    backend = "gloo" if dmap else "nccl"
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the c3poa HIP backend has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(device)
+    local_rank = device
     from c3poa_amd import _lib
     md = synth.CONFIGS[a.cfg]["mdist"]
     h = _lib.Handle(device=local_rank, mdistcutoff=md)
@@ -227,12 +236,20 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tm = h.last_timing
     res, cbuf, coff = res_raw
     ok = res["status"] == 0
+    # digest of this rank's shard (status + consensus bytes of the last step): lets a test compare the union of the shards of an
+    # N-rank run with single-process results
+    import hashlib
+    digest = hashlib.sha1(res["status"].tobytes() + res["cons_len"].tobytes() + cbuf.tobytes()[:int(coff[-1])]).hexdigest()
+    digests = [digest]
+    if dist is not None:
+        digests = [None] * world
+        dist.all_gather_object(digests, digest)
 
     out = None
     if rank == 0:
@@ -269,7 +286,7 @@ def main():
                 a.cfg, n_unique, "" if reps == 1 else ", tiled x%d" % reps),
             "config": {"workload": "%s: %d reads/GPU/step, %s" % (a.cfg, a.reads, WORKLOAD_TEXT.get(a.cfg, "")),
                        "stages": "stage(H2D+pack, overlapped) | conk+peaks/split+POA+polish | results(D2H) | commit",
-                       "reads_per_gpu_step": a.reads,
+                       "reads_per_gpu_step": a.reads, "shard_digests": digests,
                        "consensus_ok": int(ok.sum()), "mean_read_len": float(lens.mean()),
                        "identity_vs_truth": {"mean": round(float(idents.mean()), 5), "median": round(float(np.median(idents)), 5), "reads": int(n_id)},
                        "resident_only_reads_per_s": round(a.reads * world / float(np.mean(run_s)), 1),

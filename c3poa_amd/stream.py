@@ -166,6 +166,9 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
 
     def device_thread(w):                           # one per GPU: c3_batch_run sizes its stages on the host, so it blocks
         dev = w % n_dev
+        if os.environ.get("C3_DEVICE_MAP"):             # test hook: worker -> physical device (two workers on one GPU)
+            dmap = [int(x) for x in os.environ["C3_DEVICE_MAP"].split(",")]
+            dev = dmap[dev % len(dmap)]
         mine = [k for k in range(n_ranges) if k % n_work == w]      # the ranges this worker serves, round-robin
         live = list(mine)
         rr = [0]
