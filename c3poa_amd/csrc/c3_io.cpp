@@ -358,65 +358,133 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
 // ---- writer ------------------------------------------------------------------------------------------------------
 namespace {
 
+// Output bytes are produced straight into slices of one pooled arena per call (kept across calls: after the first group no
+// page of it is faulted in again, nothing grows by copying).  A slice is sized from an upper bound of its records, so the
+// appender needs no capacity checks.
+struct Out {
+  char* p;
+  inline void put(char c) { *p++ = c; }
+  inline void app(const char* s, size_t n) { memcpy(p, s, n); p += n; }
+  inline void num(long long v) {                 // decimal, no allocation
+    char t[24]; int k = 0;
+    unsigned long long u = v < 0 ? (unsigned long long)(-v) : (unsigned long long)v;
+    do { t[k++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *p++ = '-';
+    while (k) *p++ = t[--k];
+  }
+};
+
 // str(round(sum / n, 2)) of Python: correctly rounded to 2 decimals, then the shortest repr (trailing zeros dropped,
 // one decimal kept) -- C3POa.py:168
-void avg_qual_text(const char* q, int64_t n, std::string& out) {
-  long long sum = 0;
-  for (int64_t i = 0; i < n; ++i) sum += (unsigned char)q[i] - 33;
+void avg_qual_text(const char* q, int64_t n, Out& out) {
+  unsigned long long sum = 0;
+  const unsigned char* u = (const unsigned char*)q;
+  for (int64_t i = 0; i < n; ++i) sum += u[i];                 // (vectorises; the -33 per base comes off afterwards)
+  const long long tot = (long long)sum - 33LL * n;
   char tmp[64];
-  int k = snprintf(tmp, sizeof(tmp), "%.2f", (double)sum / (double)n);
+  int k = snprintf(tmp, sizeof(tmp), "%.2f", (double)tot / (double)n);
   while (k > 0 && tmp[k - 1] == '0' && k >= 2 && tmp[k - 2] != '.') --k;
-  out.append(tmp, (size_t)k);
+  out.app(tmp, (size_t)k);
 }
 
-void fastq(std::string& o, const char* name, size_t nl, long idx, const char* s, const char* q, int64_t b, int64_t e) {
-  o.push_back('@'); o.append(name, nl); o.push_back('_'); o += std::to_string(idx); o.push_back('\n');
-  o.append(s + b, (size_t)(e - b)); o.append("\n+\n", 3); o.append(q + b, (size_t)(e - b)); o.push_back('\n');
+inline void fastq(Out& o, const char* name, size_t nl, long idx, const char* s, const char* q, int64_t b, int64_t e) {
+  o.put('@'); o.app(name, nl); o.put('_'); o.num(idx); o.put('\n');
+  o.app(s + b, (size_t)(e - b)); o.app("\n+\n", 3); o.app(q + b, (size_t)(e - b)); o.put('\n');
+}
+inline size_t fastq_bound(size_t nl, int64_t len) { return nl + 2 * (size_t)std::max<int64_t>(len, 0) + 32; }
+
+// which records does read i produce?  (one place for the rules of C3POa.py:115-132 / determine_consensus.py:57-77,108-114)
+struct Emit { bool any, cons; int ns; };
+inline Emit emit_of(const c3_read_result& r, int s, int n_splints, int zero, int64_t clen) {
+  Emit e = {false, false, r.n_sub};
+  if (s < 0 || s >= n_splints) return e;
+  if (r.status == C3_ST_NOT_ASSIGNED || r.status == C3_ST_NO_PEAKS || r.status == C3_ST_TOO_SHORT) return e;   // C3POa.py:115,125,131
+  const int nd = (r.has_front ? 1 : 0) + (r.has_tail ? 1 : 0);
+  if (r.n_sub == 0) { if (!(zero && nd == 2)) return e; }
+  else if (r.status == C3_ST_LIMIT) return e;
+  e.any = true; e.cons = r.status == C3_ST_OK && clen > 0;
+  return e;
 }
 
 }  // namespace
 
 namespace {
 
-// records of reads [i0, i1) appended to fa[s] / fq[s] (one string pair per splint)
-void format_range(const c3_host_batch* b, const c3_read_result* res, const char* cons, const int64_t* cons_off,
-                  const int16_t* splint_id, int n_splints, int zero, int i0, int i1,
-                  std::vector<std::string>& oc, std::vector<std::string>& os) {
+// upper bound of the bytes reads [i0, i1) append to the consensus / subread file of every splint
+void bound_range(const c3_host_batch* b, const c3_read_result* res, const char* cons, const int64_t* cons_off,
+                 const int16_t* splint_id, int n_splints, int zero, int i0, int i1, size_t* bc, size_t* bs) {
   for (int i = i0; i < i1; ++i) {
     const c3_read_result& r = res[i];
     const int s = splint_id[i];
-    if (s < 0 || s >= n_splints) continue;
-    if (r.status == C3_ST_NOT_ASSIGNED || r.status == C3_ST_NO_PEAKS || r.status == C3_ST_TOO_SHORT) continue;   // C3POa.py:115,125,131
+    const int64_t clen = cons ? cons_off[i + 1] - cons_off[i] : 0;
+    const Emit e = emit_of(r, s, n_splints, zero, clen);
+    if (!e.any) continue;
+    const size_t nl = (size_t)(b->name_off[i + 1] - b->name_off[i]);
+    const int64_t L = b->off[i + 1] - b->off[i];
+    size_t q = 0;
+    if (e.ns == 0) q = fastq_bound(nl, r.front_end) + fastq_bound(nl, L - r.tail_beg);
+    else {
+      for (int k = 0; k < e.ns; ++k) q += fastq_bound(nl, (int64_t)r.sub_end[k] - r.sub_beg[k]);
+      if (r.has_front) q += fastq_bound(nl, r.front_end);
+      if (r.has_tail) q += fastq_bound(nl, L - r.tail_beg);
+    }
+    bs[s] += q;
+    if (e.cons) bc[s] += nl + (size_t)clen + 96;
+  }
+}
+
+// records of reads [i0, i1) appended to oc[s] / os[s] (one slice pair per splint)
+void format_range(const c3_host_batch* b, const c3_read_result* res, const char* cons, const int64_t* cons_off,
+                  const int16_t* splint_id, int n_splints, int zero, int i0, int i1, Out* oc, Out* os) {
+  for (int i = i0; i < i1; ++i) {
+    const c3_read_result& r = res[i];
+    const int s = splint_id[i];
+    const int64_t clen = cons ? cons_off[i + 1] - cons_off[i] : 0;
+    const Emit e = emit_of(r, s, n_splints, zero, clen);
+    if (!e.any) continue;
     const char* name = b->names + b->name_off[i]; const size_t nl = (size_t)(b->name_off[i + 1] - b->name_off[i]);
     const char* seq = b->seqs + b->off[i]; const char* qual = b->quals + b->off[i];
     const int64_t L = b->off[i + 1] - b->off[i];
-    const int64_t clen = cons ? cons_off[i + 1] - cons_off[i] : 0;
-    const int ns = r.n_sub, nd = (r.has_front ? 1 : 0) + (r.has_tail ? 1 : 0);
-    std::string& fq = os[(size_t)s];
-    bool emit = false;
+    const int ns = e.ns;
+    Out& fq = os[s];
     if (ns == 0) {
-      if (!(zero && nd == 2)) continue;
       fastq(fq, name, nl, 0, seq, qual, 0, r.front_end);
       fastq(fq, name, nl, 1, seq, qual, r.tail_beg, L);
-      emit = (r.status == C3_ST_OK && clen > 0);
     } else {
-      if (r.status == C3_ST_LIMIT) continue;
       for (int k = 0; k < ns; ++k) fastq(fq, name, nl, k + 1, seq, qual, r.sub_beg[k], r.sub_end[k]);
       int j = 0;
       if (r.has_front) { fastq(fq, name, nl, 0, seq, qual, 0, r.front_end); ++j; }
       if (r.has_tail) fastq(fq, name, nl, j == 0 ? 0 : ns + 1, seq, qual, r.tail_beg, L);
-      emit = (r.status == C3_ST_OK && clen > 0);
     }
-    if (emit) {
-      std::string& fa = oc[(size_t)s];
-      fa.push_back('>'); fa.append(name, nl); fa.push_back('_');
+    if (e.cons) {
+      Out& fa = oc[s];
+      fa.put('>'); fa.app(name, nl); fa.put('_');
       avg_qual_text(qual, L, fa);
-      fa.push_back('_'); fa += std::to_string((long long)L); fa.push_back('_'); fa += std::to_string(ns);
-      fa.push_back('_'); fa += std::to_string((long long)clen); fa.push_back('\n');
-      fa.append(cons + cons_off[i], (size_t)clen); fa.push_back('\n');
+      fa.put('_'); fa.num((long long)L); fa.put('_'); fa.num(ns);
+      fa.put('_'); fa.num((long long)clen); fa.put('\n');
+      fa.app(cons + cons_off[i], (size_t)clen); fa.put('\n');
     }
   }
 }
+
+// pooled arenas: one per c3_write_group call in flight, grow-only, reused by later calls
+struct Arena { char* p = nullptr; size_t cap = 0; };
+std::mutex g_arena_mu;
+std::vector<Arena> g_arena_free;
+Arena arena_get(size_t need) {
+  Arena a;
+  {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    size_t best = (size_t)-1;
+    for (size_t k = 0; k < g_arena_free.size(); ++k)
+      if (g_arena_free[k].cap >= need && (best == (size_t)-1 || g_arena_free[k].cap < g_arena_free[best].cap)) best = k;
+    if (best == (size_t)-1 && !g_arena_free.empty()) best = 0;                 // too small: take one and grow it
+    if (best != (size_t)-1) { a = g_arena_free[best]; g_arena_free.erase(g_arena_free.begin() + (long)best); }
+  }
+  if (a.cap < need) { free(a.p); a.cap = need + need / 8 + 4096; a.p = (char*)malloc(a.cap); if (!a.p) a.cap = 0; }
+  return a;
+}
+void arena_put(Arena a) { if (a.p) { std::lock_guard<std::mutex> lk(g_arena_mu); g_arena_free.push_back(a); } }
 
 bool pwrite_all(int fd, const char* p, size_t n, off_t at) {
   while (n) {
@@ -474,21 +542,31 @@ extern "C" int c3_write_group(const c3_host_batch* b, const c3_read_result* res,
                               const char* const* sub_paths, int zero) {
   if (!b || !res || !cons_off || !splint_id || n_splints <= 0 || !cons_paths || !sub_paths) return C3_E_ARG;
   int T = 1;
-  if (b->n >= 4096) { T = 8; if (const char* e = getenv("C3_WRITER_THREADS")) T = std::max(1, std::min(32, atoi(e))); }
-  typedef std::vector<std::string> Strs;
-  std::vector<Strs> oc((size_t)T, Strs((size_t)n_splints)), os((size_t)T, Strs((size_t)n_splints));
-  // phase 1: format (parallel)
-  {
+  if (b->n >= 4096) { T = 8; if (const char* e = getenv("C3_WRITER_THREADS")) T = std::max(1, std::min(64, atoi(e))); }
+  const size_t NS = (size_t)n_splints;
+  auto range = [&](int k, int* i0, int* i1) { *i0 = (int)((int64_t)b->n * k / T); *i1 = (int)((int64_t)b->n * (k + 1) / T); };
+  auto run_all = [&](auto&& fn) {
     std::vector<std::thread> th;
-    for (int k = 0; k < T; ++k) {
-      const int i0 = (int)((int64_t)b->n * k / T), i1 = (int)((int64_t)b->n * (k + 1) / T);
-      auto fn = [&, k, i0, i1]() { format_range(b, res, cons, cons_off, splint_id, n_splints, zero, i0, i1, oc[(size_t)k], os[(size_t)k]); };
-      if (k + 1 < T) th.emplace_back(fn); else fn();
-    }
+    for (int k = 0; k < T; ++k) { if (k + 1 < T) th.emplace_back(fn, k); else fn(k); }
     for (auto& x : th) x.join();
-  }
+  };
+  // phase 0: size of every (thread, kind, splint) slice from an upper bound of its records; one pooled arena holds them all
+  std::vector<size_t> bc((size_t)T * NS, 0), bs((size_t)T * NS, 0);
+  run_all([&](int k) { int i0, i1; range(k, &i0, &i1); bound_range(b, res, cons, cons_off, splint_id, n_splints, zero, i0, i1, &bc[(size_t)k * NS], &bs[(size_t)k * NS]); });
+  size_t need = 64;
+  for (size_t x : bc) need += x;
+  for (size_t x : bs) need += x;
+  Arena ar = arena_get(need);
+  if (!ar.p) return C3_E_NOMEM;
+  std::vector<char*> sc((size_t)T * NS), ss((size_t)T * NS);             // slice starts
+  { char* p = ar.p; for (size_t x = 0; x < (size_t)T * NS; ++x) { sc[x] = p; p += bc[x]; ss[x] = p; p += bs[x]; } }
+  std::vector<Out> oc((size_t)T * NS), os((size_t)T * NS);
+  for (size_t x = 0; x < (size_t)T * NS; ++x) { oc[x].p = sc[x]; os[x].p = ss[x]; }
+  // phase 1: format (parallel), straight into the slices
+  run_all([&](int k) { int i0, i1; range(k, &i0, &i1); format_range(b, res, cons, cons_off, splint_id, n_splints, zero, i0, i1, &oc[(size_t)k * NS], &os[(size_t)k * NS]); });
+  if (getenv("C3_WRITER_NO_IO")) { arena_put(ar); return C3_E_OK; }      // diagnostic (tools/formatter_throughput.py): the formatter alone
   // phase 2: one pwrite stream per (thread, file), offsets from the current file size
-  struct Job { int fd; const std::string* txt; off_t at; };
+  struct Job { int fd; const char* txt; size_t len; off_t at; };
   std::vector<std::vector<Job>> jobs((size_t)T);
   std::vector<int> fds;
   bool ok = true;
@@ -496,28 +574,26 @@ extern "C" int c3_write_group(const c3_host_batch* b, const c3_read_result* res,
     for (int kind = 0; kind < 2 && ok; ++kind) {
       const char* path = kind ? sub_paths[s] : cons_paths[s];
       size_t total = 0;
-      for (int k = 0; k < T; ++k) total += (kind ? os : oc)[(size_t)k][(size_t)s].size();
+      for (int k = 0; k < T; ++k) { const size_t x = (size_t)k * NS + (size_t)s; total += kind ? (size_t)(os[x].p - ss[x]) : (size_t)(oc[x].p - sc[x]); }
       if (!total || !path) continue;
       int fd = open(path, O_WRONLY | O_CREAT, 0644);
       if (fd < 0) { ok = false; break; }
       fds.push_back(fd);
       off_t at = reserve_append(fd, total);                 // several writer threads (one per GPU worker) append to one file
       for (int k = 0; k < T; ++k) {
-        const std::string& x = (kind ? os : oc)[(size_t)k][(size_t)s];
-        if (!x.empty()) { jobs[(size_t)k].push_back({fd, &x, at}); at += (off_t)x.size(); }
+        const size_t x = (size_t)k * NS + (size_t)s;
+        const char* t0 = kind ? ss[x] : sc[x];
+        const size_t len = kind ? (size_t)(os[x].p - ss[x]) : (size_t)(oc[x].p - sc[x]);
+        if (len) { jobs[(size_t)k].push_back({fd, t0, len, at}); at += (off_t)len; }
       }
     }
   }
   if (ok) {
     std::vector<char> good((size_t)T, 1);
-    std::vector<std::thread> th;
-    for (int k = 0; k < T; ++k) {
-      auto fn = [&, k]() { for (const Job& j : jobs[(size_t)k]) if (!pwrite_all(j.fd, j.txt->data(), j.txt->size(), j.at)) good[(size_t)k] = 0; };
-      if (k + 1 < T) th.emplace_back(fn); else fn();
-    }
-    for (auto& x : th) x.join();
+    run_all([&](int k) { for (const Job& j : jobs[(size_t)k]) if (!pwrite_all(j.fd, j.txt, j.len, j.at)) good[(size_t)k] = 0; });
     for (char g : good) ok = ok && g;
   }
+  arena_put(ar);
   for (int fd : fds) { release_append(fd); if (close(fd) != 0) ok = false; }
   return ok ? C3_E_OK : C3_E_ARG;
 }
