@@ -290,10 +290,13 @@ template <class T> struct WArr {
 struct WCtx {
   int* I; int* E; uint8_t* B8; long long* score; int32_t* H; uint8_t* D; uint4* rdesc;
   int K, n, Ncap; long long hcap;
+  int osel = 0;                  // which of the two order buffers is current (w_reorder writes the other one and flips)
 #define W_I(name, k) __device__ __forceinline__ WArr<int> name() const { return {I, (unsigned)(k) * (unsigned)Ncap}; }
-  W_I(n_in, 0) W_I(n_out, 1) W_I(grp, 2) W_I(order, 3) W_I(order2, 4) W_I(index, 5) W_I(gfirst, 6) W_I(glast, 7) W_I(ncov, 8)
+  W_I(n_in, 0) W_I(n_out, 1) W_I(grp, 2) W_I(index, 5) W_I(gfirst, 6) W_I(glast, 7) W_I(ncov, 8)
   W_I(rowof, 9) W_I(anchor, 10) W_I(pred, 11) W_I(hend, 11) /* shares pred (disjoint lifetimes) */ W_I(opn, 12) /* 2N */ W_I(opq, 14) /* 2N */
   W_I(rows, 16) /* N+1 */
+  __device__ __forceinline__ WArr<int> order() const { return {I, (unsigned)(3 + osel) * (unsigned)Ncap}; }
+  __device__ __forceinline__ WArr<int> order2() const { return {I, (unsigned)(4 - osel) * (unsigned)Ncap}; }
   __device__ __forceinline__ WArr<int> lob() const { return {I, 17u * (unsigned)Ncap + 8u}; }   /* N+1: band start | block index << 16 of every DP row */
 #undef W_I
   __device__ __forceinline__ WArr<int> in_from() const { return {E, 0u}; }
@@ -305,21 +308,28 @@ struct WCtx {
 };
 #define W_INTS 19   // ints of Ncap per slot in WCtx::I (18*Ncap + 9 used)
 
+// The graph phases are chains of dependent memory round trips (position -> node -> its group / edges ...), and a wave that
+// waits for one has nothing else to do: every loop over the nodes therefore takes WU chunks of 64 per iteration, all loads of
+// one level issued back to back, so a level costs ONE memory latency per WU*64 nodes instead of one per 64.
+#define WU 4
 __device__ void w_blocks(WCtx& c, int lane) {
   // The members of an aligned block are CONTIGUOUS in the topological order (a new sibling is merged right behind its
-  // block), so a block's extent is a run of equal group ids: its first / last position are where the id changes --
-  // plain stores, no initialisation pass, no atomics.
-  for (int i0 = 0; i0 < c.n; i0 += 64) {
-    const int i = i0 + lane;
-    const bool live = i < c.n;
-    const int r = live ? c.grp()[c.order()[i]] : -2;
-    int rp = __builtin_amdgcn_update_dpp(-1, r, 0x138, 0xf, 0xf, false);          // lane - 1 (wave_shr:1)
-    int rn = __builtin_amdgcn_update_dpp(-1, r, 0x130, 0xf, 0xf, false);          // lane + 1 (wave_shl:1)
-    if (lane == 0 && i > 0) rp = c.grp()[c.order()[i - 1]];
-    if (lane == 63 && i + 1 < c.n) rn = c.grp()[c.order()[i + 1]];
-    if (live) {
-      if (r != rp) c.gfirst()[r] = i;
-      if (r != rn || i + 1 >= c.n) c.glast()[r] = i;
+  // block), so a block's extent is a run of equal group ids: where the id changes, the new block starts and the previous one
+  // ends -- plain stores, no initialisation pass, no atomics, no look-ahead.
+  int gprev = -1;                                                       // group of position i0 - 1
+  for (int i0 = 0; i0 < c.n; i0 += 64 * WU) {
+    int v[WU], r[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) { const int i = i0 + 64 * u + lane; v[u] = i < c.n ? c.order()[i] : -1; }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) r[u] = v[u] >= 0 ? c.grp()[v[u]] : -2;
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      const int i = i0 + 64 * u + lane;
+      const int rp = wave_shr1(r[u], gprev);
+      gprev = wave_bcast(r[u], 63);
+      if (v[u] >= 0 && r[u] != rp) { c.gfirst()[r[u]] = i; if (i > 0) c.glast()[rp] = i - 1; }
+      if (v[u] >= 0 && i + 1 == c.n) c.glast()[r[u]] = i;
     }
   }
   WSYNC();
@@ -328,33 +338,27 @@ __device__ void w_reorder(WCtx& c, int n_old, int lane, int* lds, int lds_cap) {
   const int n_new = c.n - n_old;
   // old node at old index i moves to i + #(anchor < i); new node k goes to anchor[k] + 1 + k.  The (sorted) anchors of the new
   // nodes are staged in LDS first: the binary search per old node is then 6-8 LDS reads instead of 6-8 dependent global loads
-  // per 64 nodes (the LDS scratch of the alignment is idle during the graph phases)
-  if (n_new <= lds_cap) {
-    for (int k = lane; k < n_new; k += 64) lds[k] = c.anchor()[k];
-    WSYNC();
-    for (int i = lane; i < n_old; i += 64) {
+  // per 64 nodes (the LDS scratch of the alignment is idle during the graph phases).  The new order is written to the OTHER
+  // order buffer together with index[], and the buffers swap roles: no copy-back pass.
+  const bool inl = n_new <= lds_cap;
+  if (inl) { for (int k = lane; k < n_new; k += 64) lds[k] = c.anchor()[k]; WSYNC(); }
+  for (int i0 = 0; i0 < n_old; i0 += 64 * WU) {
+    int v[WU];
+#pragma unroll
+    for (int u = 0; u < WU; ++u) { const int i = i0 + 64 * u + lane; v[u] = i < n_old ? c.order()[i] : -1; }
+#pragma unroll
+    for (int u = 0; u < WU; ++u) {
+      const int i = i0 + 64 * u + lane;
+      if (v[u] < 0) continue;
       int lo = 0, hi = n_new;                 // first k with anchor[k] >= i
-      while (lo < hi) { int m = (lo + hi) >> 1; if (lds[m] < i) lo = m + 1; else hi = m; }
-      c.order2()[i + lo] = c.order()[i];
+      if (inl) { while (lo < hi) { int m = (lo + hi) >> 1; if (lds[m] < i) lo = m + 1; else hi = m; } }
+      else { while (lo < hi) { int m = (lo + hi) >> 1; if (c.anchor()[m] < i) lo = m + 1; else hi = m; } }
+      c.order2()[i + lo] = v[u]; c.index()[v[u]] = i + lo;
     }
-    for (int k = lane; k < n_new; k += 64) c.order2()[lds[k] + 1 + k] = n_old + k;
-    WSYNC();                                  // (the LDS words are free again)
-  } else {
-    for (int i = lane; i < n_old; i += 64) {
-      int lo = 0, hi = n_new;
-      while (lo < hi) { int m = (lo + hi) >> 1; if (c.anchor()[m] < i) lo = m + 1; else hi = m; }
-      c.order2()[i + lo] = c.order()[i];
-    }
-    for (int k = lane; k < n_new; k += 64) c.order2()[c.anchor()[k] + 1 + k] = n_old + k;
-    WSYNC();
   }
-#ifdef C3_EXP_X2_RFIN
-  for (int i = lane; i < c.n; i += 64) { int v = c.order2()[i]; c.order()[i] = v; c.index()[v] = i; }
-  WSYNC();
-  w_blocks(c, lane);
-#endif
-  for (int i = lane; i < c.n; i += 64) { int v = c.order2()[i]; c.order()[i] = v; c.index()[v] = i; }
-  WSYNC();
+  for (int k = lane; k < n_new; k += 64) { const int pos = (inl ? lds[k] : c.anchor()[k]) + 1 + k; c.order2()[pos] = n_old + k; c.index()[n_old + k] = pos; }
+  c.osel ^= 1;
+  WSYNC();                                  // (the LDS words are free again)
   w_blocks(c, lane);
 }
 
@@ -994,6 +998,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
       else { for (int i = lane; i < blen; i += 64) out[i] = bb[i]; olen = blen; }
     } else {
       // ---- backbone chain (weight-0 edges, coverage 1)
+      c.osel = 0;
       for (int i = lane; i < blen; i += 64) {
         c.base()[i] = bb[i]; c.grp()[i] = i; c.order()[i] = i; c.index()[i] = i; c.ncov()[i] = 1;
         c.n_in()[i] = i > 0; c.n_out()[i] = i + 1 < blen;
@@ -1049,16 +1054,21 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
 #ifdef C3_EXP_X2_COMP
         for (int rep_ = 0; rep_ < 2; ++rep_) { R = 0;
 #endif
-        for (int i0 = 0; i0 < c.n; i0 += 64) {        // order-preserving compaction
-          const int i = i0 + lane;
-          const int v = i < c.n ? c.order()[i] : 0;
-          const bool in = i < c.n && (full || c.mask()[v]);
-          const unsigned long long bal = __ballot(in);
-          if (i < c.n) {
-            if (in) { int r = R + 1 + __popcll(bal & ((1ull << lane) - 1)); c.rows()[r] = v; c.rowof()[v] = r; }
-            else c.rowof()[v] = -1;
+        for (int i0 = 0; i0 < c.n; i0 += 64 * WU) {   // order-preserving compaction, WU chunks of 64 positions per iteration
+          int v[WU]; bool in[WU];
+#pragma unroll
+          for (int u = 0; u < WU; ++u) { const int i = i0 + 64 * u + lane; v[u] = i < c.n ? c.order()[i] : -1; }
+#pragma unroll
+          for (int u = 0; u < WU; ++u) in[u] = v[u] >= 0 && (full || c.mask()[v[u]]);
+#pragma unroll
+          for (int u = 0; u < WU; ++u) {
+            const unsigned long long bal = __ballot(in[u]);
+            if (v[u] >= 0) {
+              if (in[u]) { int r = R + 1 + __popcll(bal & ((1ull << lane) - 1)); c.rows()[r] = v[u]; c.rowof()[v[u]] = r; }
+              else c.rowof()[v[u]] = -1;
+            }
+            R += __popcll(bal);
           }
-          R += __popcll(bal);
         }
 #ifdef C3_EXP_X2_COMP
         WSYNC(); }
