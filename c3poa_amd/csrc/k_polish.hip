@@ -287,6 +287,15 @@ template <class T> struct WArr {
   __device__ __forceinline__ T& operator[](size_t i) const { return at((unsigned)i); }
   __device__ __forceinline__ T* ptr() const { return base + off; }
 };
+// rq / tq of one layer (DP row and node of every query base): in LDS when the layer has at most W_QCAP bases (every layer of a
+// 500-base window in practice), in the slot's global arrays otherwise.  The traceback's stores and the fusion's loads of these
+// two small arrays were a sixth of the graph phases' vector memory instructions.
+#define W_QCAP 1024
+struct QArr {
+  unsigned short* l; WArr<int> g; bool big;
+  __device__ __forceinline__ int get(int i) const { return big ? g[i] : (int)l[i]; }
+  __device__ __forceinline__ void set(int i, int v) const { if (big) g[i] = v; else l[i] = (unsigned short)v; }
+};
 struct WCtx {
   int* I; int* E; uint8_t* B8; long long* score; int32_t* H; uint8_t* D; uint4* rdesc;
   int K, n, Ncap; long long hcap;
@@ -1082,7 +1091,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
           int nblocks = 0;
           if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, d0bits, d1bits, ring_off, lds_ints, l.begin, l.end, blen, &cb, &nblocks) < 0) { fail = 1; break; }
 #ifdef C3_PHASE_PROF
-          ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1]; ph_acc_[15] += dbg_[5];
+          ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1];
 #endif
           PH_MARK(3)
           cells_done += (long long)(R + 1) * (cb ? 64 * cb : Q + 1);
@@ -1116,14 +1125,17 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         // LDS read: the wave checks 64 cells down the diagonal at once ("diagonal move from the row above"?), consumes the
         // run, and resolves the cell that breaks it.  One memory round trip per 64 rows instead of one per break -- and
         // the traceback no longer fetches about as many bytes as the fill wrote.
-        const WArr<int> rq = c.opq(), tq = c.opn();
+        // (LDS behind the traceback windows: 512 dwords in, 2 x W_QCAP shorts)
+        const QArr rq = {(unsigned short*)((unsigned*)lds_dyn + ring_off + 512), c.opq(), Q > W_QCAP};
+        const QArr tq = {(unsigned short*)((unsigned*)lds_dyn + ring_off + 512) + W_QCAP, c.opn(), Q > W_QCAP};
+        unsigned long long tbp_[4] = {0, 0, 0, 0};
 #ifdef C3_PHASE_PROF
         unsigned long long tbc_[3] = {0, 0, 0};
 #endif
 #ifdef C3_EXP_X2_TB
         for (int tbrep = 0; tbrep < 2; ++tbrep)
 #endif
-        if (cb) win_traceback_band(c, cb, R, Q, (gbs == INT32_MIN) ? 0 : gbr, m2bits, mabits, d0bits, d1bits, (unsigned*)lds_dyn + ring_off, rq, lane);
+        if (cb) win_traceback_band(c.I, c.E, c.D, c.rdesc, c.K, c.n, c.Ncap, cb, R, Q, (gbs == INT32_MIN) ? 0 : gbr, MW, Q > W_QCAP, tbp_);
         else
         {
           unsigned* WD = (unsigned*)lds_dyn + ring_off;       // [64][4] dwords, behind the row-type bitmasks
@@ -1131,7 +1143,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
           const int tb = cpl <= 8 ? 2 : 4;                                       // bytes per lane of a 2-bit row
           int r = (gbs == INT32_MIN) ? 0 : gbr, j = Q;
           while (r > 0 || j > 0) {
-            if (r == 0) { for (int q = lane; q < j; q += 64) rq[q] = 0; break; }
+            if (r == 0) { for (int q = lane; q < j; q += 64) rq.set(q, 0); break; }
             if (j == 0) break;                                   // only vertical moves remain
             const int rt = r, jt = j;
             const int rk = rt - lane;
@@ -1165,7 +1177,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
               const bool hit = val && bo >= 0 && bo + (two ? tb : 1) <= 16;
               const unsigned wv = WD[lane * 4 + (min(max(bo, 0), 15) >> 2)];
               int d, prow = -1;
-              if (two) { const unsigned cellw = tb == 2 ? (wv >> (8 * (bo & 2))) & 0xffffu : wv; d = 63 + 64 * (int)((cellw >> (2 * cw)) & 3u); prow = adj ? rk - 1 : -3; }
+              if (two) { const unsigned cellw = tb == 2 ? (wv >> (8 * (bo & 2))) & 0xffffu : wv; d = 63 + 64 * (int)((cellw >> (2 * cw)) & 3u); prow = adj ? rk - 1 : (int)(de.y & 0xffff); }     /* a single predecessor: the descriptor this lane holds names it (no reload at a break) */
               else {
                 d = (int)((wv >> (8 * (bo & 3))) & 0xffu);
                 if (win_d_type(d) != 2) prow = ((de.x >> 16) & 1) ? -2 : win_pred_row(c, de, rk, win_d_pred(d));
@@ -1173,7 +1185,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
               const bool diag1 = hit && jk >= 1 && win_d_type(d) == 0 && prow == rk - 1;
               const unsigned long long bal = __ballot(diag1) >> s;
               const int m = (~bal) ? __builtin_ctzll(~bal) : 64;  // length of the diagonal run
-              if (lane >= s && lane < s + m) rq[jk - 1] = rk;
+              if (lane >= s && lane < s + m) rq.set(jk - 1, rk);
               r -= m; j -= m;
               if (s + m >= 64 || r <= 0 || j <= 0) break;
               // the breaking cell (r, j) sits in lane cl
@@ -1193,10 +1205,10 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
                 }
               }
               const int ty = win_d_type(db);
-              if (ty == 2) { if (lane == 0) rq[j - 1] = 0; --j; }
+              if (ty == 2) { if (lane == 0) rq.set(j - 1, 0); --j; }
               else {
                 if (pb <= -2) pb = win_pred_row(c, c.rdesc[r], r, win_d_pred(db));   // > 4 predecessors, a 2-bit row whose predecessor is not r-1, or a window miss
-                if (ty == 0) { if (lane == 0) rq[j - 1] = r; --j; }
+                if (ty == 0) { if (lane == 0) rq.set(j - 1, r); --j; }
                 r = pb;
               }
               if (r <= 0 || j <= 0) break;
@@ -1209,7 +1221,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         WSYNC();
         PH_MARK(5)
 #ifdef C3_PHASE_PROF
-        ph_acc_[12] += tbc_[0]; ph_acc_[13] += tbc_[1]; ph_acc_[14] += tbc_[2];       // traceback census: blocks, steps, window misses (overrides the row-kind cycles)
+        ph_acc_[12] += tbp_[0]; ph_acc_[13] += tbp_[1]; ph_acc_[14] += tbp_[2]; ph_acc_[15] += tbp_[3];       // traceback census: blocks, steps, window misses (overrides the row-kind cycles)
 #endif
         // ---- fusion, parallel over the query bases (every graph node is touched by at most one base)
         const int n_old = c.n;
@@ -1217,7 +1229,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         for (int q0 = 0; q0 < Q; q0 += 64) {
           const int q = q0 + lane;
           const bool act = q < Q;
-          const int r = act ? rq[q] : 0;
+          const int r = act ? rq.get(q) : 0;
           const int v = r > 0 ? c.rows()[r] : -1;
           const int cb = act ? c3_code_at(pk, l.qbeg + q) : 0;
           int tgt = -1, gnew = -1, anc = -1;
@@ -1242,17 +1254,17 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
             }
             tgt = id;
           }
-          if (act) tq[q] = tgt;
+          if (act) tq.set(q, tgt);
         }
         const int nn = n_old + carry_new;
         if (nn > c.Ncap) { fail = 1; break; }
         WSYNC();
         const int K = c.K;
         for (int q = lane; q < Q; q += 64) {
-          const int v = tq[q];
+          const int v = tq.get(q);
           c.ncov()[v] += 1;
           if (q == 0) continue;
-          const int u = tq[q - 1];
+          const int u = tq.get(q - 1);
           const int w = ((int)qual[l.qbeg + q - 1] - 33) + ((int)qual[l.qbeg + q] - 33);
           const int no = c.n_out()[u];
           int hit = -1;

@@ -72,64 +72,102 @@ __device__ int win_build_desc_band(WCtx& c, int R, int Q, int begin, int end, in
   const int BW = 64 * CB, WLf = wb_left(CB), span = end - begin + 1, lomax = Q + 1 - BW;
   if (R >= 16000 || Q > 1000) return 0;
   int bbc = begin - 1, loc = 0, nbc = 0, gprev = -1, bad = 0;
-  for (int r0 = 1; r0 <= R; r0 += 64) {
-    const int r = r0 + lane;
-    const bool live = r <= R;
-    const int v = live ? c.rows()[r] : 0;
-    // backbone position reached so far -> band start (non-decreasing)
-    const int bbs = max(wave_scan_max(live && v < blen ? v : -1), bbc);
-    bbc = wave_bcast(bbs, 63);
-    const int cen = (int)(((long long)(bbs - begin + 1) * Q + span / 2) / span);
-    const int lo = min(max(cen - WLf, 0), lomax);
-    const int lop = wave_shr1(lo, loc);                               // lo of the row above
-    loc = wave_bcast(lo, 63);
-    const int dl = live ? lo - lop : 0;
-    if (dl > 3) bad = 1;
-    // aligned blocks: runs of equal group ids in the row order
-    const int gr = live ? c.grp()[v] : -2;
-    const int grp_ = wave_shr1(gr, gprev);
-    gprev = wave_bcast(gr, 63);
-    const unsigned long long bs = __ballot(live && gr != grp_);
-    const int bidx = nbc + __popcll(bs & ((2ull << lane) - 1));
-    nbc += __popcll(bs);
-    bool two = false, adj = false;
-    unsigned p[4] = {0, 0, 0, 0}, has = 0, far = 0, fast = 0, other = 0, next = 0, virt = 0, ovf = 0, vb = 0;
-    int np = 0, dist = 0;
-    if (live) {
-      const int nin = c.n_in()[v], nout = c.n_out()[v];
-      vb = (unsigned)c.base()[v] & 3u;
-      for (int k = 0; k < nin; ++k) {
-        const int pr = c.rowof()[c.in_from()[EI(v, k)]];
-        if (pr < 0) continue;
-        if (np < 4) p[np] = (unsigned)pr;
-        ++np;
-      }
-      for (int k = 0; k < nout; ++k) {
-        const int sr = c.rowof()[c.out_to()[EI(v, k)]];
-        if (sr < 0) continue;
-        has = 1; dist = max(dist, sr - r);
-        if (sr == r + 1) next = 1; else other = 1;
-      }
-      far = dist > WB_RING;
-      if (dist > 64) bad = 1;                                          // (the certificate reads the shifts of at most 64 rows)
-      ovf = np > 4; virt = np == 0;
-      if (np == 0) np = 1;
-      two = np == 1;
-      adj = two && (int)p[0] == r - 1;
-      fast = adj && !far && has && dl <= 1;
+#ifndef WB_DU
+#define WB_DU 1
+#endif
+  constexpr int DU = WB_DU;                                               // 64-row chunks per iteration: the loads of one level go out together
+  for (int rb = 1; rb <= R; rb += 64 * DU) {
+    int v[DU], nin[DU], nout[DU], gr[DU], pe[DU][4], se[DU][4];
+    unsigned vb[DU];
+#pragma unroll
+    for (int u = 0; u < DU; ++u) { const int r = rb + 64 * u + lane; v[u] = r <= R ? c.rows()[r] : -1; }
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const bool live = v[u] >= 0;
+      nin[u] = live ? c.n_in()[v[u]] : 0; nout[u] = live ? c.n_out()[v[u]] : 0;
+      vb[u] = live ? (unsigned)c.base()[v[u]] & 3u : 0u; gr[u] = live ? c.grp()[v[u]] : -2;
     }
-    // wr: a successor other than the row below, or the row below is not a fast row (its kind sits one lane up; the last
-    // lane of a step does not see it and writes the ring to be safe)
-    const unsigned fastn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)fast, 0x130, 0xf, 0xf, false);       // wave_shl:1
-    if (live) {
-      const unsigned wr = other | (next & (fastn ^ 1u));
-      uint4 d; d.x = vb * 8u | ((unsigned)min(np, 255) << 8) | (ovf << 16) | (far << 17) | ((has ^ 1u) << 18) | ((unsigned)two << 19) | (fast << 20)
-                     | ((unsigned)(fast ? dl : 0) << 22) | (wr << 23) | (virt << 24);
-      d.y = p[0] | (p[1] << 16); d.z = p[2] | (p[3] << 16); d.w = (unsigned)lo | ((unsigned)min(dist, 255) << 10) | ((unsigned)bidx << 18);
-      c.rdesc[r] = d;
+    int kmax = 0;
+#pragma unroll
+    for (int u = 0; u < DU; ++u) kmax = max(kmax, max(nin[u], nout[u]));
+    kmax = min(wave_max(kmax), 4);
+    // first four in- / out-edges of every row (slot-major adjacency: independent loads), then the rows of their nodes
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+      for (int u = 0; u < DU; ++u) { pe[u][k] = -1; se[u][k] = -1; }
+      if (k < kmax) {
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+          if (k < nin[u]) pe[u][k] = c.in_from()[EI(v[u], k)];
+          if (k < nout[u]) se[u][k] = c.out_to()[EI(v[u], k)];
+        }
+      }
     }
-    const unsigned long long b2 = __ballot(two), ba = __ballot(adj), bd0 = __ballot(dl & 1), bd1 = __ballot((dl & 2) != 0);
-    if (lane == 0) { m2[r0 >> 6] = b2; ma[r0 >> 6] = ba; d0[r0 >> 6] = bd0; d1[r0 >> 6] = bd1; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (k < kmax) {
+#pragma unroll
+        for (int u = 0; u < DU; ++u) {
+          if (pe[u][k] >= 0) pe[u][k] = c.rowof()[pe[u][k]];
+          if (se[u][k] >= 0) se[u][k] = c.rowof()[se[u][k]];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < DU; ++u) {
+      const int r0 = rb + 64 * u, r = r0 + lane;
+      if (r0 > R) break;
+      const bool live = v[u] >= 0;
+      // backbone position reached so far -> band start (non-decreasing)
+      const int bbs = max(wave_scan_max(live && v[u] < blen ? v[u] : -1), bbc);
+      bbc = wave_bcast(bbs, 63);
+      const int cen = (int)(((long long)(bbs - begin + 1) * Q + span / 2) / span);
+      const int lo = min(max(cen - WLf, 0), lomax);
+      const int lop = wave_shr1(lo, loc);                               // lo of the row above
+      loc = wave_bcast(lo, 63);
+      const int dl = live ? lo - lop : 0;
+      if (dl > 3) bad = 1;
+      // aligned blocks: runs of equal group ids in the row order
+      const int grp_ = wave_shr1(gr[u], gprev);
+      gprev = wave_bcast(gr[u], 63);
+      const unsigned long long bs = __ballot(live && gr[u] != grp_);
+      const int bidx = nbc + __popcll(bs & ((2ull << lane) - 1));
+      nbc += __popcll(bs);
+      bool two = false, adj = false;
+      unsigned p[4] = {0, 0, 0, 0}, has = 0, far = 0, fast = 0, other = 0, next = 0, virt = 0, ovf = 0;
+      int np = 0, dist = 0;
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (pe[u][k] >= 0) { p[np < 4 ? np : 3] = (unsigned)pe[u][k]; ++np; }
+        for (int k = 4; k < nin[u]; ++k) { const int pr = c.rowof()[c.in_from()[EI(v[u], k)]]; if (pr >= 0) ++np; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) if (se[u][k] >= 0) { has = 1; dist = max(dist, se[u][k] - r); if (se[u][k] == r + 1) next = 1; else other = 1; }
+        for (int k = 4; k < nout[u]; ++k) {
+          const int sr = c.rowof()[c.out_to()[EI(v[u], k)]];
+          if (sr >= 0) { has = 1; dist = max(dist, sr - r); if (sr == r + 1) next = 1; else other = 1; }
+        }
+        far = dist > WB_RING;
+        if (dist > 64) bad = 1;                                          // (the certificate reads the shifts of at most 64 rows)
+        ovf = np > 4; virt = np == 0;
+        if (np == 0) np = 1;
+        two = np == 1;
+        adj = two && (int)p[0] == r - 1;
+        fast = adj && !far && has && dl <= 1;
+      }
+      // wr: a successor other than the row below, or the row below is not a fast row (its kind sits one lane up; the last
+      // lane of a step does not see it and writes the ring to be safe)
+      const unsigned fastn = (unsigned)__builtin_amdgcn_update_dpp(0, (int)fast, 0x130, 0xf, 0xf, false);       // wave_shl:1
+      if (live) {
+        const unsigned wr = other | (next & (fastn ^ 1u));
+        uint4 d; d.x = vb[u] * 8u | ((unsigned)min(np, 255) << 8) | (ovf << 16) | (far << 17) | ((has ^ 1u) << 18) | ((unsigned)two << 19) | (fast << 20)
+                       | ((unsigned)(fast ? dl : 0) << 22) | (wr << 23) | (virt << 24);
+        d.y = p[0] | (p[1] << 16); d.z = p[2] | (p[3] << 16); d.w = (unsigned)lo | ((unsigned)min(dist, 255) << 10) | ((unsigned)bidx << 18);
+        c.rdesc[r] = d;
+      }
+      const unsigned long long b2 = __ballot(two), ba = __ballot(adj), bd0 = __ballot(dl & 1), bd1 = __ballot((dl & 2) != 0);
+      if (lane == 0) { m2[r0 >> 6] = b2; ma[r0 >> 6] = ba; d0[r0 >> 6] = bd0; d1[r0 >> 6] = bd1; }
+    }
   }
   *nblocks = nbc;
   bad = __ballot(bad) != 0;
@@ -415,8 +453,22 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
 // direction words of its rows around the path (NW words x LW lanes) and -- for rows with several predecessors -- four
 // dwords of predecessor-index bytes are all fetched at once; the band start of every row comes from the shift bitmasks
 // in LDS, not from memory.  rq[q] = DP row aligned to query base q, 0 = insertion.
-__device__ void win_traceback_band(WCtx& c, int CB, int R, int Q, int r, const unsigned long long* m2bits, const unsigned long long* mabits,
-                                   const unsigned long long* d0bits, const unsigned long long* d1bits, unsigned* lds, const WArr<int>& rq, int lane) {
+// (a real call, like the rows: inlined into k_window the eleven-column tables pushed the kernel's register allocation over
+// the edge -- 130 more bytes of scratch per lane, every reload a vector load that waits for all older stores)
+__device__ __attribute__((noinline)) void win_traceback_band(int* cI, int* cE, uint8_t* cD, uint4* crdesc, int cK, int cn, int cNcap, int CB_, int R_, int Q_, int r_,
+                                                             int mw_, int big_, unsigned long long* prof_) {
+  WCtx c;
+  c.I = uni_ptr(cI); c.E = uni_ptr(cE); c.B8 = nullptr; c.score = nullptr; c.H = nullptr; c.D = uni_ptr(cD);
+  c.rdesc = uni_ptr(crdesc); c.K = uni32(cK); c.n = uni32(cn); c.Ncap = uni32(cNcap); c.hcap = 0;
+  const int CB = uni32(CB_), R = uni32(R_), Q = uni32(Q_), MW = uni32(mw_);
+  int r = uni32(r_);
+  unsigned long long* prof = uni_ptr(prof_);
+  const int lane = wave_lane();
+  extern __shared__ int lds_dyn[];
+  const unsigned long long* m2bits = (const unsigned long long*)lds_dyn; const unsigned long long* mabits = m2bits + MW;
+  const unsigned long long* d0bits = mabits + MW; const unsigned long long* d1bits = d0bits + MW;
+  unsigned* lds = (unsigned*)lds_dyn + 8 * MW;                              // traceback windows behind the four bitmask arrays
+  const QArr rq = {(unsigned short*)(lds + 512), c.opq(), uni32(big_) != 0};
   const int RPW = wb_rpw(CB), BPR = 2 * CB, BIT0 = wb_bit0(CB), BW = 64 * CB;
   const int NW = 64 / RPW + 1, LW = CB == 2 ? 14 : 7;                       // direction words of a block, lanes fetched per word
   const int cdiv = (65536 + CB - 1) / CB;                                    // o / CB == (o * cdiv) >> 16 for o < 2^13
@@ -429,8 +481,11 @@ __device__ void win_traceback_band(WCtx& c, int CB, int R, int Q, int r, const u
   int j = Q;
   int lo_t = r > 0 ? WB_W_LO(c.rdesc[r].w) : 0;                             // band start of the current row
   while (r > 0 || j > 0) {
-    if (r == 0) { for (int q = lane; q < j; q += 64) rq[q] = 0; break; }
+    if (r == 0) { for (int q = lane; q < j; q += 64) rq.set(q, 0); break; }
     if (j == 0) break;                                   // only vertical moves remain
+#ifdef C3_PHASE_PROF
+    const unsigned long long tb_t0 = __builtin_readcyclecounter();
+#endif
     const int rt = r, jt = j;
     // band shifts of the 64 rows above rt: bit 63 - x of sd0 / sd1 = shift bit of row rt - x
     unsigned long long sd0, sd1;
@@ -473,10 +528,20 @@ __device__ void win_traceback_band(WCtx& c, int CB, int R, int Q, int r, const u
       *(uint4*)(WP + lane * 4) = make_uint4(src[0], src[1], src[2], src[3]);
     }
     WSYNC();
+#ifdef C3_PHASE_PROF
+    const unsigned long long tb_t1 = __builtin_readcyclecounter();
+    prof[0] += 1; prof[1] += tb_t1 - tb_t0;
+#endif
     const int wik = ghi - (max(rk, 1) - 1) / RPW;                            // this lane's word in the block
     const int kin = (max(rk, 1) - 1) % RPW;                                  // ... and its row inside the word
     const int wl0 = (wik >= 0 && wik < NW) ? WL0[wik] : 0;
+    // (Tried: per-lane tables of the row's cells at the 11 columns around the block's diagonal, built once per block, so that
+    // a step is a shift + ballot.  The walk itself got a third cheaper in wave time, the kernel 4 % SLOWER: the table build is
+    // ~330 vector instructions per block in a kernel whose throughput is set by vector issue, while the steps below mostly wait.)
     for (;;) {
+#ifdef C3_PHASE_PROF
+      prof[2] += 1;
+#endif
       const int s = rt - r;                               // lane s holds the current row
       const int jk = j - (lane - s);
       const int ok_ = jk - lok;                           // band offset of the cell
@@ -488,7 +553,7 @@ __device__ void win_traceback_band(WCtx& c, int CB, int R, int Q, int r, const u
       const unsigned wv = WD[min(max(wik, 0), NW - 1) * LW + min(max(ix, 0), LW - 1)];
       const unsigned cell = (wv >> (BIT0 + BPR * kin + 2 * cw)) & 3u;
       int d = 63 + 64 * (int)cell, prow = -1;
-      if (two) prow = adj ? rk - 1 : -3;
+      if (two) prow = adj ? rk - 1 : (int)(de.y & 0xffff);      // a single predecessor: this lane's descriptor names it (no reload at a break; 0 = the virtual start row)
       else {
         const int px = lq - pl0;
         if (px < 0 || px > 3) hit = false;
@@ -499,7 +564,7 @@ __device__ void win_traceback_band(WCtx& c, int CB, int R, int Q, int r, const u
       const bool diag1 = hit && jk >= 1 && win_d_type(d) == 0 && prow == rk - 1;
       const unsigned long long bal = __ballot(diag1) >> s;
       const int m = (~bal) ? __builtin_ctzll(~bal) : 64;  // length of the diagonal run
-      if (lane >= s && lane < s + m) rq[jk - 1] = rk;
+      if (lane >= s && lane < s + m) rq.set(jk - 1, rk);
       r -= m; j -= m;
       if (s + m >= 64 || r <= 0 || j <= 0) break;
       // the breaking cell (r, j) sits in lane cl
@@ -517,16 +582,19 @@ __device__ void win_traceback_band(WCtx& c, int CB, int R, int Q, int r, const u
         else { db -= (int)((PX[(size_t)r * 64 + l0_] >> (8 * c0)) & 63u); pb = -2; }
       }
       const int ty = win_d_type(db);
-      if (ty == 2) { if (lane == 0) rq[j - 1] = 0; --j; }
+      if (ty == 2) { if (lane == 0) rq.set(j - 1, 0); --j; }
       else {
-        if (pb <= -2) pb = win_pred_row(c, c.rdesc[r], r, win_d_pred(db));   // > 4 predecessors, a 2-bit row whose predecessor is not r-1, or a window miss
-        if (ty == 0) { if (lane == 0) rq[j - 1] = r; --j; }
+        if (pb <= -2) pb = win_pred_row(c, c.rdesc[r], r, win_d_pred(db));   // > 4 predecessors or a window miss
+        if (ty == 0) { if (lane == 0) rq.set(j - 1, r); --j; }
         r = pb;
       }
       if (r <= 0 || j <= 0) break;
       const int drift = (jt - j) - (rt - r);
       if (rt - r >= 64 || drift > 5 || drift < -5) break;
     }
+#ifdef C3_PHASE_PROF
+    prof[3] += __builtin_readcyclecounter() - tb_t1;
+#endif
     // band start of the row the next block starts at
     if (r > 0) {
       const int back = rt - r;

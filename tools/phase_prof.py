@@ -36,6 +36,8 @@ for which, kn in ((0, "k_poa"), (1, "k_window")):
         print("   cycles per general row: several predecessors %.0f, one far predecessor %.0f, r-1 kept %.0f; all DP-row cycles / all rows = %.0f" % (
             out[12] / max(multi, 1), out[13] / max(far, 1), out[14] / max(kept, 1), out[3] / max(rows, 1)))
     if which == 1:
-        print("   traceback census: blocks %d, steps %d, window misses %d; descriptor build = %.1f%% of the wave time (inside 'DP rows')" % (out[12], out[13], out[14], 100.0 * out[15] / tot))
+        if out[12]:
+            print("   band traceback: %d blocks, load+sync %.0f cycles per block (%.1f%% of the wave time), %.1f steps per block, %.0f cycles per step (%.1f%%)" % (
+                out[12], out[13] / out[12], 100.0 * out[13] / tot, out[14] / out[12], out[15] / max(out[14], 1), 100.0 * out[15] / tot))
     if which == 0 and out[1]:
         print("   DP rows by kind (cycles): fast %.1f%%, near %.1f%%, general %.1f%% of the row loop" % tuple(100.0 * out[i] / max(out[8] + out[10] + out[11], 1) for i in (8, 10, 11)))
