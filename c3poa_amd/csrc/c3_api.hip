@@ -644,6 +644,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     a.wout = h->d_wout.as<uint8_t>(); a.wout_cap = wout_cap;
     HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 256, h->stream));
     a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
+    if (const char* e = getenv("C3_DEBUG_BAND")) a.band_mode = !strcmp(e, "off") ? 1 : !strcmp(e, "fail") ? 2 : 0;    // test hook (tests/test_gpu_band.py)
     c3k_launch_window(&a, slots, h->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h->phase_win, h->d_counter.as<char>() + 64, 128, hipMemcpyDeviceToHost, h->stream));

@@ -37,6 +37,7 @@ struct WinArgs {
   int32_t* H; uint16_t* D; uint4* rdesc; int Ncap, K; long long hcap; uint8_t* wout; int wout_cap;
   int Lcap;                               // nodes the LDS consensus sweep can hold (<= Ncap)
   unsigned long long* phases;
+  int band_mode;                          // 0 = banded rows with certificate (default), 1 = never banded, 2 = every certificate counts as failed (test hook: C3_DEBUG_BAND)
 };
 struct StitchArgs {
   C3Batch b; C3Info* info; const int* work; int n_work; const WinRec* wrec; const int* win_base; const uint8_t* wout; int wout_cap; char* cons;

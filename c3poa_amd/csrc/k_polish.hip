@@ -1084,7 +1084,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
 #endif
         WSYNC();
         PH_MARK(2)
-        int cpl = 0, RS = 0, cb = 1, gbs = INT32_MIN, gbr = 0;
+        int cpl = 0, RS = 0, cb = a.band_mode != 1, gbs = INT32_MIN, gbr = 0;
         const int ring_off = 8 * MW;                                          // LDS behind the four row bitmasks, in dwords
         for (int attempt = 0; attempt < 2; ++attempt) {
           unsigned long long dbg_[6] = {0, 0, 0, 0, 0, 0};
@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
 #ifdef C3_EXP_NOCERT
             if (cb) { ++n_band; break; }
 #endif
-            if (gbs != INT32_MIN && bound < gbs) { ++n_band; break; }
+            if (gbs != INT32_MIN && bound < gbs && a.band_mode != 2) { ++n_band; break; }
           } else {
             int bs = INT32_MIN, br = INT32_MAX / 2;
             for (int r = 1 + lane; r <= R; r += 64) { const int sc = c.hend()[r]; if (sc > bs) { bs = sc; br = r; } }

@@ -1,0 +1,82 @@
+"""k_window's banded rows: the band is an optimisation with a proof obligation, never a change of result.
+The oracle always fills the full matrix; the HIP path must equal it
+  * with the band and its certificate (default),
+  * with the band switched off (the unbanded rows),
+  * with every certificate declared failed (band attempted, thrown away, layer redone unbanded -- the fallback path),
+and the timing counters must tell the three apart (cells computed vs cells of the full matrices, band layers, fallbacks)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from c3poa_amd import _lib, synth  # noqa: E402
+from oracle import oracle_py as O  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(recs, mdist, mode):
+    old = os.environ.get("C3_DEBUG_BAND")
+    if mode:
+        os.environ["C3_DEBUG_BAND"] = mode
+    else:
+        os.environ.pop("C3_DEBUG_BAND", None)
+    try:
+        h = _lib.Handle(mdistcutoff=mdist)
+        h.set_splints([synth.SPLINT1])
+        h.upload([r[1] for r in recs], [r[2] for r in recs], [r[3] for r in recs])
+        h.run()
+        res, cons = h.results()
+        t = h.timing()
+        h.close()
+    finally:
+        if old is None:
+            os.environ.pop("C3_DEBUG_BAND", None)
+        else:
+            os.environ["C3_DEBUG_BAND"] = old
+    return res, cons, t
+
+
+@pytest.mark.parametrize("cfg,n", [("cfg2", 96), ("cfg4", 24), ("cfg3", 64)])
+def test_band_certificate_and_fallback_all_equal_the_full_matrix(cfg, n):
+    recs = list(synth.generate(cfg, n_reads=n))
+    md = synth.CONFIGS[cfg]["mdist"]
+    ores, ocons = O.process_batch(synth.SPLINT1, [(r[1], r[2]) for r in recs], [r[3] for r in recs],
+                                  params=O.default_params(mdistcutoff=md), threads=8)
+    cells_full = sum(int(r.cells_polish) for r in ores)
+    seen = {}
+    for mode in (None, "off", "fail"):
+        res, cons, t = _run(recs, md, mode)
+        for i in range(n):
+            assert res[i]["status"] == ores[i].status and cons[i] == ocons[i], (cfg, mode, i)
+        assert t["cells_polish"] == cells_full                         # the algorithmic count never changes
+        seen[mode] = t
+    band, off, fail = seen[None], seen["off"], seen["fail"]
+    assert off["n_band_layers"] == 0 and off["n_band_fallback"] == 0 and off["cells_polish_computed"] == cells_full
+    assert band["n_band_layers"] > 0 and band["cells_polish_computed"] < 0.6 * cells_full
+    assert band["n_band_fallback"] <= 0.05 * (band["n_band_layers"] + band["n_band_fallback"]) + 2
+    assert fail["n_band_layers"] == 0 and fail["n_band_fallback"] == band["n_band_layers"] + band["n_band_fallback"]
+    assert fail["cells_polish_computed"] > cells_full                  # band attempts + full matrices
+
+
+def test_layers_longer_than_the_lds_query_arrays():
+    """a subread with a 1.3 kb insertion inside one 500-base window: that layer has > 1024 bases, so its per-base row / node
+    arrays live in global memory instead of LDS (W_QCAP) and its rows take the generic unbanded path"""
+    rng = np.random.default_rng(31)
+    recs = list(synth.generate("cfg2", n_reads=6))
+    out = []
+    for k, r in enumerate(recs):
+        name, seq, qual, strand, truth = r
+        if k % 2 == 0:
+            at = 1750 + 300 + int(rng.integers(0, 200))               # inside the second subread
+            ins = "".join("ACGT"[i] for i in rng.integers(0, 4, 1300))
+            seq = seq[:at] + ins + seq[at:]
+            qual = qual[:at] + "5" * len(ins) + qual[at:]
+        out.append((name, seq, qual, strand, truth))
+    ores, ocons = O.process_batch(synth.SPLINT1, [(r[1], r[2]) for r in out], [r[3] for r in out], threads=6)
+    res, cons, _t = _run(out, 500, None)
+    for i in range(len(out)):
+        assert res[i]["status"] == ores[i].status and cons[i] == ocons[i], i
