@@ -644,7 +644,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     a.wout = h->d_wout.as<uint8_t>(); a.wout_cap = wout_cap;
     HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 256, h->stream));
     a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
-    if (const char* e = getenv("C3_DEBUG_BAND")) a.band_mode = !strcmp(e, "off") ? 1 : !strcmp(e, "fail") ? 2 : 0;    // test hook (tests/test_gpu_band.py)
+    if (const char* e = getenv("C3_DEBUG_BAND")) a.band_mode = !strcmp(e, "off") ? 1 : !strcmp(e, "fail") ? 2 : !strcmp(e, "verify") ? 3 : 0;    // test hook (tests/test_gpu_band.py)
     c3k_launch_window(&a, slots, h->stream);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(h->phase_win, h->d_counter.as<char>() + 64, 128, hipMemcpyDeviceToHost, h->stream));
@@ -660,7 +660,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   HIPCHK(hipEventRecord(h->ev[9], h->stream));
   HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 64, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
-  if (n_win > 0) { h->tm.cells_polish += *(long long*)(cnt + 2); h->tm.cells_polish_computed += *(long long*)(cnt + 4); h->tm.n_band_layers = cnt[6]; h->tm.n_band_fallback = cnt[7]; }
+  if (n_win > 0) { h->tm.cells_polish += *(long long*)(cnt + 2); h->tm.cells_polish_computed += *(long long*)(cnt + 4); h->tm.n_band_layers = cnt[6]; h->tm.n_band_fallback = cnt[7]; h->tm.n_band_mismatch = cnt[8]; if (cnt[8]) fprintf(stderr, "c3poa: band verify mismatch in window %d layer %d (R = %d): last differing base q = %d, band row %d, full row %d, row of q+1 = %d\n", cnt[9], cnt[10], cnt[11], cnt[12], cnt[13], cnt[14], cnt[15]); }
   HIPCHK(hipEventElapsedTime(ms_prep, h->ev[5], h->ev[6]));
   HIPCHK(hipEventElapsedTime(ms_win, h->ev[7], h->ev[8]));
   HIPCHK(hipEventElapsedTime(ms_st, h->ev[8], h->ev[9]));
@@ -681,7 +681,7 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
   if (stages & C3_STAGE_CONK) { h->tm.ms_conk = 0; h->tm.cells_conk = 0; }
   if (stages & C3_STAGE_PEAKS) h->tm.ms_peaks = 0;
   if (stages & C3_STAGE_POA) { h->tm.ms_poa = 0; h->tm.cells_poa = 0; }
-  if (stages & C3_STAGE_POLISH) { h->tm.ms_prep = h->tm.ms_window = h->tm.ms_stitch = 0; h->tm.cells_polish = 0; h->tm.cells_polish_computed = 0; h->tm.n_band_layers = h->tm.n_band_fallback = 0; h->tm.n_windows = 0; }
+  if (stages & C3_STAGE_POLISH) { h->tm.ms_prep = h->tm.ms_window = h->tm.ms_stitch = 0; h->tm.cells_polish = 0; h->tm.cells_polish_computed = 0; h->tm.n_band_layers = h->tm.n_band_fallback = h->tm.n_band_mismatch = 0; h->tm.n_windows = 0; }
   HIPCHK(hipEventRecord(t0, h->stream));
   if (stages & C3_STAGE_CONK) { if ((rc = run_conk(h))) return rc; h->tm.cells_conk = 0; for (int i = 0; i < h->n; ++i) h->tm.cells_conk += (h->off[i + 1] - h->off[i]) * (int64_t)h->max_spl; }
   HIPCHK(hipEventRecord(t1, h->stream));

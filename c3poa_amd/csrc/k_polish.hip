@@ -1084,8 +1084,15 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
 #endif
         WSYNC();
         PH_MARK(2)
-        int cpl = 0, RS = 0, cb = a.band_mode != 1, gbs = INT32_MIN, gbr = 0;
         const int ring_off = 8 * MW;                                          // LDS behind the four row bitmasks, in dwords
+        // (LDS behind the traceback windows: 512 dwords in, 2 x W_QCAP shorts)
+        const QArr rq = {(unsigned short*)((unsigned*)lds_dyn + ring_off + 512), c.opq(), Q > W_QCAP};
+        const QArr tq = {(unsigned short*)((unsigned*)lds_dyn + ring_off + 512) + W_QCAP, c.opn(), Q > W_QCAP};
+        // (band_mode 3, test hook: every layer the certificate accepted is aligned a second time with the full matrix and the two
+        // tracebacks are compared base by base -- the certificate's claim, checked on the device)
+        bool verify = false;
+        for (int vpass = 0; vpass < 2 && !fail; ++vpass) {
+        int cpl = 0, RS = 0, cb = a.band_mode != 1 && vpass == 0, gbs = INT32_MIN, gbr = 0;
         for (int attempt = 0; attempt < 2; ++attempt) {
           unsigned long long dbg_[6] = {0, 0, 0, 0, 0, 0};
           int nblocks = 0;
@@ -1125,9 +1132,6 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         // LDS read: the wave checks 64 cells down the diagonal at once ("diagonal move from the row above"?), consumes the
         // run, and resolves the cell that breaks it.  One memory round trip per 64 rows instead of one per break -- and
         // the traceback no longer fetches about as many bytes as the fill wrote.
-        // (LDS behind the traceback windows: 512 dwords in, 2 x W_QCAP shorts)
-        const QArr rq = {(unsigned short*)((unsigned*)lds_dyn + ring_off + 512), c.opq(), Q > W_QCAP};
-        const QArr tq = {(unsigned short*)((unsigned*)lds_dyn + ring_off + 512) + W_QCAP, c.opn(), Q > W_QCAP};
         unsigned long long tbp_[4] = {0, 0, 0, 0};
 #ifdef C3_PHASE_PROF
         unsigned long long tbc_[3] = {0, 0, 0};
@@ -1216,6 +1220,25 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
               if (rt - r >= 64 || drift > 5 || drift < -5) break;
             }
             WSYNC();
+          }
+        }
+        if (!(a.band_mode == 3 && vpass == 0 && cb)) break;
+        verify = true;
+        WSYNC();
+        for (int q = lane; q < Q; q += 64) c.opq()[q] = rq.get(q);          // (global: the unbanded rows reuse the LDS, their descriptor build uses opn)
+        WSYNC();
+        }
+        if (verify && !fail) {
+          int diff = 0;
+          for (int q = lane; q < Q; q += 64) diff |= c.opq()[q] != rq.get(q);
+          const unsigned long long dm = __ballot(diff);
+          if (dm != 0) {
+            // the highest differing query base (the walks start at the end): enough to find the row where they part
+            int qd = -1;
+            for (int q = lane; q < Q; q += 64) if (c.opq()[q] != rq.get(q)) qd = q;
+            qd = wave_max(qd);
+            if (lane == 0) { atomicAdd(a.counter + 8, 1); a.counter[9] = wi; a.counter[10] = t; a.counter[11] = R; a.counter[12] = qd; a.counter[13] = c.opq()[qd]; a.counter[14] = rq.get(qd);
+                             a.counter[15] = qd + 1 < Q ? rq.get(qd + 1) : -1; }
           }
         }
         WSYNC();

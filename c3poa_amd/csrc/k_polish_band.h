@@ -140,7 +140,7 @@ __device__ int win_build_desc_band(WCtx& c, int R, int Q, int begin, int end, in
       if (live) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (pe[u][k] >= 0) { p[np < 4 ? np : 3] = (unsigned)pe[u][k]; ++np; }
-        for (int k = 4; k < nin[u]; ++k) { const int pr = c.rowof()[c.in_from()[EI(v[u], k)]]; if (pr >= 0) ++np; }
+        for (int k = 4; k < nin[u]; ++k) { const int pr = c.rowof()[c.in_from()[EI(v[u], k)]]; if (pr >= 0) { if (np < 4) p[np] = (unsigned)pr; ++np; } }     // (masked-out predecessors in the first slots: a later edge can still be one of the first four ROWS)
 #pragma unroll
         for (int k = 0; k < 4; ++k) if (se[u][k] >= 0) { has = 1; dist = max(dist, se[u][k] - r); if (se[u][k] == r + 1) next = 1; else other = 1; }
         for (int k = 4; k < nout[u]; ++k) {
@@ -154,6 +154,9 @@ __device__ int win_build_desc_band(WCtx& c, int R, int Q, int begin, int end, in
         two = np == 1;
         adj = two && (int)p[0] == r - 1;
         fast = adj && !far && has && dl <= 1;
+#ifdef C3_EXP_NOFAST
+        fast = 0;
+#endif
       }
       // wr: a successor other than the row below, or the row below is not a fast row (its kind sits one lane up; the last
       // lane of a step does not see it and writes the ring to be safe)
@@ -550,6 +553,9 @@ __device__ __attribute__((noinline)) void win_traceback_band(int* cI, int* cE, u
       const int lq = (oc * cdiv) >> 16, cw = oc - lq * CB;
       const int ix = lq - wl0;
       bool hit = val && ix >= 0 && ix < LW;
+#ifdef C3_EXP_TBSLOW
+      hit = false;
+#endif
       const unsigned wv = WD[min(max(wik, 0), NW - 1) * LW + min(max(ix, 0), LW - 1)];
       const unsigned cell = (wv >> (BIT0 + BPR * kin + 2 * cw)) & 3u;
       int d = 63 + 64 * (int)cell, prow = -1;

@@ -88,6 +88,7 @@ typedef struct {
   int64_t cells_polish_computed;   /* polish DP cells actually computed: banded layers fill 64*CB columns per row, a layer whose band
                                       certificate failed counts band + full matrix.  cells_polish stays the full-matrix count (= oracle) */
   int64_t n_band_layers, n_band_fallback;   /* window layers aligned in a band and accepted / redone unbanded after a failed certificate */
+  int64_t n_band_mismatch;                  /* C3_DEBUG_BAND=verify only: accepted band layers whose traceback differs from the full matrix's (must be 0) */
 } c3_timing;
 
 typedef struct c3_handle c3_handle;

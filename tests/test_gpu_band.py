@@ -80,3 +80,19 @@ def test_layers_longer_than_the_lds_query_arrays():
     res, cons, _t = _run(out, 500, None)
     for i in range(len(out)):
         assert res[i]["status"] == ores[i].status and cons[i] == ocons[i], i
+
+
+def test_band_verify_on_device_and_the_fifth_in_edge_regression():
+    """C3_DEBUG_BAND=verify aligns every accepted band layer a second time with the full matrix ON THE DEVICE and counts the layers
+    whose tracebacks differ: must be 0.  The read is a fuzz find of round 3 (tools/fuzz_parity.py 2000 33, read 188): a window
+    node with five in-edges of which the first two lie outside the layer's sub-graph -- the band descriptor build dropped the
+    fifth edge's row from the first-four list, the DP took the virtual start row instead, one path differed by a tie."""
+    import pickle
+    read, strand = pickle.load(open(os.path.join(ROOT, "tests", "golden", "band_regress_read.pkl"), "rb"))
+    recs = [("fuzz33_188", read[0], read[1], strand, "")] + list(synth.generate("cfg4", n_reads=6)) + list(synth.generate("cfg3", n_reads=24))
+    ores, ocons = O.process_batch(synth.SPLINT1, [(r[1], r[2]) for r in recs], [r[3] for r in recs], threads=8)
+    for mode in (None, "verify"):
+        res, cons, t = _run(recs, 500, mode)
+        for i in range(len(recs)):
+            assert res[i]["status"] == ores[i].status and cons[i] == ocons[i], (mode, i)
+        assert t["n_band_layers"] > 100 and t["n_band_mismatch"] == 0

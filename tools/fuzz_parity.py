@@ -2,7 +2,8 @@
 """Randomised parity sweep, GPU path against the oracle (diagnostic, slower than the test suite):
    python tools/fuzz_parity.py [n_reads] [seed]
 Concatemers with random insert length (60..3500), repeats (0..14), flank lengths, error rate (0..25 %), strand, quality
-profile, occasional non-ACGT bytes / lower case, plus pure noise reads."""
+profile, occasional non-ACGT bytes / lower case, ragged repeats (a 25-90 base chunk missing or duplicated in some copies), plus
+pure noise reads.  Prints the band counters of k_window (layers accepted by the certificate / redone unbanded)."""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -24,7 +25,19 @@ for i in range(n):
         ins = rnd(int(rng.integers(60, 3500)))
         reps = int(rng.integers(0, 15)) if len(ins) < 1200 else int(rng.integers(0, 6))
         k0, k1 = int(rng.integers(0, len(ins))), int(rng.integers(0, len(ins)))
-        clean = ins[len(ins) - k0:] + (synth.SPLINT1 + ins) * reps + synth.SPLINT1 + ins[:k1]
+        if kind in (3, 4) and len(ins) > 300 and reps >= 2:
+            # ragged repeats: some copies of the insert miss a 25-90 base chunk or carry it twice (layers that do not follow the
+            # draft's diagonal: the banded window rows must fall back or certify, never differ)
+            units = []
+            for _r in range(reps):
+                u = ins
+                if rng.random() < 0.5:
+                    c0 = int(rng.integers(30, len(ins) - 120)); ln = int(rng.integers(25, 90))
+                    u = ins[:c0] + ins[c0 + ln:] if rng.random() < 0.5 else ins[:c0 + ln] + ins[c0:]
+                units.append(synth.SPLINT1 + u)
+            clean = ins[len(ins) - k0:] + "".join(units) + synth.SPLINT1 + ins[:k1]
+        else:
+            clean = ins[len(ins) - k0:] + (synth.SPLINT1 + ins) * reps + synth.SPLINT1 + ins[:k1]
         err = float(rng.choice([0.0, 0.03, 0.1, 0.1, 0.15, 0.25]))
         sb, qb = synth._mutate(rng, np.frombuffer(clean.encode(), dtype=np.uint8), sub=err * 0.4, ins=err * 0.25, dele=err * 0.35)
         s, q = sb.decode(), qb.decode()
@@ -56,5 +69,7 @@ for i in range(len(reads)):
             print("MISMATCH read %d len %d strand %s: gpu status %d n_sub %d cons %d | oracle status %d n_sub %d cons %d" % (
                 i, len(reads[i][0]), strands[i], res[i]["status"], res[i]["n_sub"], len(cons[i]), o.status, o.n_sub, len(ocons[i])))
 st = np.bincount(res["status"], minlength=6)
-print("reads %d  mismatches %d  statuses OK/NA/NOPEAK/NOCONS/SHORT/LIMIT = %s" % (len(reads), bad, st.tolist()))
+t = h.timing()
+print("reads %d  mismatches %d  statuses OK/NA/NOPEAK/NOCONS/SHORT/LIMIT = %s  band layers %d fallback %d computed/full cells %.3f" % (
+    len(reads), bad, st.tolist(), t["n_band_layers"], t["n_band_fallback"], t["cells_polish_computed"] / max(t["cells_polish"], 1)))
 sys.exit(1 if bad else 0)
