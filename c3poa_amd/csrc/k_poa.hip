@@ -29,12 +29,15 @@
 struct Ctx {
   int* I; int* E; char* C; uint8_t* B8; long long* score_; uint4* desc_; int* jump_; int* path_;
   int K, n, Ncap, cells_cap;
+  int osel;                  // which of the two order buffers is current (g_reorder writes the other one and flips)
   const uint32_t* pk;        // packed read
 #define CTX_I(name, k) __device__ __forceinline__ int* name() const { return I + (size_t)(k) * Ncap; }
-  CTX_I(n_in, 0) CTX_I(n_out, 1) CTX_I(grp, 2) CTX_I(order, 3) CTX_I(order2, 4) CTX_I(index, 5) CTX_I(gfirst, 6) CTX_I(glast, 7)
+  CTX_I(n_in, 0) CTX_I(n_out, 1) CTX_I(grp, 2) CTX_I(index, 5) CTX_I(gfirst, 6) CTX_I(glast, 7)
   CTX_I(rem, 8) CTX_I(mpl, 9) CTX_I(mpr, 10) CTX_I(rowm, 11) /* 3 ints per row: band begin, band end, cell offset (blocks 11..13) */ CTX_I(anchor, 14) CTX_I(col, 15)
   CTX_I(col2t, 16) CTX_I(nxt, 17)
 #undef CTX_I
+  __device__ __forceinline__ int* order() const { return I + (size_t)(3 + osel) * Ncap; }
+  __device__ __forceinline__ int* order2() const { return I + (size_t)(4 - osel) * Ncap; }
   __device__ __forceinline__ int* in_from() const { return E; }
   __device__ __forceinline__ int* out_to() const { return E + (size_t)Ncap * K; }
   __device__ __forceinline__ int* out_w() const { return E + 2 * (size_t)Ncap * K; }
@@ -62,22 +65,29 @@ __device__ __forceinline__ void g_add_edge(Ctx& c, int u, int v, int w) {
   c.in_from()[EI(v, ni)] = u; c.n_in()[v] = ni + 1;
 }
 
-// block extents from order/grp (parallel)
+// block extents from order/grp (parallel).  GU chunks of 64 positions per iteration: the two dependent levels (position -> node ->
+// group) cost one memory latency per GU*64 nodes; no look-ahead loads (a block's last position is known when the next one starts).
+#ifndef GU
+#define GU 2
+#endif
 __device__ void g_blocks(Ctx& c, int lane) {
   // The members of an aligned block are CONTIGUOUS in the topological order (a new sibling is merged right behind its
-  // block), so a block's extent is a run of equal group ids: its first / last position are where the id changes --
-  // plain stores, no initialisation pass, no atomics.
-  for (int i0 = 0; i0 < c.n; i0 += 64) {
-    const int i = i0 + lane;
-    const bool live = i < c.n;
-    const int r = live ? c.grp()[c.order()[i]] : -2;
-    int rp = __builtin_amdgcn_update_dpp(-1, r, 0x138, 0xf, 0xf, false);          // lane - 1 (wave_shr:1)
-    int rn = __builtin_amdgcn_update_dpp(-1, r, 0x130, 0xf, 0xf, false);          // lane + 1 (wave_shl:1)
-    if (lane == 0 && i > 0) rp = c.grp()[c.order()[i - 1]];
-    if (lane == 63 && i + 1 < c.n) rn = c.grp()[c.order()[i + 1]];
-    if (live) {
-      if (r != rp) c.gfirst()[r] = i;
-      if (r != rn || i + 1 >= c.n) c.glast()[r] = i;
+  // block), so a block's extent is a run of equal group ids: where the id changes, the new block starts and the previous one
+  // ends -- plain stores, no initialisation pass, no atomics.
+  int gprev = -1;
+  for (int i0 = 0; i0 < c.n; i0 += 64 * GU) {
+    int v[GU], r[GU];
+#pragma unroll
+    for (int u = 0; u < GU; ++u) { const int i = i0 + 64 * u + lane; v[u] = i < c.n ? c.order()[i] : -1; }
+#pragma unroll
+    for (int u = 0; u < GU; ++u) r[u] = v[u] >= 0 ? c.grp()[v[u]] : -2;
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const int i = i0 + 64 * u + lane;
+      const int rp = wave_shr1(r[u], gprev);
+      gprev = wave_bcast(r[u], 63);
+      if (v[u] >= 0 && r[u] != rp) { c.gfirst()[r[u]] = i; if (i > 0) c.glast()[rp] = i - 1; }
+      if (v[u] >= 0 && i + 1 == c.n) c.glast()[r[u]] = i;
     }
   }
   WSYNC();
@@ -88,28 +98,27 @@ __device__ void g_reorder(Ctx& c, int n_old, int lane, int* lds, int lds_cap) {
   const int n_new = c.n - n_old;
   // old node at old index i moves to i + #(anchor < i); new node k goes to anchor[k] + 1 + k.  The (sorted) anchors of the new
   // nodes are staged in LDS first: the binary search per old node is then 6-8 LDS reads instead of 6-8 dependent global loads
-  // per 64 nodes (the LDS scratch of the alignment is idle during the graph phases)
-  if (n_new <= lds_cap) {
-    for (int k = lane; k < n_new; k += 64) lds[k] = c.anchor()[k];
-    WSYNC();
-    for (int i = lane; i < n_old; i += 64) {
+  // per 64 nodes (the LDS scratch of the alignment is idle during the graph phases).  The new order goes to the OTHER order
+  // buffer together with index[], and the two buffers swap roles: no copy-back pass.
+  const bool inl = n_new <= lds_cap;
+  if (inl) { for (int k = lane; k < n_new; k += 64) lds[k] = c.anchor()[k]; WSYNC(); }
+  for (int i0 = 0; i0 < n_old; i0 += 64 * GU) {
+    int v[GU];
+#pragma unroll
+    for (int u = 0; u < GU; ++u) { const int i = i0 + 64 * u + lane; v[u] = i < n_old ? c.order()[i] : -1; }
+#pragma unroll
+    for (int u = 0; u < GU; ++u) {
+      const int i = i0 + 64 * u + lane;
+      if (v[u] < 0) continue;
       int lo = 0, hi = n_new;                 // first k with anchor[k] >= i
-      while (lo < hi) { int m = (lo + hi) >> 1; if (lds[m] < i) lo = m + 1; else hi = m; }
-      c.order2()[i + lo] = c.order()[i];
+      if (inl) { while (lo < hi) { int m = (lo + hi) >> 1; if (lds[m] < i) lo = m + 1; else hi = m; } }
+      else { while (lo < hi) { int m = (lo + hi) >> 1; if (c.anchor()[m] < i) lo = m + 1; else hi = m; } }
+      c.order2()[i + lo] = v[u]; c.index()[v[u]] = i + lo;
     }
-    for (int k = lane; k < n_new; k += 64) c.order2()[lds[k] + 1 + k] = n_old + k;
-    WSYNC();                                  // (the LDS words are free again)
-  } else {
-    for (int i = lane; i < n_old; i += 64) {
-      int lo = 0, hi = n_new;
-      while (lo < hi) { int m = (lo + hi) >> 1; if (c.anchor()[m] < i) lo = m + 1; else hi = m; }
-      c.order2()[i + lo] = c.order()[i];
-    }
-    for (int k = lane; k < n_new; k += 64) c.order2()[c.anchor()[k] + 1 + k] = n_old + k;
-    WSYNC();
   }
-  for (int i = lane; i < c.n; i += 64) { int v = c.order2()[i]; c.order()[i] = v; c.index()[v] = i; }
-  WSYNC();
+  for (int k = lane; k < n_new; k += 64) { const int pos = (inl ? lds[k] : c.anchor()[k]) + 1 + k; c.order2()[pos] = n_old + k; c.index()[n_old + k] = pos; }
+  c.osel ^= 1;
+  WSYNC();                                  // (the LDS words are free again)
   g_blocks(c, lane);
 }
 
@@ -835,7 +844,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
   c.I = a.ibase + (size_t)slot * C3_POA_NI * N; c.path_ = a.pbase + (size_t)slot * a.Pcap; c.E = a.ebase + (size_t)slot * 3 * N * a.K;
   c.C = a.cellsb + (size_t)slot * 18 * (size_t)a.cells_cap; c.B8 = a.bbase + (size_t)slot * 5 * N;
   c.score_ = a.score + (size_t)slot * N; c.desc_ = a.desc + (size_t)slot * 2 * N; c.jump_ = a.jump + (size_t)slot * C3_JUMP_LEVELS * N;
-  c.K = a.K; c.Ncap = a.Ncap; c.cells_cap = a.cells_cap;
+  c.K = a.K; c.Ncap = a.Ncap; c.cells_cap = a.cells_cap; c.osel = 0;
   PH_DECL
 
   for (;;) {
@@ -858,6 +867,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
       for (int k = lane; k < C; k += 64) { draft[k] = (uint8_t)c3_code_at(c.pk, qb + k); tpos[qb + k] = k; }
     } else {
       // ---- build the graph, one subread at a time
+      c.osel = 0;
       if (lane == 0) {
         c.base()[SRC] = 0; c.base()[SNK] = 0; c.n_in()[SRC] = c.n_out()[SRC] = c.n_in()[SNK] = c.n_out()[SNK] = 0;
         c.grp()[SRC] = SRC; c.grp()[SNK] = SNK; c.order()[0] = SRC; c.order()[1] = SNK; c.index()[SRC] = 0; c.index()[SNK] = 1;

@@ -320,7 +320,9 @@ struct WCtx {
 // The graph phases are chains of dependent memory round trips (position -> node -> its group / edges ...), and a wave that
 // waits for one has nothing else to do: every loop over the nodes therefore takes WU chunks of 64 per iteration, all loads of
 // one level issued back to back, so a level costs ONE memory latency per WU*64 nodes instead of one per 64.
+#ifndef WU
 #define WU 4
+#endif
 __device__ void w_blocks(WCtx& c, int lane) {
   // The members of an aligned block are CONTIGUOUS in the topological order (a new sibling is merged right behind its
   // block), so a block's extent is a run of equal group ids: where the id changes, the new block starts and the previous one
