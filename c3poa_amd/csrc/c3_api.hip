@@ -639,7 +639,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     a.draft = h->d_draft.as<uint8_t>();
     a.ibase = h->s_win_i.as<int>(); a.ebase = h->s_win_nk.as<int>();
     a.base = h->s_win_b.as<uint8_t>(); a.score = h->s_win_sc.as<long long>();
-    a.H = h->s_win_h.as<int32_t>(); a.D = h->s_win_d.as<uint16_t>(); a.rdesc = h->s_win_desc.as<uint4>(); a.Ncap = Ncap; a.K = K; a.hcap = hcap; a.Lcap = std::min(Ncap, 2 * WL + 30 * NLcap);
+    a.H = h->s_win_h.as<int32_t>(); a.D = h->s_win_d.as<uint16_t>(); a.rdesc = h->s_win_desc.as<uint4>(); a.Ncap = Ncap; a.K = K; a.hcap = hcap; a.Lcap = std::min(std::min(Ncap, 2 * WL + 30 * NLcap), ((getenv("C3_DEBUG_WIN_LDS") ? atoi(getenv("C3_DEBUG_WIN_LDS")) : 6656) - 16) / 6);       // (LDS per wave capped at 6.5 KB: at cfg4 the uncapped sweep arrays took 8.5 KB and k_window ran 7 % slower; larger graphs use the global-scratch sweep)
     if (const char* e = getenv("C3_DEBUG_WIN_LCAP")) a.Lcap = std::max(64, std::min(Ncap, atoi(e)));   // test hook: forces the global-scratch consensus path
     a.wout = h->d_wout.as<uint8_t>(); a.wout_cap = wout_cap;
     HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 256, h->stream));

@@ -290,7 +290,8 @@ template <class T> struct WArr {
 // rq / tq of one layer (DP row and node of every query base): in LDS when the layer has at most W_QCAP bases (every layer of a
 // 500-base window in practice), in the slot's global arrays otherwise.  The traceback's stores and the fusion's loads of these
 // two small arrays were a sixth of the graph phases' vector memory instructions.
-#define W_QCAP 1024
+#define W_QCAP 704
+#define W_TBW 448            /* dwords of traceback windows in front of rq / tq */
 struct QArr {
   unsigned short* l; WArr<int> g; bool big;
   __device__ __forceinline__ int get(int i) const { return big ? g[i] : (int)l[i]; }
@@ -766,8 +767,9 @@ __device__ int win_rows_lin(WCtx& c, const C3Params& P, const uint32_t* pk, int 
 __host__ __device__ __forceinline__ int win_mask_words(int Ncap) { return ((Ncap + 64) >> 6) + 1; }
 __host__ __device__ __forceinline__ size_t win_lds_bytes(int Lcap, int Ncap) {
   const size_t masks = (size_t)32 * win_mask_words(Ncap);
-  const size_t a = (size_t)Lcap * 6 + 16, b = masks + 4 * 5 * 64 * 4 + 64, c = masks + 4 * (size_t)wb_lds_dwords(639, 4);
-  return (a > b ? (a > c ? a : c) : (b > c ? b : c));
+  const size_t a = (size_t)Lcap * 6 + 16, b = masks + 4 * 5 * 64 * 4 + 64, c = masks + 4 * (size_t)wb_lds_dwords(639, 4), d = masks + 4 * (size_t)(W_TBW + W_QCAP);
+  size_t m = a > b ? a : b; m = m > c ? m : c; m = m > d ? m : d;
+  return m;
 }
 
 // byte index of column j inside a D row for the layout chosen by win_rows_dispatch
@@ -1087,9 +1089,9 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         WSYNC();
         PH_MARK(2)
         const int ring_off = 8 * MW;                                          // LDS behind the four row bitmasks, in dwords
-        // (LDS behind the traceback windows: 512 dwords in, 2 x W_QCAP shorts)
-        const QArr rq = {(unsigned short*)((unsigned*)lds_dyn + ring_off + 512), c.opq(), Q > W_QCAP};
-        const QArr tq = {(unsigned short*)((unsigned*)lds_dyn + ring_off + 512) + W_QCAP, c.opn(), Q > W_QCAP};
+        // (LDS behind the traceback windows: W_TBW dwords in, 2 x W_QCAP shorts)
+        const QArr rq = {(unsigned short*)((unsigned*)lds_dyn + ring_off + W_TBW), c.opq(), Q > W_QCAP};
+        const QArr tq = {(unsigned short*)((unsigned*)lds_dyn + ring_off + W_TBW) + W_QCAP, c.opn(), Q > W_QCAP};
         // (band_mode 3, test hook: every layer the certificate accepted is aligned a second time with the full matrix and the two
         // tracebacks are compared base by base -- the certificate's claim, checked on the device)
         bool verify = false;

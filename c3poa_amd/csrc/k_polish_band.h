@@ -32,15 +32,16 @@
 #pragma once
 
 #define WB_PADL 4            /* shorts in front of cell 0 of a ring slot: [0..1] lo, [3] = -inf (offset -1) */
-#define WB_PADR 36           /* -inf shorts behind the last cell: a predecessor is read at offsets up to BW - 1 + WB_MAXSHIFT + CB */
-#define WB_MAXSHIFT 32       /* lo(row) - lo(predecessor) beyond this: the layer is not banded */
+#define WB_PADR 28           /* -inf shorts behind the last cell: a predecessor is read at offsets up to BW - 1 + WB_MAXSHIFT + CB */
+#define WB_MAXSHIFT 24       /* lo(row) - lo(predecessor) beyond this: the layer is not banded */
 #ifndef WB_RING
 #define WB_RING 4            /* rows kept in the LDS ring (power of two) */
 #endif
-#define WB_EROW 16           /* shorts per row of band-edge cells parked for the certificate */
+#define WB_EROW 12           /* shorts per row of band-edge cells parked for the certificate: [0, 2*CB) first cells, [8, 8+CB) last lane */
+#define WB_EROWS 32          /* rows parked before the certificate bound of those rows is evaluated */
 __host__ __device__ __forceinline__ int wb_slot_shorts(int cb) { return WB_PADL + 64 * cb + WB_PADR; }
 // LDS of the banded rows behind the row-type bitmasks, in dwords: substitution table, ring, edge cells of 64 rows
-__host__ __device__ __forceinline__ int wb_lds_dwords(int Q, int cb) { return ((Q + 2) & ~1) + WB_RING * wb_slot_shorts(cb) / 2 + 64 * WB_EROW / 2; }
+__host__ __device__ __forceinline__ int wb_lds_dwords(int Q, int cb) { return ((Q + 2) & ~1) + WB_RING * wb_slot_shorts(cb) / 2 + WB_EROWS * WB_EROW / 2; }
 __device__ __forceinline__ int wb_left(int cb) { return cb == 2 ? 70 : cb == 3 ? 105 : 140; }     // columns left of the centre (the rest, 57 / 86 / 115, right)
 __host__ __device__ __forceinline__ int wb_rpw(int cb) { return cb == 2 ? 8 : 4; }                 // rows per packed direction word (2*cb bits per row and lane)
 __host__ __device__ __forceinline__ int wb_bit0(int cb) { return 32 - 2 * cb * wb_rpw(cb); }       // first used bit of a direction word (cb == 3: 8)
@@ -212,7 +213,7 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
   constexpr int RPW = CB == 2 ? 8 : 4, BPR = 2 * CB, BIT0 = 32 - BPR * RPW;
   unsigned* tbl = (unsigned*)lds_dyn + uni32(lds_off_);                      // [Q + 1] substitution bytes per column
   unsigned short* ring = (unsigned short*)(tbl + ((Q + 2) & ~1));
-  unsigned short* ebuf = ring + WB_RING * SLOT;                              // [64][WB_EROW] band-edge cells of the current 64 rows
+  unsigned short* ebuf = ring + WB_RING * SLOT;                              // [WB_EROWS][WB_EROW] band-edge cells of the current 32 rows
   const unsigned long long* d0bits = (const unsigned long long*)(lds_dyn + uni32(lds_off_) / 2);      // the four bitmask arrays fill [0, lds_off)
   const unsigned long long* d1bits = (const unsigned long long*)(lds_dyn + uni32(lds_off_) / 4 * 3);
   struct { int pol_match, pol_mismatch, pol_gap; } P = {uni32(mt_), uni32(mm_), uni32(g_)};
@@ -252,7 +253,7 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
   for (int k = 0; k <= CB; ++k) tn[k] = tp[k];
   unsigned dacc = 0;                                                        // direction bits of the rows of the current word
   unsigned dwoff = (unsigned)lane;                                          // dword index of this lane's next direction word
-  const unsigned ebase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short*)ebuf + 2u * (lane < 2 ? (unsigned)(lane * CB) : (unsigned)(WB_EROW - CB));
+  const unsigned ebase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned short*)ebuf + 2u * (lane < 2 ? (unsigned)(lane * CB) : 8u);
   int best = (BW - 1) * gap + ups * (Q - BW + 1);                           // certificate: right exit of the virtual row (its band ends at BW - 1 < Q)
   int ebs = INT32_MIN, ebr = INT32_MAX / 2, bandbad = 0;                    // best end row seen by this lane
 #ifdef C3_PHASE_PROF
@@ -277,7 +278,7 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
       }                                                                                                          \
       dacc = (dacc >> BPR) | w2;                                                                                 \
       if (PIDX) GP(unsigned, PX)[(unsigned)r * 64u + (unsigned)lane] = pidx;                                     \
-      wb_park_edge<CB>(ebase + (unsigned)li * (2u * WB_EROW), hcur);                                             \
+      wb_park_edge<CB>(ebase + (unsigned)(li & (WB_EROWS - 1)) * (2u * WB_EROW), hcur);                                             \
     }
 #define WB_RING_WRITE()                                                                                          \
     {                                                                                                            \
@@ -292,7 +293,9 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
     uint4 dblk = make_uint4(dv.x, dv.y, dv.z, dv.w);
     asm volatile("" : "+v"(dblk.x), "+v"(dblk.y), "+v"(dblk.z), "+v"(dblk.w));
     const int cnt = min(64, R - rb + 1);
-    for (int li = 0; li < cnt; ++li) {
+    for (int half_ = 0; half_ < 64 && half_ < cnt; half_ += WB_EROWS) {
+    const int hend_ = min(half_ + WB_EROWS, cnt);
+    for (int li = half_; li < hend_; ++li) {
       const int r = rb + li;
       const unsigned dx = (unsigned)__builtin_amdgcn_readlane((int)dblk.x, li);
       int key[CB];
@@ -410,17 +413,17 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
       }
       if ((li & (RPW - 1)) == RPW - 1) { GP(unsigned, DW)[dwoff] = dacc; dwoff += 64; dacc = 0; }
     }
-    if (cnt & (RPW - 1)) {                                                   // the last, partial word of the layer
+    if (hend_ == cnt && (cnt & (RPW - 1))) {                                 // the last, partial word of the layer
       const int miss = RPW - (cnt & (RPW - 1));
       GP(unsigned, DW)[dwoff] = dacc >> (BPR * miss); dwoff += 64; dacc = 0;
     }
-    // certificate bound of these rows: lane li holds the descriptor of row rb + li, the edge cells sit in ebuf[li]
-    if (lane < cnt) {
-      const unsigned short* e = ebuf + lane * WB_EROW;
+    // certificate bound of these rows: lane li holds the descriptor of row rb + li, the edge cells sit in ebuf[li & 31]
+    if (lane >= half_ && lane < hend_) {
+      const unsigned short* e = ebuf + (lane & (WB_EROWS - 1)) * WB_EROW;
       const int r = rb + lane;
       const int lo_r = WB_W_LO(dblk.w), dist = WB_W_DIST(dblk.w), nb = NB - WB_W_BIDX(dblk.w);
       const int hi = lo_r + BW - 1;
-      if (hi < Q) best = max(best, ((int)(short)e[WB_EROW - 1] >> 2) + ups * (Q - hi));
+      if (hi < Q) best = max(best, ((int)(short)e[8 + CB - 1] >> 2) + ups * (Q - hi));
       if (((dblk.x >> 24) & 1) && lo_r > 0) best = max(best, ups * min(Q, nb + 1) + gap * max(0, Q - nb - 1));      // entered from (0, j), j < lo
       if (dist > 0) {
         // leftspan = lo(r + dist) - lo(r): shift bits of rows r+1 .. r+dist = bit indices r .. r+dist-1
@@ -435,6 +438,7 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
           best = max(best, ((int)(short)e[b] >> 2) + ups * min(rem, nb) + gap * max(0, rem - nb));
         }
       }
+    }
     }
   }
 #undef WB_ROW_TAIL
@@ -471,7 +475,7 @@ __device__ __attribute__((noinline)) void win_traceback_band(int* cI, int* cE, u
   const unsigned long long* m2bits = (const unsigned long long*)lds_dyn; const unsigned long long* mabits = m2bits + MW;
   const unsigned long long* d0bits = mabits + MW; const unsigned long long* d1bits = d0bits + MW;
   unsigned* lds = (unsigned*)lds_dyn + 8 * MW;                              // traceback windows behind the four bitmask arrays
-  const QArr rq = {(unsigned short*)(lds + 512), c.opq(), uni32(big_) != 0};
+  const QArr rq = {(unsigned short*)(lds + W_TBW), c.opq(), uni32(big_) != 0};
   const int RPW = wb_rpw(CB), BPR = 2 * CB, BIT0 = wb_bit0(CB), BW = 64 * CB;
   const int NW = 64 / RPW + 1, LW = CB == 2 ? 14 : 7;                       // direction words of a block, lanes fetched per word
   const int cdiv = (65536 + CB - 1) / CB;                                    // o / CB == (o * cdiv) >> 16 for o < 2^13
