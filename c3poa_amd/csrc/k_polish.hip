@@ -775,7 +775,8 @@ __host__ __device__ __forceinline__ size_t win_lds_bytes(int Lcap, int Ncap) {
 // byte index of column j inside a D row for the layout chosen by win_rows_dispatch
 __device__ __forceinline__ int win_idx(int j, int cpl) { return cpl ? (j / cpl) * ((cpl + 3) & ~3) + j % cpl : j; }
 
-// cb_io: in = banding allowed, out = cells per lane of the band chosen (0 = the unbanded rows ran)
+// cb_io: in = 0: not banded, k >= 1: banded with at least k cells per lane (a retry after a failed certificate asks for a wider
+// band); out = cells per lane of the band that ran (0 = the unbanded rows ran)
 __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane, int* cpl_out, int* rs_out, unsigned long long* dbg,
                                  unsigned long long* m2, unsigned long long* ma, unsigned long long* d0, unsigned long long* d1, int ring_off, int lds_ints, int begin, int end, int blen, int* cb_io, int* nblocks) {
   const int need = (Q + 1 + 63) / 64;
@@ -795,7 +796,9 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
   // weaker the certificate's bounds and the wider the band it needs (tools/band_model.py)
   const int span = end - begin + 1;
   int cb = R * 4 < span * 5 ? 2 : R * 2 < span * 3 ? 3 : 4;
-  if (!*cb_io || !ok16 || need > 10 || need <= cb || span < 1 || max(P.pol_match, P.pol_mismatch) <= 0 || ring_off + wb_lds_dwords(Q, cb) > lds_ints) cb = 0;
+  cb = max(cb, *cb_io);
+  if (cb > 4) cb = 0;
+  if (!*cb_io || !cb || !ok16 || need > 10 || need <= cb || span < 1 || max(P.pol_match, P.pol_mismatch) <= 0 || ring_off + wb_lds_dwords(Q, cb) > lds_ints) cb = 0;
 #ifdef C3_BAND_OFF
   cb = 0;
 #endif
@@ -1097,7 +1100,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         bool verify = false;
         for (int vpass = 0; vpass < 2 && !fail; ++vpass) {
         int cpl = 0, RS = 0, cb = a.band_mode != 1 && vpass == 0, gbs = INT32_MIN, gbr = 0;
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        for (int attempt = 0; attempt < 4; ++attempt) {
           unsigned long long dbg_[6] = {0, 0, 0, 0, 0, 0};
           int nblocks = 0;
           if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, d0bits, d1bits, ring_off, lds_ints, l.begin, l.end, blen, &cb, &nblocks) < 0) { fail = 1; break; }
@@ -1124,7 +1127,9 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
             gbr = wave_min(bs == gbs ? br : INT32_MAX / 2);
             break;
           }
-          ++n_fallback; cb = 0;                                                // redo the layer with the full matrix
+          // a failed certificate: one more try with the next wider band (half again / twice the margin for the bounds, still well
+          // below the full matrix), then the full matrix
+          ++n_fallback; cb = (cb < 4 && a.band_mode == 0) ? cb + 1 : 0;
         }
         if (fail) break;
         cells += (long long)(R + 1) * (Q + 1);

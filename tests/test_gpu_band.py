@@ -58,7 +58,10 @@ def test_band_certificate_and_fallback_all_equal_the_full_matrix(cfg, n):
     assert off["n_band_layers"] == 0 and off["n_band_fallback"] == 0 and off["cells_polish_computed"] == cells_full
     assert band["n_band_layers"] > 0 and band["cells_polish_computed"] < 0.6 * cells_full
     assert band["n_band_fallback"] <= 0.05 * (band["n_band_layers"] + band["n_band_fallback"]) + 2
-    assert fail["n_band_layers"] == 0 and fail["n_band_fallback"] == band["n_band_layers"] + band["n_band_fallback"]
+    # "fail": every band-eligible layer makes ONE band attempt and is redone unbanded; normally a failed attempt is retried with
+    # the next wider band first, so a layer can count several failed attempts before it is accepted (or goes unbanded)
+    assert fail["n_band_layers"] == 0
+    assert band["n_band_layers"] <= fail["n_band_fallback"] <= band["n_band_layers"] + band["n_band_fallback"]
     assert fail["cells_polish_computed"] > cells_full                  # band attempts + full matrices
 
 
