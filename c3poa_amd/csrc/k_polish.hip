@@ -1097,6 +1097,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         const QArr tq = {(unsigned short*)((unsigned*)lds_dyn + ring_off + W_TBW) + W_QCAP, c.opn(), Q > W_QCAP};
         // (band_mode 3, test hook: every layer the certificate accepted is aligned a second time with the full matrix and the two
         // tracebacks are compared base by base -- the certificate's claim, checked on the device)
+        unsigned long long tbp_[4] = {0, 0, 0, 0};
         bool verify = false;
         for (int vpass = 0; vpass < 2 && !fail; ++vpass) {
         int cpl = 0, RS = 0, cb = a.band_mode != 1 && vpass == 0, gbs = INT32_MIN, gbr = 0;
@@ -1141,7 +1142,6 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         // LDS read: the wave checks 64 cells down the diagonal at once ("diagonal move from the row above"?), consumes the
         // run, and resolves the cell that breaks it.  One memory round trip per 64 rows instead of one per break -- and
         // the traceback no longer fetches about as many bytes as the fill wrote.
-        unsigned long long tbp_[4] = {0, 0, 0, 0};
 #ifdef C3_PHASE_PROF
         unsigned long long tbc_[3] = {0, 0, 0};
 #endif
