@@ -795,7 +795,7 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
   // band width by the inflation of the graph (rows per backbone position of the layer): the more alternative nodes, the
   // weaker the certificate's bounds and the wider the band it needs (tools/band_model.py)
   const int span = end - begin + 1;
-  int cb = R * 4 < span * 5 ? 2 : R * 2 < span * 3 ? 3 : 4;
+  int cb = R * 4 < span * 5 ? 2 : R * 2 < span * 3 ? 3 : 4;             // (starting narrower -- 1.3 / 1.7 -- and relying on the retry was measured 1 % slower at cfg4)
   cb = max(cb, *cb_io);
   if (cb > 4) cb = 0;
   if (!*cb_io || !cb || !ok16 || need > 10 || need <= cb || span < 1 || max(P.pol_match, P.pol_mismatch) <= 0 || ring_off + wb_lds_dwords(Q, cb) > lds_ints) cb = 0;
