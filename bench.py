@@ -117,8 +117,8 @@ def worker_command(n_gpus, argv, port=None):
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--reads", type=int, default=0, help="reads per step per GPU (0 = the config's size: cfg2 100k)")
     ap.add_argument("--cfg", default="cfg2")
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic reads generated per rank (0 = all)")
@@ -209,32 +209,42 @@ def main():
     KERNEL_MS = ("ms_conk", "ms_peaks", "ms_poa", "ms_prep", "ms_window", "ms_stitch")     # hipEvent times of the kernels
     host_ms = {}                                                                             # host wall figures of c3_batch_run
 
-    def step(timed):
+    # results: c3_batch_results_snapshot freezes them on the device right after the run; a helper thread copies the snapshot to the
+    # host (c3_batch_results_fetch) while this thread commits, stages and runs the NEXT batch -- the same pattern as the CLI's
+    # fetch thread (c3poa_amd/stream.py).  Every timed step still delivers one batch of results: the copy of step k lands during
+    # step k+1 and the last one is waited for inside the timed region.
+    fetcher = _lib.ResultFetcher(h, pinned=bool(int(os.environ.get('C3_BENCH_PINNED_RESULTS', '0'))))
+
+    def step(timed, k):
         h.stage_pinned(host)                     # next batch: copy engine + pack kernel on the second stream
         t1 = time.perf_counter()
         h.run()                                  # resident batch: conk -> peaks -> POA -> polish
         t2 = time.perf_counter()
-        out = h.results_raw()                    # per-read records + consensus bytes on the host
+        out = fetcher.after_run()                # snapshot of this batch; returns the PREVIOUS batch's records + consensus bytes
         t3 = time.perf_counter()
         h.commit()
         if timed:
             run_s.append(t2 - t1); fetch_s.append(t3 - t2)
-            for k, v in h.last_timing.items():
-                if k in KERNEL_MS:
-                    stage_ms.setdefault(k, []).append(v)
-                elif k in ("ms_wall", "ms_host_worklist", "ms_alloc", "ms_host_gap"):
-                    host_ms.setdefault(k, []).append(v)
+            for k_, v in h.last_timing.items():
+                if k_ in KERNEL_MS:
+                    stage_ms.setdefault(k_, []).append(v)
+                elif k_ in ("ms_wall", "ms_host_worklist", "ms_alloc", "ms_host_gap"):
+                    host_ms.setdefault(k_, []).append(v)
         return out
 
-    for _ in range(a.warmup):
-        step(False)
+    for k in range(a.warmup):
+        step(False, k)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for k in range(a.steps):
         h.last_timing = None
-        res_raw = step(True)
+        step(True, a.warmup + k)
+    t_last = time.perf_counter()
+    res_raw = fetcher.drain()                    # the last batch's results
+    fetch_s.append(time.perf_counter() - t_last)
     barrier()
     dt = time.perf_counter() - t0
+    fetcher.close()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -285,12 +295,12 @@ def main():
             "data": "synthetic (c3poa_amd.synth %s: %d distinct reads%s)" % (
                 a.cfg, n_unique, "" if reps == 1 else ", tiled x%d" % reps),
             "config": {"workload": "%s: %d reads/GPU/step, %s" % (a.cfg, a.reads, WORKLOAD_TEXT.get(a.cfg, "")),
-                       "stages": "stage(H2D+pack, overlapped) | conk+peaks/split+POA+polish | results(D2H) | commit",
+                       "stages": "stage(H2D+pack, overlapped) | conk+peaks/split+POA+polish | results snapshot (D2H by a helper thread beside the next run) | commit",
                        "reads_per_gpu_step": a.reads, "shard_digests": digests,
                        "consensus_ok": int(ok.sum()), "mean_read_len": float(lens.mean()),
                        "identity_vs_truth": {"mean": round(float(idents.mean()), 5), "median": round(float(np.median(idents)), 5), "reads": int(n_id)},
                        "resident_only_reads_per_s": round(a.reads * world / float(np.mean(run_s)), 1),
-                       "run_ms": round(float(np.mean(run_s)) * 1e3, 2), "fetch_ms": round(float(np.mean(fetch_s)) * 1e3, 2),
+                       "run_ms": round(float(np.mean(run_s)) * 1e3, 2), "fetch_ms_exposed": round(float(np.sum(fetch_s)) / a.steps * 1e3, 2),
                        "upload_ms_unoverlapped": round(t_up * 1e3, 1)},
             "roofline": {"bound": "hbm", "kernel": dom.replace("ms_", "k_"), "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
@@ -301,6 +311,7 @@ def main():
                          "cells_per_step": int(cells),
                          "cells_polish_full_matrix": int(tm["cells_polish"]), "cells_polish_computed": int(tm["cells_polish_computed"]),
                          "band_layers": int(tm["n_band_layers"]), "band_fallback_layers": int(tm["n_band_fallback"]),
+                         "windows": int(tm["n_windows"]), "windows_second_launch": int(tm["n_win_redo"]),
                          "gcups": round(cells / (sum(avg.values()) * 1e-3) / 1e9, 2)},
             "gen_s": round(t_gen, 1),
         }
@@ -321,7 +332,7 @@ OTHER_UNIQUE = 20000
 
 
 def run_other_config(cfg, device, recs, gen_s, steps=3):
-    """the same pipelined step (stage || run -> results -> commit) on another BASELINE config, per-GPU size, `unique` distinct
+    """the same pipelined step (stage || run -> results snapshot -> commit, fetch beside the next run) on another BASELINE config, per-GPU size, `unique` distinct
     reads tiled: driver-clocked rates for cfg3 / cfg4 next to the cfg2 headline (parity of these shapes: tests/test_gpu_configs.py)"""
     import torch
     from c3poa_amd import _lib, synth
@@ -339,20 +350,23 @@ def run_other_config(cfg, device, recs, gen_s, steps=3):
     h.upload_pinned(host)
     kms = {}
 
+    fetcher = _lib.ResultFetcher(h, pinned=bool(int(os.environ.get('C3_BENCH_PINNED_RESULTS', '0'))))
+
     def step(timed):
-        h.stage_pinned(host); h.run(); res = h.results_raw(); h.commit()
+        h.stage_pinned(host); h.run(); fetcher.after_run(); h.commit()
         if timed:
             for k, v in h.last_timing.items():
                 if k.startswith("ms_") and k not in ("ms_pack", "ms_total", "ms_wall", "ms_alloc", "ms_host_worklist", "ms_host_gap"):
                     kms.setdefault(k, []).append(v)
-        return res
     step(False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
-        res_raw = step(True)
+        step(True)
+    res_raw = fetcher.drain()                    # (the copy of every step but the last ran beside the next step's kernels)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    fetcher.close()
     tm = h.last_timing
     res, cbuf, coff = res_raw
     raw = cbuf.tobytes()
@@ -361,7 +375,7 @@ def run_other_config(cfg, device, recs, gen_s, steps=3):
     o = {"value": round(n * steps / dt, 1), "unit": "reads/s", "reads_per_step": n, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2),
          "kernel_ms": {k: round(float(np.mean(v)), 2) for k, v in kms.items()},
          "cells": int(tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish"]), "cells_polish_computed": int(tm["cells_polish_computed"]),
-         "band_fallback_layers": int(tm["n_band_fallback"]), "band_layers": int(tm["n_band_layers"]),
+         "band_fallback_layers": int(tm["n_band_fallback"]), "band_layers": int(tm["n_band_layers"]), "windows_second_launch": int(tm["n_win_redo"]),
          "consensus_ok": int((res["status"] == 0).sum()), "identity_vs_truth_mean": round(float(np.mean(idents)), 5),
          "data": "synthetic %s, %d distinct reads tiled x%d" % (cfg, nu, reps), "gen_s": round(gen_s, 1)}
     h.close(); host.close()

@@ -16,7 +16,7 @@ STAGE_CONK, STAGE_PEAKS, STAGE_POA, STAGE_POLISH, STAGES_ALL = 1, 2, 4, 8, 15
 ST_OK, ST_NOT_ASSIGNED, ST_NO_PEAKS, ST_NO_CONSENSUS, ST_TOO_SHORT, ST_LIMIT = range(6)
 
 EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_create", "c3_destroy", "c3_last_error", "c3_set_splints",
-           "c3_batch_upload", "c3_batch_stage", "c3_batch_commit", "c3_batch_assign", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_timing",
+           "c3_batch_upload", "c3_batch_stage", "c3_batch_commit", "c3_batch_assign", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_results_snapshot", "c3_batch_results_fetch", "c3_batch_timing",
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
            "c3_call_peaks", "c3_poa_msa", "c3_pairwise_consensus", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
            "c3_reader_open", "c3_reader_open_range", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_reader_next_set", "c3_reader_noqual", "c3_reader_reserved_bytes", "c3_reader_range_lost", "c3_write_group",
@@ -53,7 +53,7 @@ class Timing(C.Structure):
                                          "ms_stitch", "ms_total")] + \
                [(n, C.c_int64) for n in ("n_reads", "n_bases", "n_windows", "cells_conk", "cells_poa", "cells_polish", "n_poa_redo")] + \
                [(n, C.c_float) for n in ("ms_wall", "ms_host_worklist", "ms_alloc", "ms_host_gap")] + \
-               [(n, C.c_int64) for n in ("cells_polish_computed", "n_band_layers", "n_band_fallback", "n_band_mismatch")]
+               [(n, C.c_int64) for n in ("cells_polish_computed", "n_band_layers", "n_band_fallback", "n_band_mismatch", "n_win_redo")]
 
 
 class HostBatchStruct(C.Structure):
@@ -89,6 +89,8 @@ def load():
     lib.c3_batch_run.argtypes = [vp, C.c_int]
     lib.c3_batch_sync.argtypes = [vp]
     lib.c3_batch_results.argtypes = [vp, vp, vp, C.c_int64, i64p]
+    lib.c3_batch_results_snapshot.argtypes = [vp]
+    lib.c3_batch_results_fetch.argtypes = [vp, vp, vp, C.c_int64, i64p]
     lib.c3_batch_timing.argtypes = [vp, C.POINTER(Timing)]
     lib.c3_fetch_track.argtypes = [vp, C.c_int, vp, C.c_int64]
     lib.c3_fetch_smoothed.argtypes = [vp, C.c_int, vp, C.c_int64]
@@ -272,6 +274,21 @@ class Handle:
         self._chk(self.lib.c3_batch_results(self.h, res.ctypes.data, buf.ctypes.data, len(buf), coff.ctypes.data))
         return res, buf, coff
 
+    def results_snapshot(self):
+        """first half of results_raw (c3_batch_results_snapshot): freezes the results of the resident batch on the device; the
+        handle may then commit and run the next batch.  Returns what results_fetch needs to size its buffers."""
+        self._chk(self.lib.c3_batch_results_snapshot(self.h))
+        return self.n, int(self.off[-1]) + 16
+
+    def results_fetch(self, into, shape):
+        """second half (c3_batch_results_fetch): copies the snapshot into `into` (a ResultBuffers); may run on ANOTHER thread
+        while this handle's owner works on the next batch.  `shape` = the value results_snapshot returned."""
+        res, buf, coff = into.fit(*shape)
+        rc = self.lib.c3_batch_results_fetch(self.h, res.ctypes.data, buf.ctypes.data, len(buf), coff.ctypes.data)
+        if rc != 0:
+            raise C3Error("c3_batch_results_fetch failed (%d)" % rc)
+        return res, buf, coff
+
     def results(self, with_consensus=True):
         res = np.zeros(self.n, dtype=RESULT_DTYPE)
         coff = np.zeros(self.n + 1, dtype=np.int64)
@@ -424,17 +441,76 @@ def device_count():
 
 
 class ResultBuffers:
-    """grow-only host buffers for one batch of results (no page faults per batch); owned by whoever holds the object"""
+    """grow-only host buffers for one batch of results (no page faults per batch); owned by whoever holds the object.
+    pinned=True takes them from c3_host_alloc (page-locked): what c3_batch_results_begin needs to copy asynchronously"""
 
-    def __init__(self):
-        self.res = self.buf = None
+    def __init__(self, pinned=False):
+        self.res = self.buf = self.coff = None
+        self.pinned = pinned
+        self._p = []
+        self.lib = load() if pinned else None
+
+    def _alloc(self, count, dtype):
+        if not self.pinned:
+            return np.empty(count, dtype=dtype)
+        nbytes = count * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        if self.lib.c3_host_alloc(nbytes + 64, C.byref(p)) != 0:
+            raise MemoryError("c3_host_alloc(%d)" % nbytes)
+        self._p.append(p)
+        return np.frombuffer((C.c_char * nbytes).from_address(p.value), dtype=dtype, count=count)
 
     def fit(self, n, cons_cap):
         if self.buf is None or len(self.buf) < cons_cap:
-            self.buf = np.empty(cons_cap + cons_cap // 4, dtype=np.uint8)
+            self.buf = self._alloc(cons_cap + cons_cap // 4, np.uint8)
         if self.res is None or len(self.res) < n:
-            self.res = np.empty(n + n // 4 + 1, dtype=RESULT_DTYPE)
-        return self.res[:n], self.buf, np.zeros(n + 1, dtype=np.int64)
+            self.res = self._alloc(n + n // 4 + 1, RESULT_DTYPE)
+        if not self.pinned:
+            return self.res[:n], self.buf, np.zeros(n + 1, dtype=np.int64)
+        if self.coff is None or len(self.coff) < n + 1:
+            self.coff = self._alloc(n + n // 4 + 2, np.int64)
+        return self.res[:n], self.buf, self.coff[:n + 1]
+
+    def close(self):
+        self.res = self.buf = self.coff = None
+        for p in self._p:
+            self.lib.c3_host_free(p)
+        self._p = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ResultFetcher:
+    """software pipeline for the results of one handle: after_run() freezes the resident batch's results on the device
+    (c3_batch_results_snapshot) and hands the copy to a helper thread (c3_batch_results_fetch: it runs beside the next batch's
+    kernels); it returns the PREVIOUS batch's (res, cons bytes, cons_off), or None the first time.  drain() returns the last."""
+
+    def __init__(self, handle, n_buffers=2, pinned=False):
+        from concurrent.futures import ThreadPoolExecutor
+        self.h = handle
+        self.pool = ThreadPoolExecutor(1)
+        self.rbs = [ResultBuffers(pinned=pinned) for _ in range(n_buffers)]
+        self.k = 0
+        self.fut = None
+
+    def after_run(self):
+        prev = self.drain()
+        shape = self.h.results_snapshot()
+        self.fut = self.pool.submit(self.h.results_fetch, self.rbs[self.k % len(self.rbs)], shape)
+        self.k += 1
+        return prev
+
+    def drain(self):
+        fut, self.fut = self.fut, None
+        return fut.result() if fut is not None else None
+
+    def close(self):
+        self.drain()
+        self.pool.shutdown()
 
 
 class PinnedBatch:

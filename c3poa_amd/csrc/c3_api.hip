@@ -64,6 +64,40 @@ __global__ __launch_bounds__(256) void k_gather_cons(const char* arena, const in
     for (int64_t k = lane; k < len; k += 64) dst[k] = src[k];
   }
 }
+// cons_off[i + 1] = sum over reads <= i of (status OK ? cons_len : 0), on the device (three tiny launches: block sums, scan of the
+// block sums by one block, block-local scan + block offset): the host no longer needs the records before it can size the copy
+__device__ __forceinline__ long long cons_len_of(const C3Info* p) { return p->status == C3_ST_OK ? (long long)p->cons_len : 0; }
+__global__ __launch_bounds__(256) void k_coff_sums(const C3Info* info, int n, long long* part) {
+  __shared__ long long sh[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  sh[threadIdx.x] = i < n ? cons_len_of(info + i) : 0;
+  __syncthreads();
+  for (int d = 128; d > 0; d >>= 1) { if ((int)threadIdx.x < d) sh[threadIdx.x] += sh[threadIdx.x + d]; __syncthreads(); }
+  if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+__global__ __launch_bounds__(1024) void k_coff_scan(long long* part, int nb, int64_t* coff, int n) {
+  __shared__ long long sh[1024];
+  long long carry = 0;
+  for (int b0 = 0; b0 < nb; b0 += 1024) {
+    const int b = b0 + threadIdx.x;
+    const long long v = b < nb ? part[b] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { long long t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
+    if (b < nb) part[b] = carry + sh[threadIdx.x] - v;               // exclusive
+    carry += sh[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { coff[0] = 0; coff[n] = carry; }
+}
+__global__ __launch_bounds__(256) void k_coff_final(const C3Info* info, int n, const long long* part, int64_t* coff) {
+  __shared__ long long sh[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  sh[threadIdx.x] = i < n ? cons_len_of(info + i) : 0;
+  __syncthreads();
+  for (int d = 1; d < 256; d <<= 1) { long long t = (int)threadIdx.x >= d ? sh[threadIdx.x - d] : 0; __syncthreads(); sh[threadIdx.x] += t; __syncthreads(); }
+  if (i < n) coff[i + 1] = part[blockIdx.x] + sh[threadIdx.x];
+}
 __global__ void k_init_info(C3Info* info, int n) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) { C3Info* p = &info[i]; p->status = C3_ST_OK; p->n_peaks = 0; p->n_sub = 0; p->has_front = p->has_tail = 0;
@@ -83,6 +117,7 @@ __global__ void k_summary(const C3Info* info, const int64_t* off, int n, Summary
   out[i] = s;
 }
 
+#include <atomic>
 #include <chrono>
 static inline double dbg_now_ms() { using namespace std::chrono; return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count(); }
 // C3_DEBUG=1: progress lines on stderr, each stamped with the host clock (ms) -- shows the host gaps between the stages
@@ -99,6 +134,9 @@ struct DBuf {
     size_t want = bytes + bytes / 8 + 256;
     hipError_t e = hipMalloc(&p, want);
     if (e == hipSuccess) cap = want;
+    // test hook: fresh device memory usually reads as zero, which hides reads of cells nobody wrote; C3_DEBUG_POISON fills every
+    // new buffer with a pattern instead (tests/test_gpu_band.py runs the pipeline that way)
+    if (e == hipSuccess && getenv("C3_DEBUG_POISON")) e = hipMemset(p, 0xA5, want);
     g_alloc_ms += dbg_now_ms() - t0;
     return e;
   }
@@ -111,6 +149,10 @@ struct c3_handle {
   c3_config cfg; std::string err; hipStream_t stream = nullptr; int n_cus = 256; size_t mem_total = 0;
   // staged (next) batch: copied on its own stream while the resident batch is being processed
   hipStream_t stream_up = nullptr; hipEvent_t ev_up[2] = {nullptr, nullptr};
+  // results in flight (c3_batch_results_snapshot .. _fetch): snapshot of the records + compact consensus bytes, copied on a third stream
+  hipStream_t stream_dn = nullptr; hipEvent_t ev_dn = nullptr; long long* h_tot = nullptr;
+  std::atomic<bool> snap_pending{false}; int snap_n = 0, snap_kp = 0; long long snap_tot = 0; bool snap_cons = false;
+  DBuf d_info_snap, d_coff_part;
   struct Staged { DBuf d_ascii, d_pk, d_woff, d_qual, d_off, d_strand, d_sid; std::vector<int64_t> off, woff; std::vector<int16_t> sid; std::string strand;
                   int n = 0; int64_t total = 0, words = 0, maxL = 0; bool pending = false; } st;
   hipEvent_t ev[EV_N];
@@ -123,7 +165,7 @@ struct c3_handle {
   DBuf s_poa_i, s_poa_nk, s_poa_cells, s_poa_b, s_poa_sc, s_poa_desc, s_poa_jump, s_poa_path, d_overflow;      // POA scratch
   int n_poa_redo = 0;        // reads of the last run that needed the full-size second POA pass
   DBuf s_eH, s_eD, s_lw, d_wrec, d_wlay, d_wbase, d_wout;       // prep / windows
-  DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc;
+  DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc, s_win_h2, s_win_d2, d_wovf;
   DBuf s_zero_d, d_zinfo, d_zflag, d_zwork; std::vector<int> zwork;  // window scratch
   std::vector<Summary> sum; std::vector<int> work;
   int res_prefix = 0;            // entries of peaks[] / sub_beg[] / sub_end[] that any read of the resident batch uses (0: unknown)
@@ -182,6 +224,9 @@ extern "C" int c3_create(const c3_config* cfg, c3_handle** out) {
   h->mem_total = prop.totalGlobalMem;
   if ((e = hipStreamCreate(&h->stream)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   if ((e = hipStreamCreate(&h->stream_up)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  if ((e = hipStreamCreate(&h->stream_dn)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  if ((e = hipEventCreateWithFlags(&h->ev_dn, hipEventDisableTiming)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  if ((e = hipHostMalloc((void**)&h->h_tot, 64, hipHostMallocDefault)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   for (int i = 0; i < 2; ++i) if ((e = hipEventCreate(&h->ev_up[i])) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   for (int i = 0; i < EV_N; ++i) if ((e = hipEventCreate(&h->ev[i])) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   memset(&h->tm, 0, sizeof(h->tm));
@@ -193,6 +238,10 @@ extern "C" void c3_destroy(c3_handle* h) {
   if (!h) return;
   (void)hipSetDevice(h->cfg.device);
   (void)hipStreamSynchronize(h->stream);
+  if (h->stream_dn) { (void)hipStreamSynchronize(h->stream_dn); (void)hipStreamDestroy(h->stream_dn); }
+  if (h->ev_dn) (void)hipEventDestroy(h->ev_dn);
+  if (h->h_tot) (void)hipHostFree(h->h_tot);
+  h->d_info_snap.release(); h->d_coff_part.release(); h->s_win_h2.release(); h->s_win_d2.release(); h->d_wovf.release();
   DBuf* all[] = {&h->d_sp_codes, &h->d_sp_len, &h->d_ascii, &h->d_pk, &h->d_woff, &h->d_qual, &h->d_off, &h->d_strand, &h->d_sid,
                  &h->d_info, &h->d_track, &h->d_draft, &h->d_tpos, &h->d_cons, &h->d_counter, &h->d_raw, &h->d_nraw, &h->d_sum,
                  &h->d_work, &h->d_bufA, &h->d_bufB, &h->d_cand, &h->d_cst, &h->d_msa, &h->d_msa_off, &h->d_msa_len,
@@ -403,6 +452,14 @@ static int copy_summary(c3_handle* h) {
   hipLaunchKernelGGL(k_summary, dim3((n + 255) / 256), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), h->d_off.as<int64_t>(), n, h->d_sum.as<Summary>());
   h->sum.resize(n);
   HIPCHK(hipMemcpyAsync(h->sum.data(), h->d_sum.p, sizeof(Summary) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  // This wait (k_conk + k_peaks, ~15 % of a batch) is followed by the only host section the GPU waits for: the work list.  A
+  // thread that slept through it (blocking sync) wakes up on a core that has dropped its clock, and the section then takes twice
+  // as long (measured: 2.0 ms against 0.9 per 100 000 reads); so THIS wait polls.
+  if (!getenv("C3_NO_SPIN")) {
+    hipError_t q;
+    while ((q = hipStreamQuery(h->stream)) == hipErrorNotReady) { for (int k_ = 0; k_ < 64; ++k_) __builtin_ia32_pause(); }
+    if (q != hipSuccess) HIPCHK(q);
+  }
   HIPCHK(hipStreamSynchronize(h->stream));
   // longest used prefix of the per-read arrays (peaks / kept subreads are final after k_peaks; the zero-repeat rescue adds two)
   int k = 2;
@@ -623,16 +680,29 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   if (n_win > 0) {
     HIPCHK(h->d_wout.ensure((size_t)n_win * wout_cap));
     const int Ncap = 3 * WL + 40 * NLcap, K = NLcap + 2;   // cfg2: 1700 nodes -> 10.2 KB of LDS per wave, 16 waves per CU
-    long long hcap = (long long)(Ncap + 1) * 64 * 12;
-    if (const char* e = getenv("C3_DEBUG_HCAP_DIV")) hcap = hcap / std::max(1, atoi(e)) / 64 * 64;       // experiment: smaller DP scratch per slot (wide unbanded layers then fail)
+    // DP scratch per slot, in cells (4 bytes of H + 1 byte of D each).  Worst case: every node a row, 704+ columns.  The FIRST
+    // launch gets what the usual layer needs -- banded rows or a matrix of at most 256 columns over a graph of a window and a
+    // quarter plus the branches its layers add: 256 bytes of direction words per row (+ a quarter for the index rows) -- which is
+    // a sixth of the worst case; a window with a layer beyond that is queued on the device and redone by a SECOND launch with
+    // worst-case scratch on a few slots (no host round trip: it reads the count from device memory).  40 GB -> 8 GB of scratch
+    // at cfg2 / cfg5 on 256 CUs: that much less to allocate and to touch for the first time in a fresh process.
+    const long long hcap_full = (long long)(Ncap + 1) * 64 * 12;
+    const int R_typ = std::min(Ncap, WL + WL / 4 + 30 * NLcap + 64);
+    long long hcap = std::min(hcap_full, (long long)(R_typ + R_typ / 4 + 4) * 256);
+    if (const char* e = getenv("C3_DEBUG_HCAP_DIV")) hcap = std::max(4096LL, hcap_full / std::max(1, atoi(e)) / 64 * 64);       // test hook: smaller first-launch scratch (more windows take the second launch)
     const size_t N = (size_t)Ncap;
     const int NI = 19;      // W_INTS of k_polish.hip
-    const size_t per_slot = N * (NI * 4 + 8 + 2) + N * K * 16 + (size_t)hcap * 6;
+    const size_t per_slot = N * (NI * 4 + 8 + 2) + N * K * 16 + (size_t)hcap * 5;
     const int slots = auto_slots(h, h->cfg.slots_win, per_slot, n_win, 20);
+    const int slots2 = hcap < hcap_full ? std::min(slots, 256) : 0;
     HIPCHK(h->s_win_i.ensure(sizeof(int) * N * NI * slots + 64)); HIPCHK(h->s_win_nk.ensure(sizeof(int) * N * K * 4 * slots));
-    HIPCHK(h->s_win_h.ensure(sizeof(int32_t) * (size_t)hcap * slots)); HIPCHK(h->s_win_d.ensure(sizeof(uint16_t) * (size_t)hcap * slots));
+    HIPCHK(h->s_win_h.ensure(sizeof(int32_t) * (size_t)hcap * slots)); HIPCHK(h->s_win_d.ensure((size_t)hcap * slots + 256));
     HIPCHK(h->s_win_b.ensure(N * 2 * slots)); HIPCHK(h->s_win_sc.ensure(sizeof(long long) * N * slots));
     HIPCHK(h->s_win_desc.ensure(sizeof(uint4) * (N + 1) * slots));
+    if (slots2) {
+      HIPCHK(h->s_win_h2.ensure(sizeof(int32_t) * (size_t)hcap_full * slots2)); HIPCHK(h->s_win_d2.ensure((size_t)hcap_full * slots2 + 256));
+      HIPCHK(h->d_wovf.ensure(sizeof(int) * (size_t)n_win));
+    }
     WinArgs a; memset(&a, 0, sizeof(a));
     a.b = dev_batch(h); a.p = dev_params(h->cfg); a.counter = h->d_counter.as<int>(); a.n_win = n_win;
     a.wrec_in = h->d_wrec.as<WinRec>(); a.wrec = h->d_wrec.as<WinRec>(); a.wlay = h->d_wlay.as<WLayer>(); a.NLcap = NLcap;
@@ -645,8 +715,15 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 256, h->stream));
     a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
     if (const char* e = getenv("C3_DEBUG_BAND")) a.band_mode = !strcmp(e, "off") ? 1 : !strcmp(e, "fail") ? 2 : !strcmp(e, "verify") ? 3 : 0;    // test hook (tests/test_gpu_band.py)
+    a.queue_idx = 0; a.ovf_list = slots2 ? h->d_wovf.as<int>() : nullptr;
     c3k_launch_window(&a, slots, h->stream);
     HIPCHK(hipGetLastError());
+    if (slots2) {
+      a.H = h->s_win_h2.as<int32_t>(); a.D = h->s_win_d2.as<uint16_t>(); a.hcap = hcap_full;
+      a.wlist = h->d_wovf.as<int>(); a.n_win_dev = h->d_counter.as<int>() + W_CNT_OVF; a.ovf_list = nullptr; a.queue_idx = W_CNT_Q2;
+      c3k_launch_window(&a, slots2, h->stream);
+      HIPCHK(hipGetLastError());
+    }
     HIPCHK(hipMemcpyAsync(h->phase_win, h->d_counter.as<char>() + 64, 128, hipMemcpyDeviceToHost, h->stream));
   }
   HIPCHK(hipEventRecord(h->ev[8], h->stream));
@@ -658,8 +735,11 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   c3k_launch_stitch(&s, std::min(nw, h->n_cus * 16), h->stream);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(h->ev[9], h->stream));
-  HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 64, hipMemcpyDeviceToHost, h->stream));
+  int cnt_all[64];
+  HIPCHK(hipMemcpyAsync(cnt_all, h->d_counter.p, 256, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  memcpy(cnt, cnt_all, 64);
+  if (n_win > 0) h->tm.n_win_redo = cnt_all[W_CNT_OVF];
   if (n_win > 0) { h->tm.cells_polish += *(long long*)(cnt + 2); h->tm.cells_polish_computed += *(long long*)(cnt + 4); h->tm.n_band_layers = cnt[6]; h->tm.n_band_fallback = cnt[7]; h->tm.n_band_mismatch = cnt[8]; if (cnt[8]) fprintf(stderr, "c3poa: band verify mismatch in window %d layer %d (R = %d): last differing base q = %d, band row %d, full row %d, row of q+1 = %d\n", cnt[9], cnt[10], cnt[11], cnt[12], cnt[13], cnt[14], cnt[15]); }
   HIPCHK(hipEventElapsedTime(ms_prep, h->ev[5], h->ev[6]));
   HIPCHK(hipEventElapsedTime(ms_win, h->ev[7], h->ev[8]));
@@ -681,7 +761,7 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
   if (stages & C3_STAGE_CONK) { h->tm.ms_conk = 0; h->tm.cells_conk = 0; }
   if (stages & C3_STAGE_PEAKS) h->tm.ms_peaks = 0;
   if (stages & C3_STAGE_POA) { h->tm.ms_poa = 0; h->tm.cells_poa = 0; }
-  if (stages & C3_STAGE_POLISH) { h->tm.ms_prep = h->tm.ms_window = h->tm.ms_stitch = 0; h->tm.cells_polish = 0; h->tm.cells_polish_computed = 0; h->tm.n_band_layers = h->tm.n_band_fallback = h->tm.n_band_mismatch = 0; h->tm.n_windows = 0; }
+  if (stages & C3_STAGE_POLISH) { h->tm.ms_prep = h->tm.ms_window = h->tm.ms_stitch = 0; h->tm.cells_polish = 0; h->tm.cells_polish_computed = 0; h->tm.n_band_layers = h->tm.n_band_fallback = h->tm.n_band_mismatch = 0; h->tm.n_windows = 0; h->tm.n_win_redo = 0; }
   HIPCHK(hipEventRecord(t0, h->stream));
   if (stages & C3_STAGE_CONK) { if ((rc = run_conk(h))) return rc; h->tm.cells_conk = 0; for (int i = 0; i < h->n; ++i) h->tm.cells_conk += (h->off[i + 1] - h->off[i]) * (int64_t)h->max_spl; }
   HIPCHK(hipEventRecord(t1, h->stream));
@@ -729,41 +809,97 @@ extern "C" int c3_batch_sync(c3_handle* h) {
   return C3_E_OK;
 }
 
+// Results of the resident batch, in two halves so that the copy can run beside the NEXT batch's kernels:
+//   c3_batch_results_snapshot  (owner thread, after c3_batch_run) freezes the records and the compact consensus bytes in device
+//                              buffers of their own: offsets by a device scan (one 8-byte read back for the total), one gather
+//                              kernel, three strided device copies -- ~0.3 ms;
+//   c3_batch_results_fetch     copies the snapshot into the caller's buffers on the handle's third stream and waits for it.  It
+//                              touches nothing but the snapshot, so ANOTHER thread may call it while the owner commits and runs
+//                              the next batch (the only pair of calls on one handle that may overlap).
+// One snapshot exists per handle: a second _snapshot before the _fetch returns C3_E_STATE.  c3_batch_results = both, back to back.
+extern "C" int c3_batch_results_snapshot(c3_handle* h) {
+  if (!h || h->n <= 0) return C3_E_ARG;
+  if (h->snap_pending.load(std::memory_order_acquire)) return c3_fail(h, C3_E_STATE, "c3_batch_results_snapshot: the previous snapshot has not been fetched");
+  HIPCHK(hipSetDevice(h->cfg.device));
+  const int n = h->n;
+  DBuf& d_coff = h->d_gather_off; DBuf& d_out = h->d_gather;
+  const int nb = (n + 255) / 256;
+  HIPCHK(d_coff.ensure(sizeof(int64_t) * (size_t)(n + 1))); HIPCHK(h->d_coff_part.ensure(sizeof(long long) * (size_t)nb));
+  hipLaunchKernelGGL(k_coff_sums, dim3(nb), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), n, h->d_coff_part.as<long long>());
+  hipLaunchKernelGGL(k_coff_scan, dim3(1), dim3(1024), 0, h->stream, h->d_coff_part.as<long long>(), nb, d_coff.as<int64_t>(), n);
+  hipLaunchKernelGGL(k_coff_final, dim3(nb), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), n, h->d_coff_part.as<long long>(), d_coff.as<int64_t>());
+  long long tot = 0;
+  const bool have_cons = (h->stages_done & C3_STAGE_POLISH) != 0;
+  if (have_cons) {
+    HIPCHK(hipMemcpyAsync(h->h_tot, d_coff.as<int64_t>() + n, sizeof(long long), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    tot = *h->h_tot;
+  }
+  // A record is 3 kB of which a typical read uses ~150 bytes: the header plus the first n_peaks / n_sub entries of three
+  // arrays.  When the batch's longest prefix is known (after the POA / polish stages) only those bytes are kept and cross PCIe, as
+  // three strided copies; array entries past a read's n_peaks / n_sub are then UNSPECIFIED in the caller's records.
+  const int kp = h->res_prefix;
+  const bool prefix = kp > 0 && kp * 4 < C3_MAX_PEAKS && (h->stages_done & (C3_STAGE_POA | C3_STAGE_POLISH)) && !getenv("C3_FULL_RESULTS");
+  const size_t pitch = sizeof(C3Info), head = offsetof(C3Info, peaks);
+  const size_t o_sb = offsetof(C3Info, sub_beg), o_se = offsetof(C3Info, sub_end);
+  HIPCHK(h->d_info_snap.ensure(pitch * (size_t)n));
+  const char* src = h->d_info.as<char>(); char* snap = h->d_info_snap.as<char>();
+  if (prefix) {
+    HIPCHK(hipMemcpy2DAsync(snap, pitch, src, pitch, head + 4 * (size_t)kp, (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpy2DAsync(snap + o_sb, pitch, src + o_sb, pitch, 4 * (size_t)kp, (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipMemcpy2DAsync(snap + o_se, pitch, src + o_se, pitch, 4 * (size_t)kp, (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+  } else {
+    HIPCHK(hipMemcpyAsync(snap, src, pitch * (size_t)n, hipMemcpyDeviceToDevice, h->stream));
+  }
+  if (have_cons && tot > 0) {
+    // gather on the device (one wave per read): the fetch is then ONE device->host copy of the compact bytes
+    HIPCHK(d_out.ensure((size_t)tot + 64));
+    hipLaunchKernelGGL(k_gather_cons, dim3((unsigned)std::min((n + 3) / 4, h->n_cus * 32)), dim3(256), 0, h->stream,
+                       h->d_cons.as<char>(), h->d_off.as<int64_t>(), d_coff.as<int64_t>(), n, d_out.as<char>());
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(h->ev_dn, h->stream));
+  h->snap_n = n; h->snap_kp = prefix ? kp : 0; h->snap_tot = tot; h->snap_cons = have_cons;
+  h->snap_pending.store(true, std::memory_order_release);
+  return C3_E_OK;
+}
+
+extern "C" int c3_batch_results_fetch(c3_handle* h, c3_read_result* res, char* cons, int64_t cons_cap, int64_t* cons_off) {
+  if (!h || !res) return C3_E_ARG;
+  if (!h->snap_pending.load(std::memory_order_acquire)) return C3_E_STATE;          // (h->err belongs to the owner thread: not touched here)
+  hipError_t e;
+#define DNCHK(x) do { if ((e = (x)) != hipSuccess) { h->snap_pending.store(false, std::memory_order_release); return C3_E_HIP; } } while (0)
+  DNCHK(hipSetDevice(h->cfg.device));
+  const int n = h->snap_n, kp = h->snap_kp;
+  const size_t pitch = sizeof(C3Info), head = offsetof(C3Info, peaks);
+  const size_t o_sb = offsetof(C3Info, sub_beg), o_se = offsetof(C3Info, sub_end);
+  const char* snap = h->d_info_snap.as<char>(); char* dst = (char*)res;
+  hipStream_t dn = h->stream_dn;
+  DNCHK(hipStreamWaitEvent(dn, h->ev_dn, 0));
+  if (kp > 0) {
+    DNCHK(hipMemcpy2DAsync(dst, pitch, snap, pitch, head + 4 * (size_t)kp, (size_t)n, hipMemcpyDeviceToHost, dn));
+    DNCHK(hipMemcpy2DAsync(dst + o_sb, pitch, snap + o_sb, pitch, 4 * (size_t)kp, (size_t)n, hipMemcpyDeviceToHost, dn));
+    DNCHK(hipMemcpy2DAsync(dst + o_se, pitch, snap + o_se, pitch, 4 * (size_t)kp, (size_t)n, hipMemcpyDeviceToHost, dn));
+  } else {
+    DNCHK(hipMemcpyAsync(dst, snap, pitch * (size_t)n, hipMemcpyDeviceToHost, dn));
+  }
+  if (cons_off) DNCHK(hipMemcpyAsync(cons_off, h->d_gather_off.p, sizeof(int64_t) * (size_t)(n + 1), hipMemcpyDeviceToHost, dn));
+  const bool fits = !(cons_off && cons) || h->snap_tot <= cons_cap;
+  if (cons_off && cons && fits && h->snap_cons && h->snap_tot > 0) DNCHK(hipMemcpyAsync(cons, h->d_gather.p, (size_t)h->snap_tot, hipMemcpyDeviceToHost, dn));
+  DNCHK(hipStreamSynchronize(dn));
+#undef DNCHK
+  h->snap_pending.store(false, std::memory_order_release);
+  return fits ? C3_E_OK : C3_E_LIMIT;                 // too small: the records and the offsets (needed size = cons_off[n]) were still delivered
+}
+
 extern "C" int c3_batch_results(c3_handle* h, c3_read_result* res, char* cons, int64_t cons_cap, int64_t* cons_off) {
   if (!h || h->n <= 0 || !res) return C3_E_ARG;
-  HIPCHK(hipSetDevice(h->cfg.device));
-  // A record is 3 kB of which a typical read uses ~150 bytes: the header plus the first n_peaks / n_sub entries of three
-  // arrays.  When the batch's longest prefix is known (after the POA / polish stages) only those bytes cross PCIe, as three
-  // strided copies; array entries past a read's n_peaks / n_sub are then UNSPECIFIED in the caller's records.
-  const int kp = h->res_prefix;
-  if (kp > 0 && kp * 4 < C3_MAX_PEAKS && (h->stages_done & (C3_STAGE_POA | C3_STAGE_POLISH)) && !getenv("C3_FULL_RESULTS")) {
-    const size_t pitch = sizeof(C3Info), head = offsetof(C3Info, peaks);
-    const char* src = h->d_info.as<char>(); char* dst = (char*)res;
-    HIPCHK(hipMemcpy2DAsync(dst, pitch, src, pitch, head + 4 * (size_t)kp, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpy2DAsync(dst + offsetof(C3Info, sub_beg), pitch, src + offsetof(C3Info, sub_beg), pitch, 4 * (size_t)kp, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipMemcpy2DAsync(dst + offsetof(C3Info, sub_end), pitch, src + offsetof(C3Info, sub_end), pitch, 4 * (size_t)kp, (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-  } else {
-    HIPCHK(hipMemcpyAsync(res, h->d_info.p, sizeof(C3Info) * (size_t)h->n, hipMemcpyDeviceToHost, h->stream));
-  }
-  HIPCHK(hipStreamSynchronize(h->stream));
-  if (!cons_off) return C3_E_OK;
-  cons_off[0] = 0;
-  for (int i = 0; i < h->n; ++i) cons_off[i + 1] = cons_off[i] + ((res[i].status == C3_ST_OK) ? res[i].cons_len : 0);
-  if (!cons) return C3_E_OK;
-  if (cons_off[h->n] > cons_cap) return c3_fail(h, C3_E_LIMIT, "consensus buffer too small");
-  if (!(h->stages_done & C3_STAGE_POLISH)) return C3_E_OK;
-  // gather on the device (one wave per read), then ONE device->host copy of the compact bytes into the caller's buffer
-  const int64_t tot = cons_off[h->n];
-  if (tot == 0) return C3_E_OK;
-  DBuf& d_coff = h->d_gather_off; DBuf& d_out = h->d_gather;
-  HIPCHK(d_coff.ensure(sizeof(int64_t) * (size_t)(h->n + 1))); HIPCHK(d_out.ensure((size_t)tot + 64));
-  HIPCHK(hipMemcpyAsync(d_coff.p, cons_off, sizeof(int64_t) * (size_t)(h->n + 1), hipMemcpyHostToDevice, h->stream));
-  hipLaunchKernelGGL(k_gather_cons, dim3((unsigned)std::min((h->n + 3) / 4, h->n_cus * 32)), dim3(256), 0, h->stream,
-                     h->d_cons.as<char>(), h->d_off.as<int64_t>(), d_coff.as<int64_t>(), h->n, d_out.as<char>());
-  HIPCHK(hipMemcpyAsync(cons, d_out.p, (size_t)tot, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipGetLastError());
-  return C3_E_OK;
+  int rc = c3_batch_results_snapshot(h);
+  if (rc) return rc;
+  rc = c3_batch_results_fetch(h, res, cons, cons_cap, cons_off);
+  if (rc == C3_E_LIMIT) return c3_fail(h, C3_E_LIMIT, "consensus buffer too small");
+  if (rc == C3_E_HIP) return c3_fail(h, C3_E_HIP, "HIP error while copying the results");
+  return rc;
 }
 
 // PMC calibration: read `bytes` with one dword per lane, write `bytes` with one dword per

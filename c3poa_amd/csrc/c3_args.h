@@ -38,7 +38,13 @@ struct WinArgs {
   int Lcap;                               // nodes the LDS consensus sweep can hold (<= Ncap)
   unsigned long long* phases;
   int band_mode;                          // 0 = banded rows with certificate (default), 1 = never banded, 2 = every certificate counts as failed (test hook: C3_DEBUG_BAND)
+  // two launches: the first with DP scratch for the typical layer (hcap small); a window one of whose layers does not fit is
+  // dropped untouched into `ovf_list` (count in counter[W_CNT_OVF]) and redone by the second launch, which has worst-case scratch,
+  // takes its windows from `wlist` and their number from device memory (`n_win_dev`), and its queue from counter[queue_idx]
+  const int* wlist; const int* n_win_dev; int* ovf_list; int queue_idx;
 };
+#define W_CNT_OVF 48                      /* d_counter ints: [0] queue of the first launch, [48] overflow count, [49] queue of the second */
+#define W_CNT_Q2 49
 struct StitchArgs {
   C3Batch b; C3Info* info; const int* work; int n_work; const WinRec* wrec; const int* win_base; const uint8_t* wout; int wout_cap; char* cons;
   const uint8_t* zflag;

@@ -995,9 +995,13 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
 
   for (;;) {
     int wi = 0;
-    if (lane == 0) wi = atomicAdd(a.counter, 1);
+    if (lane == 0) {
+      wi = atomicAdd(a.counter + a.queue_idx, 1);
+      const int nwq = a.n_win_dev ? *(const volatile int*)a.n_win_dev : a.n_win;
+      wi = wi < nwq ? (a.wlist ? a.wlist[wi] : wi) : -1;
+    }
     wi = wave_first(wi);
-    if (wi >= a.n_win) break;
+    if (wi < 0) break;
     PH_MARK(9)
     const WinRec rec = a.wrec_in[wi];
     const int rid = rec.rid, blen = rec.blen, nl = rec.n_layers;
@@ -1104,7 +1108,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         for (int attempt = 0; attempt < 4; ++attempt) {
           unsigned long long dbg_[6] = {0, 0, 0, 0, 0, 0};
           int nblocks = 0;
-          if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, d0bits, d1bits, ring_off, lds_ints, l.begin, l.end, blen, &cb, &nblocks) < 0) { fail = 1; break; }
+          if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, d0bits, d1bits, ring_off, lds_ints, l.begin, l.end, blen, &cb, &nblocks) < 0) { fail = a.ovf_list ? 2 : 1; break; }      // (2: the layer needs more DP scratch than this launch has -- the window goes to the full-size launch)
 #ifdef C3_PHASE_PROF
           ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1];
 #endif
@@ -1251,6 +1255,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
           }
         }
         WSYNC();
+        if (fail) break;                            // (no traceback happened: rq holds nothing -- the fusion below must not run)
         PH_MARK(5)
 #ifdef C3_PHASE_PROF
         ph_acc_[12] += tbp_[0]; ph_acc_[13] += tbp_[1]; ph_acc_[14] += tbp_[2]; ph_acc_[15] += tbp_[3];       // traceback census: blocks, steps, window misses (overrides the row-kind cycles)
@@ -1324,7 +1329,9 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         if (olen < 0) { fail = 1; olen = 0; } else polished = 1;
       }
     }
-    if (lane == 0) {
+    if (fail == 2) {
+      if (lane == 0) a.ovf_list[atomicAdd(a.counter + W_CNT_OVF, 1)] = wi;          // nothing of this window has been published
+    } else if (lane == 0) {
       WinRec* r = &a.wrec[wi];
       r->out_len = fail ? -1 : olen; r->polished = polished;
       atomicAdd((unsigned long long*)(a.counter + 2), (unsigned long long)cells);

@@ -219,8 +219,8 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
   struct { int pol_match, pol_mismatch, pol_gap; } P = {uni32(mt_), uni32(mm_), uni32(g_)};
   const int K = c.K;
   const int G = (R + RPW - 1) / RPW;
-  // direction words + predecessor-index rows in the D scratch (bytes: hcap * 2), far H rows in the H scratch
-  if ((long long)(G + 2 + R) * 256 > c.hcap * 2 || (long long)(R + 1) * HS * 2 + 64 > c.hcap * 4 || R >= 65535) return -1;
+  // direction words + predecessor-index rows in the D scratch (hcap bytes per slot), far H rows in the H scratch (4 * hcap bytes)
+  if ((long long)(G + 2 + R) * 256 > c.hcap || (long long)(R + 1) * HS * 2 + 64 > c.hcap * 4 || R >= 65535) return -1;
   unsigned short* const H16 = (unsigned short*)c.H;
   unsigned* const DW = (unsigned*)c.D;
   unsigned* const PX = DW + (size_t)(G + 1) * 64;

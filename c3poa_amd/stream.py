@@ -61,7 +61,10 @@ class DictAssigner:
         return sid, bytes(st), k
 
 
-def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, finder_psl=None):
+_KEPT = []
+
+
+def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, finder_psl=None, keep_pinned=False):
     """the second pass of C3POa.py:236-271.  assigner: _lib.Assigner (native PSL table) or an adapter_dict.
     assigner=None is the fused mode: no PSL exists yet, so every batch is first scored against all splints on both
     strands (c3_scan_splints), assigned on the device (c3_batch_assign) and its PSL rows appended to finder_psl -- one pass
@@ -129,7 +132,11 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
         free_results.put(_lib.ResultBuffers())
     parsed = [queue.Queue(maxsize=1) for _ in range(n_ranges)]
     to_write = [queue.Queue(maxsize=2) for _ in range(n_work)]
-    t = dict(parse=0.0, assign=0.0, upload=0.0, upload_dev=0.0, run=0.0, run_c=0.0, run_dev=0.0, alloc=0.0, fetch=0.0, write=0.0, wait_in=0.0, wait_out=0.0,
+    to_fetch = [queue.Queue(maxsize=1) for _ in range(n_work)]
+    fetched = [threading.Event() for _ in range(n_work)]
+    for ev_ in fetched:
+        ev_.set()
+    t = dict(parse=0.0, assign=0.0, upload=0.0, upload_dev=0.0, run=0.0, run_c=0.0, run_dev=0.0, alloc=0.0, fetch=0.0, snapshot=0.0, write=0.0, wait_in=0.0, wait_out=0.0,
              setup=0.0, close=0.0, scan=0.0, reads=0, batches=0, short=0, assigned=0, ranges=n_ranges)
     seen = set()
     errors, lock = [], threading.Lock()
@@ -241,14 +248,20 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                 up_dev = h.last_timing["ms_pack"] * 1e-3
                 run_dev = h.last_timing["ms_total"] * 1e-3
                 run_c = h.last_timing.get("ms_wall", 0.0) * 1e-3; wl_c = h.last_timing.get("ms_alloc", 0.0) * 1e-3
-                rb = free_results.get()
-                res, buf, coff = h.results_raw(into=rb)
+                # results: frozen on the device here (c3_batch_results_snapshot, ~0.3 ms); the worker's fetch thread copies them to
+                # the host while this thread commits and runs the next batch.  One snapshot per handle: wait for the previous fetch
+                # (it started a whole batch ago)
+                fetched[w].wait()
+                if errors:
+                    break
+                fetched[w].clear()
+                shape = h.results_snapshot()
                 t3 = time.perf_counter()
                 with lock:
                     t["upload_dev"] += up_dev; t["run_dev"] += run_dev; t["run_c"] += run_c; t["alloc"] += wl_c
-                    t["run"] += t2 - t1; t["fetch"] += t3 - t2
+                    t["run"] += t2 - t1; t["snapshot"] += t3 - t2
                 tw = time.perf_counter()
-                to_write[w].put((hb, sid, res, buf, coff, rb))
+                to_fetch[w].put((h, hb, sid, shape))
                 with lock:
                     t["wait_out"] += time.perf_counter() - tw
                 if done:
@@ -267,6 +280,7 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                 cur = nxt
             tc = time.perf_counter()
             t["at_last_run_done"] = tc - t_start
+            fetched[w].wait()                       # the last snapshot has been copied out
             h.close()
             with lock:
                 t["close"] += time.perf_counter() - tc
@@ -277,6 +291,27 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                 take()
             except Exception:                       # noqa: BLE001
                 break
+        to_fetch[w].put(None)
+
+    def fetch_thread(w):                            # c3_batch_results_fetch of batch i beside the kernels of batch i+1
+        while True:
+            item = to_fetch[w].get()
+            if item is None:
+                break
+            h, hb, sid, shape = item
+            rb = free_results.get()
+            t0 = time.perf_counter()
+            try:
+                res, buf, coff = h.results_fetch(rb, shape)
+            except Exception as e:                  # noqa: BLE001
+                errors.append(e)
+                fetched[w].set()
+                continue
+            fetched[w].set()
+            with lock:
+                t["fetch"] += time.perf_counter() - t0
+            del h, item
+            to_write[w].put((hb, sid, res, buf, coff, rb))
         to_write[w].put(None)
 
     def writer_thread(w):                           # c3_write_group releases the GIL: overlaps parsing and the GPUs
@@ -301,6 +336,7 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
     t_start = time.perf_counter()
     rthreads = [threading.Thread(target=reader_thread, args=(k,), daemon=True) for k in range(n_ranges)]
     others = [threading.Thread(target=writer_thread, args=(w,), daemon=True) for w in range(n_work)]
+    others += [threading.Thread(target=fetch_thread, args=(w,), daemon=True) for w in range(n_work)]
     others += [threading.Thread(target=device_thread, args=(w,), daemon=True) for w in range(n_work)]
     for th in rthreads + others:
         th.start()
@@ -311,8 +347,11 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
         raise errors[0]
     for th in rthreads:
         th.join()
-    for rd in readers:
-        rd.close()
+    if keep_pinned:                                 # one-shot process (the CLI): process teardown releases the page-locked buffers
+        _KEPT.extend(readers)
+    else:
+        for rd in readers:
+            rd.close()
     t["at_readers_closed"] = time.perf_counter() - t_start
     if fused:
         os.replace(finder_psl + ".part", finder_psl)              # a rerun finds the PSL and takes the two-pass route

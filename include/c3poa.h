@@ -89,6 +89,7 @@ typedef struct {
                                       certificate failed counts band + full matrix.  cells_polish stays the full-matrix count (= oracle) */
   int64_t n_band_layers, n_band_fallback;   /* window layers aligned in a band and accepted / redone unbanded after a failed certificate */
   int64_t n_band_mismatch;                  /* C3_DEBUG_BAND=verify only: accepted band layers whose traceback differs from the full matrix's (must be 0) */
+  int64_t n_win_redo;                       /* windows with a layer beyond the first launch's DP scratch, redone by the full-size second launch of k_window */
 } c3_timing;
 
 typedef struct c3_handle c3_handle;
@@ -142,6 +143,16 @@ int c3_batch_sync(c3_handle* h);
  * After the POA / polish stages only the used part of every record is copied: peaks[k >= n_peaks] and
  * sub_beg / sub_end[k >= n_sub] of the caller's records are then unspecified (left as they were). */
 int c3_batch_results(c3_handle* h, c3_read_result* res, char* cons, int64_t cons_cap, int64_t* cons_off);
+/* The same in two halves, so that the device->host copy runs beside the NEXT batch's kernels (the reference overlaps nothing:
+ * analyze_reads writes its files before the worker takes the next group, C3POa.py:110-173).
+ * c3_batch_results_snapshot (owner thread, after c3_batch_run) freezes the records and the compact consensus bytes in device
+ * buffers of their own; afterwards the owner may c3_batch_commit and c3_batch_run the next batch.
+ * c3_batch_results_fetch copies the snapshot into the caller's buffers (same arguments and C3_E_LIMIT rule as c3_batch_results)
+ * and returns when they have landed; it touches nothing but the snapshot and MAY BE CALLED FROM ANOTHER THREAD while the owner
+ * works on the next batch -- the only two calls on one handle that may overlap (it does not set c3_last_error).
+ * One snapshot per handle: _snapshot before the previous one was fetched, or _fetch without a snapshot, returns C3_E_STATE. */
+int c3_batch_results_snapshot(c3_handle* h);
+int c3_batch_results_fetch(c3_handle* h, c3_read_result* res, char* cons, int64_t cons_cap, int64_t* cons_off);
 int c3_batch_timing(c3_handle* h, c3_timing* t);
 
 /* ---- stage probes (tests / per-stage shims), all operate on the resident batch ---- */

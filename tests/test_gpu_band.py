@@ -58,6 +58,11 @@ def test_band_certificate_and_fallback_all_equal_the_full_matrix(cfg, n):
     assert off["n_band_layers"] == 0 and off["n_band_fallback"] == 0 and off["cells_polish_computed"] == cells_full
     assert band["n_band_layers"] > 0 and band["cells_polish_computed"] < 0.6 * cells_full
     assert band["n_band_fallback"] <= 0.05 * (band["n_band_layers"] + band["n_band_fallback"]) + 2
+    # two launches of k_window: the first has DP scratch for banded / narrow layers only, so with the band off the wide layers send
+    # their windows to the full-size second launch -- same results, same cell counts (checked above) -- and with the band on
+    # almost none do
+    assert off["n_win_redo"] > 0.3 * off["n_windows"]
+    assert band["n_win_redo"] <= 0.02 * band["n_windows"] + 1
     # "fail": every band-eligible layer makes ONE band attempt and is redone unbanded; normally a failed attempt is retried with
     # the next wider band first, so a layer can count several failed attempts before it is accepted (or goes unbanded)
     assert fail["n_band_layers"] == 0
@@ -99,3 +104,30 @@ def test_band_verify_on_device_and_the_fifth_in_edge_regression():
         for i in range(len(recs)):
             assert res[i]["status"] == ores[i].status and cons[i] == ocons[i], (mode, i)
         assert t["n_band_layers"] > 100 and t["n_band_mismatch"] == 0
+
+
+def test_tiny_first_launch_scratch_sends_every_window_to_the_second_launch(monkeypatch):
+    """C3_DEBUG_HCAP_DIV shrinks the first launch's DP scratch until no layer fits: every polished window is queued on the device
+    and redone by the full-size launch; results, statuses and cell counts must not move"""
+    recs = list(synth.generate("cfg2", n_reads=64)) + list(synth.generate("cfg3", n_reads=32, start=500))
+    want, wcons, t0 = _run(recs, 500, None)
+    monkeypatch.setenv("C3_DEBUG_HCAP_DIV", "100000")
+    got, gcons, t1 = _run(recs, 500, None)
+    assert gcons == wcons and np.array_equal(got["status"], want["status"]) and np.array_equal(got["cons_len"], want["cons_len"])
+    assert t1["n_win_redo"] >= 0.9 * t1["n_windows"] > 0 and t0["n_win_redo"] <= 0.02 * t0["n_windows"] + 1
+    for k in ("cells_polish", "cells_polish_computed", "n_band_layers", "n_band_fallback"):
+        assert t1[k] == t0[k], k
+
+
+def test_results_do_not_depend_on_what_fresh_device_memory_holds(monkeypatch):
+    """every device buffer poisoned at allocation (C3_DEBUG_POISON): nothing may read a scratch cell it did not write -- with the
+    usual scratch and with the tiny first-launch scratch that sends the windows through the abort + second-launch path"""
+    recs = list(synth.generate("cfg2", n_reads=48)) + list(synth.generate("cfg3", n_reads=32, start=900)) + list(synth.generate("cfg4", n_reads=8, start=70))
+    want, wcons, _ = _run(recs, 500, None)
+    monkeypatch.setenv("C3_DEBUG_POISON", "1")
+    for div in (None, "100000"):
+        if div:
+            monkeypatch.setenv("C3_DEBUG_HCAP_DIV", div)
+        for mode in (None, "off"):
+            got, gcons, _t = _run(recs, 500, mode)
+            assert gcons == wcons and np.array_equal(got["status"], want["status"]), (div, mode)

@@ -437,6 +437,62 @@ def test_staged_upload_pipeline_equals_plain_upload(tmp_path):
     h.close()
 
 
+def test_results_snapshot_then_fetch_on_another_thread(tmp_path):
+    """c3_batch_results_snapshot / c3_batch_results_fetch: the results of batch k are frozen on the device, the owner commits and
+    runs batch k+1, and a second thread copies batch k out meanwhile -- every batch must equal its plain c3_batch_results;
+    misuse returns C3_E_STATE (-5); a too small consensus buffer still delivers records + needed size"""
+    import threading
+    from c3poa_amd import _lib
+    recs = list(synth.generate("cfg1", n_reads=96))
+    fq = str(tmp_path / "r.fastq")
+    with open(fq, "w") as fh:
+        for r in recs:
+            fh.write("@%s\n%s\n+\n%s\n" % (r[0], r[1], r[2]))
+    strand_of = {r[0]: r[3] for r in recs}
+    h = _lib.Handle(); h.set_splints([synth.SPLINT1])
+    want = []
+    for i in range(0, 96, 32):
+        b = recs[i:i + 32]
+        h.upload([r[1] for r in b], [r[2] for r in b], [r[3] for r in b]); h.run()
+        res, buf, coff = h.results_raw()
+        want.append((res["status"].copy(), res["cons_len"].copy(), res["n_sub"].copy(), buf[:coff[-1]].tobytes(), coff.copy()))
+    rd = _lib.Reader(fq, n_sets=3)
+    hbs = [rd.next(32) for _ in range(3)]
+    st = [bytes(ord(strand_of[n]) for n in hb.names()) for hb in hbs]
+    sid = np.zeros(32, dtype=np.int16)
+    rb0 = _lib.ResultBuffers()
+    assert h.lib.c3_batch_results_fetch(h.h, rb0.fit(32, 64)[0].ctypes.data, None, 0, None) == -5       # no snapshot yet
+    got, threads = [None] * 3, []
+    h.upload_host(hbs[0], st[0], sid)
+    for k in range(3):
+        if k + 1 < 3:
+            h.stage_host(hbs[k + 1], st[k + 1], sid)
+        h.run()
+        for t in threads:
+            t.join()                                                            # the previous snapshot has been fetched
+        shape = h.results_snapshot()
+        assert h.lib.c3_batch_results_snapshot(h.h) == -5                       # one snapshot per handle
+        rb = _lib.ResultBuffers(pinned=(k == 1))                                # pageable and page-locked destinations
+
+        def fetch(k=k, rb=rb, shape=shape):
+            res, buf, coff = h.results_fetch(rb, shape)
+            got[k] = (res["status"].copy(), res["cons_len"].copy(), res["n_sub"].copy(), buf[:coff[-1]].tobytes(), coff.copy())
+        threads = [threading.Thread(target=fetch)]
+        threads[0].start()
+        if k + 1 < 3:
+            h.commit()                                                          # the next batch becomes resident while batch k is copied out
+    for t in threads:
+        t.join()
+    for k in range(3):
+        for a, b in zip(got[k], want[k]):
+            assert (a == b) if isinstance(a, bytes) else np.array_equal(a, b), k
+    # too small a consensus buffer: C3_E_LIMIT (-6) from the one-call form, records + offsets delivered
+    res, buf, coff = _lib.ResultBuffers().fit(h.n, 8)
+    rc = h.lib.c3_batch_results(h.h, res.ctypes.data, buf[:8].ctypes.data, 8, coff.ctypes.data)
+    assert rc == -6 and coff[-1] == want[2][4][-1] and np.array_equal(res["cons_len"], want[2][1])
+    h.close()
+
+
 def test_scan_then_assign_equals_upload_with_known_strands():
     """the fused CLI route: upload unassigned -> c3_scan_splints -> c3_batch_assign -> run gives what an upload with the
     true splint / strand gives; c3_batch_assign rejects a splint row outside the table"""

@@ -55,9 +55,17 @@ class FakeHandle:
     def timing(self):
         return self.last_timing
 
-    def results_raw(self, into=None):
+    def results_snapshot(self):
+        # (the real handle refuses a second snapshot before the first was fetched: the pipeline must respect that)
+        assert getattr(self, "snap", None) is None, "snapshot taken before the previous one was fetched"
+        self.snap = self.cur
+        return self.cur[2], int(self.cur[3][-1]) + 16
+
+    def results_fetch(self, into, shape):
+        """runs on the pipeline's fetch thread while the device thread has moved on to the next batch"""
         from oracle import oracle_py as O
-        reads, st, n, off = self.cur
+        reads, st, n, off = self.snap
+        assert shape == (n, int(off[-1]) + 16)
         P = O.default_params(mdistcutoff=self.md)
         ores, ocons = O.process_batch(self.splint, [(r[1], r[2]) for r in reads], list(st), params=P, threads=4)
         res, buf, coff = into.fit(n, int(off[-1]) + 16)
@@ -74,6 +82,7 @@ class FakeHandle:
             pos += len(c)
         coff[n] = pos
         time.sleep(self.delays.random() * 0.03)
+        self.snap = None
         return res, buf, coff
 
     def close(self):
