@@ -682,13 +682,13 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     const int Ncap = 3 * WL + 40 * NLcap, K = NLcap + 2;   // cfg2: 1700 nodes -> 10.2 KB of LDS per wave, 16 waves per CU
     // DP scratch per slot, in cells (4 bytes of H + 1 byte of D each).  Worst case: every node a row, 704+ columns.  The FIRST
     // launch gets what the usual layer needs -- banded rows or a matrix of at most 256 columns over a graph of a window and a
-    // quarter plus the branches its layers add: 256 bytes of direction words per row (+ a quarter for the index rows) -- which is
-    // a sixth of the worst case; a window with a layer beyond that is queued on the device and redone by a SECOND launch with
-    // worst-case scratch on a few slots (no host round trip: it reads the count from device memory).  40 GB -> 8 GB of scratch
+    // quarter plus the branches its layers add: 256 bytes of direction words per row (+ the index rows and some head room) -- which is
+    // a fifth of the worst case; a window with a layer beyond that is queued on the device and redone by a SECOND launch with
+    // worst-case scratch on a few slots (no host round trip: it reads the count from device memory).  40 GB -> 10 GB of scratch
     // at cfg2 / cfg5 on 256 CUs: that much less to allocate and to touch for the first time in a fresh process.
     const long long hcap_full = (long long)(Ncap + 1) * 64 * 12;
     const int R_typ = std::min(Ncap, WL + WL / 4 + 30 * NLcap + 64);
-    long long hcap = std::min(hcap_full, (long long)(R_typ + R_typ / 4 + 4) * 256);
+    long long hcap = std::min(hcap_full, (long long)(R_typ + R_typ / 2 + 4) * 256);      // (a window in the second launch runs alone on an idle device, ~1.5 ms: sized so that a usual batch has none -- at + R_typ / 4 one cfg2 window in 400 000 took it)
     if (const char* e = getenv("C3_DEBUG_HCAP_DIV")) hcap = std::max(4096LL, hcap_full / std::max(1, atoi(e)) / 64 * 64);       // test hook: smaller first-launch scratch (more windows take the second launch)
     const size_t N = (size_t)Ncap;
     const int NI = 19;      // W_INTS of k_polish.hip
@@ -715,12 +715,12 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 256, h->stream));
     a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
     if (const char* e = getenv("C3_DEBUG_BAND")) a.band_mode = !strcmp(e, "off") ? 1 : !strcmp(e, "fail") ? 2 : !strcmp(e, "verify") ? 3 : 0;    // test hook (tests/test_gpu_band.py)
-    a.queue_idx = 0; a.ovf_list = slots2 ? h->d_wovf.as<int>() : nullptr;
+    a.ovf_list = slots2 ? h->d_wovf.as<int>() : nullptr;
     c3k_launch_window(&a, slots, h->stream);
     HIPCHK(hipGetLastError());
     if (slots2) {
       a.H = h->s_win_h2.as<int32_t>(); a.D = h->s_win_d2.as<uint16_t>(); a.hcap = hcap_full;
-      a.wlist = h->d_wovf.as<int>(); a.n_win_dev = h->d_counter.as<int>() + W_CNT_OVF; a.ovf_list = nullptr; a.queue_idx = W_CNT_Q2;
+      a.wlist = h->d_wovf.as<int>(); a.n_win_dev = h->d_counter.as<int>() + W_CNT_OVF; a.ovf_list = nullptr;
       c3k_launch_window(&a, slots2, h->stream);
       HIPCHK(hipGetLastError());
     }

@@ -40,8 +40,9 @@ struct WinArgs {
   int band_mode;                          // 0 = banded rows with certificate (default), 1 = never banded, 2 = every certificate counts as failed (test hook: C3_DEBUG_BAND)
   // two launches: the first with DP scratch for the typical layer (hcap small); a window one of whose layers does not fit is
   // dropped untouched into `ovf_list` (count in counter[W_CNT_OVF]) and redone by the second launch, which has worst-case scratch,
-  // takes its windows from `wlist` and their number from device memory (`n_win_dev`), and its queue from counter[queue_idx]
-  const int* wlist; const int* n_win_dev; int* ovf_list; int queue_idx;
+  // takes its windows from `wlist`, their number from device memory (`n_win_dev`) and its queue from counter[W_CNT_Q2]
+  // (k_window<true>: the first launch's code carries none of this)
+  const int* wlist; const int* n_win_dev; int* ovf_list;
 };
 #define W_CNT_OVF 48                      /* d_counter ints: [0] queue of the first launch, [48] overflow count, [49] queue of the second */
 #define W_CNT_Q2 49

@@ -974,6 +974,7 @@ __device__ __forceinline__ int win_consensus(WCtx& c, int* s_score, unsigned sho
 #ifndef C3_WIN_WAVES
 #define C3_WIN_WAVES 5
 #endif
+template <bool SECOND>
 __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
   const int lane = wave_lane();
   const int slot = blockIdx.x;
@@ -996,9 +997,13 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
   for (;;) {
     int wi = 0;
     if (lane == 0) {
-      wi = atomicAdd(a.counter + a.queue_idx, 1);
-      const int nwq = a.n_win_dev ? *(const volatile int*)a.n_win_dev : a.n_win;
-      wi = wi < nwq ? (a.wlist ? a.wlist[wi] : wi) : -1;
+      if (SECOND) {                                 // the windows the first launch could not hold: list and count in device memory
+        wi = atomicAdd(a.counter + W_CNT_Q2, 1);
+        wi = wi < *(const volatile int*)a.n_win_dev ? a.wlist[wi] : -1;
+      } else {
+        wi = atomicAdd(a.counter, 1);
+        if (wi >= a.n_win) wi = -1;
+      }
     }
     wi = wave_first(wi);
     if (wi < 0) break;
@@ -1108,7 +1113,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         for (int attempt = 0; attempt < 4; ++attempt) {
           unsigned long long dbg_[6] = {0, 0, 0, 0, 0, 0};
           int nblocks = 0;
-          if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, d0bits, d1bits, ring_off, lds_ints, l.begin, l.end, blen, &cb, &nblocks) < 0) { fail = a.ovf_list ? 2 : 1; break; }      // (2: the layer needs more DP scratch than this launch has -- the window goes to the full-size launch)
+          if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, d0bits, d1bits, ring_off, lds_ints, l.begin, l.end, blen, &cb, &nblocks) < 0) { fail = SECOND ? 1 : 2; break; }      // (2: the layer needs more DP scratch than this launch has -- the window goes to the full-size launch)
 #ifdef C3_PHASE_PROF
           ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1];
 #endif
@@ -1377,6 +1382,7 @@ __global__ __launch_bounds__(64) void k_stitch(StitchArgs a) {
 extern "C" void c3k_launch_prep(const PrepArgs* a, int slots, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(slots), dim3(64), 0, s, *a); }
 extern "C" void c3k_launch_window(const WinArgs* a, int slots, hipStream_t s) {
   const size_t lds = win_lds_bytes(a->Lcap, a->Ncap);
-  hipLaunchKernelGGL(k_window, dim3(slots), dim3(64), lds, s, *a);
+  if (a->wlist) hipLaunchKernelGGL(k_window<true>, dim3(slots), dim3(64), lds, s, *a);
+  else hipLaunchKernelGGL(k_window<false>, dim3(slots), dim3(64), lds, s, *a);
 }
 extern "C" void c3k_launch_stitch(const StitchArgs* a, int grid, hipStream_t s) { hipLaunchKernelGGL(k_stitch, dim3(grid), dim3(64), 0, s, *a); }

@@ -58,10 +58,8 @@ def test_band_certificate_and_fallback_all_equal_the_full_matrix(cfg, n):
     assert off["n_band_layers"] == 0 and off["n_band_fallback"] == 0 and off["cells_polish_computed"] == cells_full
     assert band["n_band_layers"] > 0 and band["cells_polish_computed"] < 0.6 * cells_full
     assert band["n_band_fallback"] <= 0.05 * (band["n_band_layers"] + band["n_band_fallback"]) + 2
-    # two launches of k_window: the first has DP scratch for banded / narrow layers only, so with the band off the wide layers send
-    # their windows to the full-size second launch -- same results, same cell counts (checked above) -- and with the band on
-    # almost none do
-    assert off["n_win_redo"] > 0.3 * off["n_windows"]
+    # two launches of k_window: the first has DP scratch for the usual layer only; with the band on almost no window needs the
+    # full-size second launch (the test below forces every window through it)
     assert band["n_win_redo"] <= 0.02 * band["n_windows"] + 1
     # "fail": every band-eligible layer makes ONE band attempt and is redone unbanded; normally a failed attempt is retried with
     # the next wider band first, so a layer can count several failed attempts before it is accepted (or goes unbanded)
