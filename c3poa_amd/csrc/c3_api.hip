@@ -15,6 +15,7 @@ extern "C" void c3k_launch_adapter(const AdapterArgs*, int, hipStream_t);
 extern "C" void c3k_launch_pairwise(const uint8_t*, int, const uint8_t*, int, const uint8_t*, int, uint8_t*, uint8_t*, int*, hipStream_t);
 extern "C" void c3k_launch_match_index(const char*, const int*, int, int, const char*, const long long*, int*, hipStream_t);
 extern "C" void c3k_launch_peaks(const PeaksArgs*, int, hipStream_t);
+extern "C" int c3k_peaks_blocks_per_cu(void);
 extern "C" void c3k_launch_poa(const PoaArgs*, int, hipStream_t);
 extern "C" void c3k_launch_prep(const PrepArgs*, int, hipStream_t);
 extern "C" void c3k_launch_window(const WinArgs*, int, hipStream_t);
@@ -428,7 +429,8 @@ static void savgol_coeffs(int window, double* c) {
 }
 
 static int run_peaks(c3_handle* h) {
-  const int grid = std::min(h->n, h->n_cus * 8);
+  static const int blocks_per_cu = c3k_peaks_blocks_per_cu();
+  const int grid = std::min(h->n, h->n_cus * blocks_per_cu);       // = the workgroups resident at once; reads come off a queue
   h->peaks_grid = grid;
   const size_t mL = (size_t)h->maxL + 8;
   HIPCHK(h->d_bufA.ensure(sizeof(double) * mL * grid)); HIPCHK(h->d_bufB.ensure(sizeof(double) * mL * grid));
@@ -440,6 +442,8 @@ static int run_peaks(c3_handle* h) {
   a.raw_peaks = h->d_raw.as<int32_t>(); a.n_raw = h->d_nraw.as<int32_t>(); a.sp_len = h->d_sp_len.as<int>();
   savgol_coeffs(h->cfg.sg_window, a.coef);
   a.maxL = (int64_t)mL; a.window = h->cfg.sg_window; a.iters = h->cfg.sg_iters; a.min_dist = h->cfg.mdistcutoff;
+  a.queue = h->d_counter.as<int>() + 60;
+  HIPCHK(hipMemsetAsync(a.queue, 0, sizeof(int), h->stream));
   c3k_launch_peaks(&a, grid, h->stream);
   HIPCHK(hipGetLastError());
   return 0;

@@ -10,6 +10,7 @@ struct ConkArgs {
 struct PeaksArgs {
   C3Batch b; const int32_t* track; C3Info* info; double* bufA; double* bufB; int32_t* cand; uint8_t* cstate;
   int32_t* raw_peaks; int32_t* n_raw; const int* sp_len; double coef[64]; int64_t maxL; int window, iters, min_dist;
+  int* queue;                              // read queue (one int, zeroed before the launch)
 };
 struct PoaArgs {
   C3Batch b; C3Info* info; C3Params p; int* counter; const int* work; int n_work;

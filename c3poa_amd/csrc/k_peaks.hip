@@ -54,7 +54,7 @@ __device__ __forceinline__ unsigned block_excl_scan(unsigned v, int* sh4, unsign
 // wave-aggregated LDS atomics for the bins that dominate a wave (in the leading passes every key falls into one or two bins:
 // 64 lanes hammering one LDS word serialise), and the bin holding the k-th key is found with a workgroup prefix sum of the
 // 256 bins instead of a serial walk by one thread.
-__device__ uint64_t block_select(const double* x, int n, int k, unsigned* hist, int* sh_i) {
+__device__ uint64_t block_select(const double* x, int n, int k, unsigned* hist, int* sh_i, uint64_t* keys /* [PK_T] */) {
   const int tid = threadIdx.x, lane = tid & 63;
   uint64_t prefix = 0, mask = 0;
   for (int pass = 7; pass >= 0; --pass) {
@@ -89,14 +89,42 @@ __device__ uint64_t block_select(const double* x, int n, int k, unsigned* hist, 
       unsigned tot;
       const unsigned cum = block_excl_scan(c, sh_i + 2, &tot);
       // the bin of the k-th key: cum <= k < cum + c; if k is beyond the total (cannot happen) the last bin as before
-      if (cum <= (unsigned)k && (unsigned)k < cum + c) { sh_i[0] = tid; sh_i[1] = (int)cum; }
-      if (tid == PK_T - 1 && (unsigned)k >= tot) { sh_i[0] = 255; sh_i[1] = (int)tot; }
+      if (cum <= (unsigned)k && (unsigned)k < cum + c) { sh_i[0] = tid; sh_i[1] = (int)cum; sh_i[6] = (int)c; }
+      if (tid == PK_T - 1 && (unsigned)k >= tot) { sh_i[0] = 255; sh_i[1] = (int)tot; sh_i[6] = INT32_MAX; }
     }
     __syncthreads();
     prefix |= (uint64_t)sh_i[0] << shift;
     mask |= (uint64_t)0xff << shift;
     k -= sh_i[1];
+    const int cb = sh_i[6];
     __syncthreads();
+    // The bin of the k-th key rarely holds more than a few dozen keys after the third pass (sign + exponent + the top mantissa
+    // bits): as soon as they fit one key per thread they are gathered into LDS and ranked there -- one more sweep over the
+    // track instead of up to five (the select was a quarter of k_peaks).  The result is a VALUE: the gather order cannot matter.
+    if (pass > 0 && cb <= PK_T) {
+      if (tid == 0) sh_i[7] = 0;
+      __syncthreads();
+      for (int i0 = 0; i0 < n; i0 += 4 * PK_T) {
+        double xv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * PK_T + tid; xv[u] = i < n ? x[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int i = i0 + u * PK_T + tid;
+          const uint64_t key = dkey(xv[u]);
+          if (i < n && (key & mask) == prefix) keys[atomicAdd(&sh_i[7], 1)] = key;
+        }
+      }
+      __syncthreads();
+      const uint64_t mine = tid < cb ? keys[tid] : ~0ull;
+      int rank = 0;
+      for (int j = 0; j < cb; ++j) { const uint64_t o = keys[j]; rank += (o < mine) || (o == mine && j < tid); }
+      if (tid < cb && rank == k) *(uint64_t*)hist = mine;
+      __syncthreads();
+      const uint64_t r = *(const uint64_t*)hist;
+      __syncthreads();
+      return r;
+    }
   }
   return prefix;
 }
@@ -110,7 +138,7 @@ __device__ __forceinline__ int c3_rounding(int x, int base) {
 }
 
 __global__ __launch_bounds__(PK_T) void k_peaks(PeaksArgs a) {
-  __shared__ unsigned hist[256];
+  __shared__ __attribute__((aligned(8))) unsigned hist[256];
   __shared__ int sh_i[8];
   __shared__ double sh_d[PK_T];
   __shared__ int sh_idx[PK_T];
@@ -124,9 +152,17 @@ __global__ __launch_bounds__(PK_T) void k_peaks(PeaksArgs a) {
   uint8_t* cst = a.cstate + (size_t)blockIdx.x * (a.maxL / 2 + 2);
   const int half = (a.window - 1) / 2;
 
-  for (int rid = blockIdx.x; rid < a.b.n; rid += gridDim.x) {
-    C3Info* info = &a.info[rid];
+  // reads come off a queue: the grid holds exactly the workgroups that are resident at once (c3k_peaks_blocks_per_cu), so no
+  // CU waits for a second, thinner round of blocks and long reads do not pile up on one block (a static stride over
+  // 8 blocks per CU, of which 6 fit, cost a fifth of the kernel)
+  __shared__ int s_rid;
+  for (;;) {
     __syncthreads();
+    if (tid == 0) s_rid = atomicAdd(a.queue, 1);
+    __syncthreads();
+    const int rid = s_rid;
+    if (rid >= a.b.n) break;
+    C3Info* info = &a.info[rid];
     if (info->status == C3_ST_NOT_ASSIGNED) { if (tid == 0) a.n_raw[rid] = 0; continue; }
     const int64_t off = a.b.off[rid];
     const int n = (int)(a.b.off[rid + 1] - off);
@@ -202,7 +238,10 @@ __global__ __launch_bounds__(PK_T) void k_peaks(PeaksArgs a) {
     // ---- np.median
     double med;
     {
-      uint64_t k1 = block_select(x, n, (n - 1) / 2, hist, sh_i);
+#ifdef C3_EXP_X2_SEL
+      { volatile uint64_t sink_ = block_select(x, n, (n - 1) / 3, hist, sh_i, (uint64_t*)sh_d); (void)sink_; }
+#endif
+      uint64_t k1 = block_select(x, n, (n - 1) / 2, hist, sh_i, (uint64_t*)sh_d);
       double v1 = dunkey(k1);
       if (n & 1) med = v1;
       else {
@@ -327,6 +366,11 @@ __global__ __launch_bounds__(PK_T) void k_peaks(PeaksArgs a) {
   }
 }
 
+extern "C" int c3k_peaks_blocks_per_cu(void) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_peaks, PK_T, 0) != hipSuccess || nb < 1) { (void)hipGetLastError(); nb = 4; }
+  return nb;
+}
 extern "C" void c3k_launch_peaks(const PeaksArgs* a, int grid, hipStream_t stream) {
   hipLaunchKernelGGL(k_peaks, dim3(grid), dim3(PK_T), 0, stream, *a);
 }
