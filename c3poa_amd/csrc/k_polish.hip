@@ -62,6 +62,82 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
   }
   int best = 0, bi = 0, bj = 0;
   long long cells = lane == 0 ? min(C, W) + 1 : 0;          // row 0
+#ifndef C3_EXT_OLD
+  if (DL) {
+    // BRANCH-FREE ROWS (the draft is in LDS).  An invalid cell -- left of column 0, right of column C, beyond the band -- always
+    // holds NEGK, so every candidate that comes from one loses by itself: no masks on the diagonal / up / left candidates, ONE
+    // select per cell (valid ? key : NEGK) before the key is split into score and tag.  The draft codes of the lane's five
+    // columns travel in one register (a nibble each, shifted by one column per row; the new nibble is the row's only LDS read),
+    // the first maximum is tracked per band offset (compare, max, select), the cell count is closed-form per row on the scalar
+    // unit.  (The masked version compiled into two EXEC-mask branches per cell: ~450 instructions per row; this is ~140.)
+    const int bb0 = lane * EC;
+    int g4bb1[EC], bestc[EC], bic[EC];
+#pragma unroll
+    for (int cc = 0; cc < EC; ++cc) { g4bb1[cc] = g4 * (bb0 + cc) + 1; bestc[cc] = 0; bic[cc] = 0; }
+    auto code_at = [&](int q) { return (unsigned)ldraft[db + dir_ * min(max(q, 0), C - 1)]; };
+    unsigned dcp = 0;                                                      // nibble cc = draft code of column j - 1 = i - W + bb - 1
+#pragma unroll
+    for (int cc = 0; cc < EC; ++cc) dcp |= code_at(1 - W + bb0 + cc - 1) << (4 * cc);
+    long long cells_s = 0;
+    for (int ib = 1; ib <= n; ib += 64) {
+      int pcs = 0;
+      if (ib + lane <= n) pcs = c3_code_at(pk, pb + dir_ * (ib + lane - 1));
+      asm volatile("" : "+v"(pcs));
+      const int cnt = min(64, n - ib + 1);
+      for (int li = 0; li < cnt; ++li) {
+        const int i = ib + li;
+        const int pc = __builtin_amdgcn_readlane(pcs, li);
+        const unsigned nxt_code = code_at(i - W + bb0 + EC - 1);          // nibble EC-1 of row i + 1 (consumed at the end of the row)
+        const int vlo = W - i;                                             // valid offsets: max(0, vlo) .. vhi
+        const int vhi = min(bw - 1, C - i + W);
+        const unsigned span = (unsigned)(vhi - vlo);                      // (vhi >= vlo whenever a valid cell exists; else every compare below fails)
+        cells_s += max(0, vhi - max(0, vlo) + 1);
+        const int nxt0 = __builtin_amdgcn_update_dpp(NEGK, hprev[0], 0x130, 0xf, 0xf, false);   // wave_shl:1
+        int key[EC], y[EC];
+        int run = NEGK;
+#pragma unroll
+        for (int cc = 0; cc < EC; ++cc) {
+          const int dcode = (int)((dcp >> (4 * cc)) & 15u);
+          const int kd = hprev[cc] + ((pc == dcode) ? mt4 + 3 : mm4 + 3);
+          const int up = (cc + 1 < EC) ? hprev[cc + 1 < EC ? cc + 1 : cc] : nxt0;
+          const int k = max(kd, up + (g4 + 2));
+          const bool val = (unsigned)(bb0 + cc - vlo) <= span && vhi >= vlo && bb0 + cc >= 0;
+          key[cc] = val ? k : NEGK;
+          y[cc] = (key[cc] & ~3) - (g4bb1[cc] - 1);
+          run = max(run, y[cc]);
+        }
+        const int s = wave_scan_max(run);
+        int ex = wave_shr1(s, NEGK);
+        unsigned d0 = 0, d1 = 0;
+#pragma unroll
+        for (int cc = 0; cc < EC; ++cc) {
+          // (no test for the row's first column: everything to its left is NEGK, so the left candidate loses by itself;
+          // an invalid cell is re-masked because ex can be a real score)
+          int k2 = max(key[cc], ex + g4bb1[cc]);
+          ex = max(ex, y[cc]);
+          k2 = key[cc] == NEGK ? NEGK : k2;
+          const int hh = k2 & ~3;
+          hprev[cc] = hh;
+          const unsigned tag = (unsigned)k2 & 3u;                           // 3 diag, 2 up, 1 left, 0 invalid
+          if (cc < 4) d0 |= tag << (8 * cc); else d1 |= tag;
+          const bool up_ = hh > bestc[cc];                                 // (column 0 and invalid cells are <= 0: never)
+          bestc[cc] = max(bestc[cc], hh);
+          bic[cc] = up_ ? i : bic[cc];
+        }
+        unsigned* drow = (unsigned*)(D + (size_t)i * 512) + lane * 2;
+        drow[0] = 0x03030303u - d0; drow[1] = 3u - d1;                     // bytes: 0 diag, 1 up, 2 left, 3 none
+        dcp = (dcp >> 4) | (nxt_code << (4 * (EC - 1)));
+      }
+    }
+    // the lane's first maximum in row-major order: smallest row, then smallest offset
+#pragma unroll
+    for (int cc = 0; cc < EC; ++cc) {
+      const bool better = bestc[cc] > best || (bestc[cc] == best && bestc[cc] > 0 && bic[cc] < bi);
+      if (better) { best = bestc[cc]; bi = bic[cc]; bj = bic[cc] - W + bb0 + cc; }
+    }
+    cells += lane == 0 ? cells_s : 0;
+  } else
+#endif
   for (int ib = 1; ib <= n; ib += 64) {
     int pcs = 0;                              // piece base of row ib+lane
     if (ib + lane <= n) pcs = c3_code_at(pk, pb + dir_ * (ib + lane - 1));
@@ -161,6 +237,12 @@ __device__ __forceinline__ void prep_one(const PrepArgs& a, int wi, int lane, ui
     long long cells = 0;
     // ---- dangling pieces (tail: anchored at the draft start; front: at the draft end)
     if ((ht || hf) && C <= EXT_DCAP) { for (int t = lane; t < C; t += 64) ldraft[t] = draft[t]; WSYNC(); }
+#ifdef C3_EXP_X2_EXT
+    if (C <= EXT_DCAP) {
+      if (ht) { long long r = extend_align<true>(a, pk, draft, ldraft, C, info->tail_beg, L - info->tail_beg, +1, tpos, eD, lane); if (r > 1LL << 60) cells += r; }
+      if (hf) { long long r = extend_align<true>(a, pk, draft, ldraft, C, info->front_end - 1, info->front_end, -1, tpos, eD, lane); if (r > 1LL << 60) cells += r; }
+    }
+#endif
     if (C <= EXT_DCAP) {
       if (ht) { long long r = extend_align<true>(a, pk, draft, ldraft, C, info->tail_beg, L - info->tail_beg, +1, tpos, eD, lane); if (r > 0) cells += r; }
       if (hf) { long long r = extend_align<true>(a, pk, draft, ldraft, C, info->front_end - 1, info->front_end, -1, tpos, eD, lane); if (r > 0) cells += r; }
