@@ -13,17 +13,24 @@ import csv, glob, json, os, shutil, sys
 from collections import defaultdict
 
 
+def kname(raw):
+    """kernel name without return type / arguments; k_window is a template (<false> = the launch that does the work, <true> =
+    the full-size second launch for windows that overflowed the first launch's DP scratch)"""
+    k = raw.split("(")[0].replace("void ", "")
+    return k.replace("k_window<false>", "k_window").replace("k_window<true>", "k_window_second_launch")
+
+
 def counter_sum(d, name):
     acc, calls = defaultdict(float), defaultdict(int)
     for f in glob.glob(os.path.join(d, "*results.db")):          # rocprofv3 default output (rocpd sqlite)
         import sqlite3
         for kn, v in sqlite3.connect(f).execute("select kernel_name, value from counters_collection where counter_name = ?", (name,)):
-            k = kn.split("(")[0].replace("void ", "")
+            k = kname(kn)
             acc[k] += float(v); calls[k] += 1
     for f in glob.glob(os.path.join(d, "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             if row["Counter_Name"] == name:
-                k = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                k = kname(row["Kernel_Name"])
                 acc[k] += float(row["Counter_Value"]); calls[k] += 1
     return {k: acc[k] / calls[k] for k in acc}
 
