@@ -1350,35 +1350,56 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         // ---- fusion, parallel over the query bases (every graph node is touched by at most one base)
         const int n_old = c.n;
         int carry_anchor = -1, carry_new = 0;
-        for (int q0 = 0; q0 < Q; q0 += 64) {
-          const int q = q0 + lane;
-          const bool act = q < Q;
-          const int r = act ? rq.get(q) : 0;
-          const int v = r > 0 ? c.rows()[r] : -1;
-          const int cb = act ? c3_code_at(pk, l.qbeg + q) : 0;
-          int tgt = -1, gnew = -1, anc = -1;
-          if (v >= 0) {
-            const int rr = c.grp()[v];
-            anc = c.glast()[rr];
-            if (c.base()[v] == cb) tgt = v;
-            else for (int i = c.gfirst()[rr]; i <= anc; ++i) { int x = c.order()[i]; if (c.base()[x] == cb) { tgt = x; break; } }
-            if (tgt < 0) gnew = rr;
+        // (two 64-base chunks per turn, the loads of one level for both chunks issued together -- rows -> group + base -> block
+        // extent -- then the scans and the stores chunk by chunk, in order: the carries run along the path)
+        for (int q0 = 0; q0 < Q; q0 += 128) {
+          int v_[2], cb_[2], rr_[2], bs_[2], anc_[2], gf_[2], tgt_[2], gnew_[2];
+          bool act_[2];
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const int q = q0 + 64 * h2 + lane;
+            act_[h2] = q < Q;
+            const int r = act_[h2] ? rq.get(q) : 0;
+            v_[h2] = r > 0 ? c.rows()[r] : -1;
+            cb_[h2] = act_[h2] ? c3_code_at(pk, l.qbeg + q) : 0;
           }
-          const int isnew = act && tgt < 0;
-          const int as = max(wave_scan_max(anc), carry_anchor);       // anchors are non-decreasing along the path
-          carry_anchor = wave_bcast(as, 63);
-          const int ps = wave_scan_add(isnew);
-          const int k = carry_new + ps - isnew;
-          carry_new += wave_bcast(ps, 63);
-          if (isnew) {
-            const int id = n_old + k;
-            if (id < c.Ncap) {
-              c.base()[id] = (uint8_t)cb; c.n_in()[id] = 0; c.n_out()[id] = 0; c.grp()[id] = gnew >= 0 ? gnew : id; c.ncov()[id] = 0;
-              c.anchor()[k] = as;
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) { const int vv = max(v_[h2], 0); rr_[h2] = c.grp()[vv]; bs_[h2] = c.base()[vv]; }
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) { anc_[h2] = c.glast()[rr_[h2]]; gf_[h2] = c.gfirst()[rr_[h2]]; }
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            int tgt = -1, gnew = -1;
+            if (v_[h2] >= 0) {
+              if (bs_[h2] == cb_[h2]) tgt = v_[h2];
+              else for (int i = gf_[h2]; i <= anc_[h2]; ++i) { int x = c.order()[i]; if (c.base()[x] == cb_[h2]) { tgt = x; break; } }
+              if (tgt < 0) gnew = rr_[h2];
+            } else anc_[h2] = -1;
+            tgt_[h2] = tgt; gnew_[h2] = gnew;
+          }
+#pragma unroll
+          for (int h2 = 0; h2 < 2; ++h2) {
+            const int q = q0 + 64 * h2 + lane;
+            if (q0 + 64 * h2 >= Q) break;
+            const bool act = act_[h2];
+            const int cb = cb_[h2], gnew = gnew_[h2], anc = anc_[h2];
+            int tgt = tgt_[h2];
+            const int isnew = act && tgt < 0;
+            const int as = max(wave_scan_max(anc), carry_anchor);       // anchors are non-decreasing along the path
+            carry_anchor = wave_bcast(as, 63);
+            const int ps = wave_scan_add(isnew);
+            const int k = carry_new + ps - isnew;
+            carry_new += wave_bcast(ps, 63);
+            if (isnew) {
+              const int id = n_old + k;
+              if (id < c.Ncap) {
+                c.base()[id] = (uint8_t)cb; c.n_in()[id] = 0; c.n_out()[id] = 0; c.grp()[id] = gnew >= 0 ? gnew : id; c.ncov()[id] = 0;
+                c.anchor()[k] = as;
+              }
+              tgt = id;
             }
-            tgt = id;
+            if (act) tq.set(q, tgt);
           }
-          if (act) tq.set(q, tgt);
         }
         const int nn = n_old + carry_new;
         if (nn > c.Ncap) { fail = 1; break; }
