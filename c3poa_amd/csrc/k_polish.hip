@@ -1139,18 +1139,48 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
           const WArr<int> gseed = c.rowof();
           for (int i = lane; i < c.n; i += 64) { const int v = c.order()[i]; c.mask()[v] = (v >= l.begin && i <= eidx) ? 1 : 0; }
           WSYNC();
+          // (every sweep takes WU chunks of 64 nodes per turn and issues the loads of one level for all of them together: the
+          // sweeps are chains of dependent gathers -- node -> out-edges -> mask of the targets -- and were all waiting)
           for (;;) {
-            for (int v = lane; v < c.n; v += 64) if (c.mask()[v]) gseed[c.grp()[v]] = 0;
+            for (int v0 = 0; v0 < c.n; v0 += 64 * WU) {
+              int m_[WU], g_[WU];
+#pragma unroll
+              for (int u = 0; u < WU; ++u) { const int v = min(v0 + 64 * u + lane, c.n - 1); m_[u] = c.mask()[v]; g_[u] = c.grp()[v]; }
+#pragma unroll
+              for (int u = 0; u < WU; ++u) if (v0 + 64 * u + lane < c.n && m_[u]) gseed[g_[u]] = 0;
+            }
             WSYNC();
-            for (int v = lane; v < c.n; v += 64) {
-              if (!c.mask()[v]) continue;
-              int seed = v == l.end;
-              for (int k = 0; k < c.n_out()[v] && !seed; ++k) seed = c.mask()[c.out_to()[EI(v, k)]];
-              if (seed) gseed[c.grp()[v]] = 1;
+            for (int v0 = 0; v0 < c.n; v0 += 64 * WU) {
+              int m_[WU], g_[WU], no_[WU], t0_[WU], t1_[WU], s0_[WU], s1_[WU];
+#pragma unroll
+              for (int u = 0; u < WU; ++u) {
+                const int v = min(v0 + 64 * u + lane, c.n - 1);
+                m_[u] = c.mask()[v]; g_[u] = c.grp()[v]; no_[u] = c.n_out()[v]; t0_[u] = c.out_to()[EI(v, 0)]; t1_[u] = c.out_to()[EI(v, 1)];
+              }
+#pragma unroll
+              for (int u = 0; u < WU; ++u) {        // (slots beyond the out-degree hold stale node ids: clamped, read, ignored)
+                s0_[u] = c.mask()[min(max(t0_[u], 0), c.Ncap - 1)]; s1_[u] = c.mask()[min(max(t1_[u], 0), c.Ncap - 1)];
+              }
+#pragma unroll
+              for (int u = 0; u < WU; ++u) {
+                const int v = v0 + 64 * u + lane;
+                if (v >= c.n || !m_[u]) continue;
+                int seed = v == l.end || (no_[u] > 0 && s0_[u]) || (no_[u] > 1 && s1_[u]);
+                for (int k = 2; k < no_[u] && !seed; ++k) seed = c.mask()[c.out_to()[EI(v, k)]];
+                if (seed) gseed[g_[u]] = 1;
+              }
             }
             WSYNC();
             int changed = 0;
-            for (int v = lane; v < c.n; v += 64) if (c.mask()[v] && !gseed[c.grp()[v]]) { c.mask()[v] = 0; changed = 1; }
+            for (int v0 = 0; v0 < c.n; v0 += 64 * WU) {
+              int m_[WU], g_[WU], gs_[WU];
+#pragma unroll
+              for (int u = 0; u < WU; ++u) { const int v = min(v0 + 64 * u + lane, c.n - 1); m_[u] = c.mask()[v]; g_[u] = c.grp()[v]; }
+#pragma unroll
+              for (int u = 0; u < WU; ++u) gs_[u] = gseed[g_[u]];
+#pragma unroll
+              for (int u = 0; u < WU; ++u) { const int v = v0 + 64 * u + lane; if (v < c.n && m_[u] && !gs_[u]) { c.mask()[v] = 0; changed = 1; } }
+            }
             changed = __ballot(changed) != 0;
             WSYNC();
             if (!changed) break;
