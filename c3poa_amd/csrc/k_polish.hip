@@ -952,7 +952,14 @@ __device__ __forceinline__ int win_consensus(WCtx& c, int* s_score, unsigned sho
     const int v = live ? c.order()[idx] : 0;
     const int nin = live ? c.n_in()[v] : 0;
     int bw = -1, bu = -1, cm = 0;
-    for (int k = 0; __builtin_amdgcn_ballot_w64(k < nin) != 0; ++k) {
+    {
+      // the first two in-edges (nearly every node has no more) are fetched together, weight and source, needed or not: one round
+      // trip where the loop made up to four
+      const int w0 = c.in_w()[EI(v, 0)], w1 = c.in_w()[EI(v, 1)], u0 = c.in_from()[EI(v, 0)], u1 = c.in_from()[EI(v, 1)];
+      if (nin > 0) { bw = w0; bu = u0; cm = 1; }
+      if (nin > 1) { if (w1 > bw) { bw = w1; bu = u1; cm = 1; } else if (w1 == bw) ++cm; }
+    }
+    for (int k = 2; __builtin_amdgcn_ballot_w64(k < nin) != 0; ++k) {
       if (k < nin) {
         const int w = c.in_w()[EI(v, k)];
         if (w > bw) { bw = w; bu = c.in_from()[EI(v, k)]; cm = 1; } else if (w == bw) ++cm;
