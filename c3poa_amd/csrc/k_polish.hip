@@ -1125,10 +1125,16 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
       PH_MARK(0)
       // ---- stable order of the layers by begin position (tiny; every lane computes it)
       const int offset = (int)(0.01 * (double)blen);
+      // (lane x holds the begin of layer x and counts the layers before it once; the t loop then finds the layer of rank t with
+      // one ballot -- the plain triple loop re-read the begins from memory nl^3 times: 2 744 loads per window at cfg4's 14 layers)
+      const int lbeg = lane < nl ? lay[min(lane, nl - 1)].begin : INT32_MAX;
+      int lrank = 0;
+      if (nl <= 64) for (int y = 0; y < nl; ++y) { const int by = __builtin_amdgcn_readlane(lbeg, y); lrank += (by < lbeg) || (by == lbeg && y < lane); }
       for (int t = 0; t < nl && !fail; ++t) {
         // rank t = the layer with t layers before it in (begin, index) order
         int li = -1;
-        for (int x = 0; x < nl; ++x) {
+        if (nl <= 64) li = __builtin_ctzll(__ballot(lane < nl && lrank == t) | (1ull << 63));
+        else for (int x = 0; x < nl; ++x) {
           int before = 0;
           for (int y = 0; y < nl; ++y) before += (lay[y].begin < lay[x].begin) || (lay[y].begin == lay[x].begin && y < x);
           if (before == t) { li = x; break; }
