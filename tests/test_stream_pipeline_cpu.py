@@ -137,3 +137,40 @@ def test_byte_range_readers_cover_the_file_once(tmp_path, monkeypatch):
     a = _run(tmp_path, "a", recs, 1, 4, monkeypatch, readers_per_gpu=3, raw=True)
     b = _run(tmp_path, "b", recs, 1, 4, monkeypatch, readers_per_gpu=3, raw=True)
     assert a == b and a[0].count(b">") == 50
+
+
+def test_result_fetcher_hands_back_the_previous_batch_in_order():
+    """_lib.ResultFetcher (bench.py's results pipeline): after_run() snapshots batch k and returns batch k-1's buffers, drain()
+    returns the last; the two buffer sets alternate, so what after_run returned stays intact while the next fetch runs"""
+    import threading
+
+    class H:
+        def __init__(self):
+            self.k, self.snap, self.lock = 0, None, threading.Lock()
+
+        def results_snapshot(self):
+            assert self.snap is None, "second snapshot before the first was fetched"
+            self.snap = self.k
+            self.k += 1
+            return (4, 64)
+
+        def results_fetch(self, into, shape):
+            res, buf, coff = into.fit(*shape)
+            time.sleep(0.02)
+            buf[:4] = self.snap                       # the batch number, as payload
+            coff[-1] = self.snap
+            self.snap = None
+            return res, buf, coff
+
+    h = H()
+    f = _lib.ResultFetcher(h)
+    assert f.after_run() is None
+    seen = []
+    for _ in range(5):
+        prev = f.after_run()                          # returns batch k-1 while batch k is being fetched
+        seen.append((int(prev[1][0]), int(prev[2][-1])))
+        time.sleep(0.03)
+        assert int(prev[1][0]) == seen[-1][0]         # still intact after the concurrent fetch of the next batch
+    last = f.drain()
+    assert seen == [(k, k) for k in range(5)] and int(last[1][0]) == 5 and f.drain() is None
+    f.close()
