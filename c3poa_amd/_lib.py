@@ -447,35 +447,39 @@ class ResultBuffers:
     def __init__(self, pinned=False):
         self.res = self.buf = self.coff = None
         self.pinned = pinned
-        self._p = []
+        self._p = {}
         self.lib = load() if pinned else None
 
-    def _alloc(self, count, dtype):
+    def _alloc(self, name, count, dtype):
         if not self.pinned:
             return np.empty(count, dtype=dtype)
         nbytes = count * np.dtype(dtype).itemsize
         p = C.c_void_p()
         if self.lib.c3_host_alloc(nbytes + 64, C.byref(p)) != 0:
             raise MemoryError("c3_host_alloc(%d)" % nbytes)
-        self._p.append(p)
+        old = self._p.pop(name, None)                 # a buffer that grows hands its predecessor back
+        setattr(self, name, None)
+        if old is not None:
+            self.lib.c3_host_free(old)
+        self._p[name] = p
         return np.frombuffer((C.c_char * nbytes).from_address(p.value), dtype=dtype, count=count)
 
     def fit(self, n, cons_cap):
         if self.buf is None or len(self.buf) < cons_cap:
-            self.buf = self._alloc(cons_cap + cons_cap // 4, np.uint8)
+            self.buf = self._alloc("buf", cons_cap + cons_cap // 4, np.uint8)
         if self.res is None or len(self.res) < n:
-            self.res = self._alloc(n + n // 4 + 1, RESULT_DTYPE)
+            self.res = self._alloc("res", n + n // 4 + 1, RESULT_DTYPE)
         if not self.pinned:
             return self.res[:n], self.buf, np.zeros(n + 1, dtype=np.int64)
         if self.coff is None or len(self.coff) < n + 1:
-            self.coff = self._alloc(n + n // 4 + 2, np.int64)
+            self.coff = self._alloc("coff", n + n // 4 + 2, np.int64)
         return self.res[:n], self.buf, self.coff[:n + 1]
 
     def close(self):
         self.res = self.buf = self.coff = None
-        for p in self._p:
+        for p in self._p.values():
             self.lib.c3_host_free(p)
-        self._p = []
+        self._p = {}
 
     def __del__(self):
         try:
