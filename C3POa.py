@@ -67,6 +67,9 @@ def configReader(path, configIn):
     return progs
 
 
+_WARMERS = []            # context-warming threads of main(); joined before a one-shot process leaves
+
+
 def main(args, one_shot=False):
     """one_shot: the process ends right after this call (the command line): the page-locked reader buffers are then left to
     process teardown instead of being unpinned one by one (1.2 s per 5 GB)"""
@@ -97,13 +100,10 @@ def main(args, one_shot=False):
     import threading
     dmap_ = [int(x) for x in os.environ["C3_DEVICE_MAP"].split(",")] if os.environ.get("C3_DEVICE_MAP") else list(range(n_dev))
 
-    def _warm(dev):
-        try:
-            _lib.Handle(device=dev).close()
-        except Exception:                                                    # noqa: BLE001 -- the worker's own handle reports it
-            pass
-    for dev in sorted(set(dmap_[:n_dev])):
-        threading.Thread(target=_warm, args=(dev,), daemon=True).start()
+    warmers = [threading.Thread(target=_lib.warm_device, args=(dev,), daemon=True) for dev in sorted(set(dmap_[:n_dev]))]
+    for th in warmers:                                                       # (context only: a failure is reported by the worker's own c3_create)
+        th.start()
+    _WARMERS.extend(warmers)
     align_psl = tmp_dir + "splint_to_read_alignments.psl"
     have_psl = os.path.exists(align_psl) and os.stat(align_psl).st_size > 0
     if not have_psl and getattr(args, "splint_finder", "gpu") == "gpu":
@@ -153,6 +153,8 @@ if __name__ == "__main__":
         print("Reads (--reads/-r) and splint (--splint_file/-s) are required", file=sys.stderr)
         sys.exit(1)
     main(args, one_shot=True)
+    for th_ in _WARMERS:                          # never leave while a thread is still inside HIP initialisation
+        th_.join()
     # every output file has been written and closed; skip the interpreter's and the HIP runtime's teardown (unpinning the reader
     # buffers, freeing the device scratch: ~1.5 s that produce nothing)
     sys.stdout.flush(); sys.stderr.flush()

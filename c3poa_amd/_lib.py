@@ -15,7 +15,7 @@ MAX_PEAKS = 256
 STAGE_CONK, STAGE_PEAKS, STAGE_POA, STAGE_POLISH, STAGES_ALL = 1, 2, 4, 8, 15
 ST_OK, ST_NOT_ASSIGNED, ST_NO_PEAKS, ST_NO_CONSENSUS, ST_TOO_SHORT, ST_LIMIT = range(6)
 
-EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_create", "c3_destroy", "c3_last_error", "c3_set_splints",
+EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_warm_device", "c3_create", "c3_destroy", "c3_last_error", "c3_set_splints",
            "c3_batch_upload", "c3_batch_stage", "c3_batch_commit", "c3_batch_assign", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_results_snapshot", "c3_batch_results_fetch", "c3_batch_timing",
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
            "c3_call_peaks", "c3_poa_msa", "c3_pairwise_consensus", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
@@ -440,6 +440,11 @@ def device_count():
     return int(load().c3_device_count())
 
 
+def warm_device(dev):
+    """create the HIP context of one device on the calling thread (nothing else); returns the c3_status"""
+    return int(load().c3_warm_device(int(dev)))
+
+
 class ResultBuffers:
     """grow-only host buffers for one batch of results (no page faults per batch); owned by whoever holds the object.
     pinned=True takes them from c3_host_alloc (page-locked): what c3_batch_results_begin needs to copy asynchronously"""
@@ -448,6 +453,7 @@ class ResultBuffers:
         self.res = self.buf = self.coff = None
         self.pinned = pinned
         self._p = {}
+        self._retired = []
         self.lib = load() if pinned else None
 
     def _alloc(self, name, count, dtype):
@@ -457,14 +463,23 @@ class ResultBuffers:
         p = C.c_void_p()
         if self.lib.c3_host_alloc(nbytes + 64, C.byref(p)) != 0:
             raise MemoryError("c3_host_alloc(%d)" % nbytes)
-        old = self._p.pop(name, None)                 # a buffer that grows hands its predecessor back
-        setattr(self, name, None)
+        # a buffer that grows hands its predecessor back -- but not before the NEXT fit(): the arrays handed out by the previous
+        # fit() are views of it (np.frombuffer owns nothing), and ResultFetcher's callers still read them while the next batch
+        # is fetched into the other buffer
+        old = self._p.pop(name, None)
         if old is not None:
-            self.lib.c3_host_free(old)
+            self._retired.append(old)
         self._p[name] = p
         return np.frombuffer((C.c_char * nbytes).from_address(p.value), dtype=dtype, count=count)
 
+    def _release_retired(self):
+        for p in self._retired:
+            self.lib.c3_host_free(p)
+        self._retired = []
+
     def fit(self, n, cons_cap):
+        if self._retired:
+            self._release_retired()                   # blocks replaced by the previous fit(): their views are two batches old now
         if self.buf is None or len(self.buf) < cons_cap:
             self.buf = self._alloc("buf", cons_cap + cons_cap // 4, np.uint8)
         if self.res is None or len(self.res) < n:
@@ -477,6 +492,7 @@ class ResultBuffers:
 
     def close(self):
         self.res = self.buf = self.coff = None
+        self._release_retired()
         for p in self._p.values():
             self.lib.c3_host_free(p)
         self._p = {}

@@ -198,6 +198,13 @@ extern "C" void c3_default_config(c3_config* c) {
 extern "C" const char* c3_version(void) { return "c3poa_amd 0.1 (gfx950)"; }
 extern "C" int c3_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n; }
 
+extern "C" int c3_warm_device(int device) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || device < 0 || device >= n) { (void)hipGetLastError(); return C3_E_NO_DEVICE; }
+  if (hipSetDevice(device) != hipSuccess || hipFree(nullptr) != hipSuccess) { (void)hipGetLastError(); return C3_E_HIP; }
+  return C3_E_OK;
+}
+
 static thread_local std::string g_create_err;
 extern "C" const char* c3_last_error(const c3_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 

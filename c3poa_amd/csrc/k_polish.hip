@@ -1504,11 +1504,11 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         if (olen < 0) { fail = 1; olen = 0; } else polished = 1;
       }
     }
-    if (fail == 2) {
+    if (fail == 2 && a.ovf_list) {
       if (lane == 0) a.ovf_list[atomicAdd(a.counter + W_CNT_OVF, 1)] = wi;          // nothing of this window has been published
     } else if (lane == 0) {
       WinRec* r = &a.wrec[wi];
-      r->out_len = fail ? -1 : olen; r->polished = polished;
+      r->out_len = fail ? -1 : olen; r->polished = polished;        // (fail == 2 with no second launch to take it: the window is over the limits)
       atomicAdd((unsigned long long*)(a.counter + 2), (unsigned long long)cells);
       atomicAdd((unsigned long long*)(a.counter + 4), (unsigned long long)cells_done);
       if (n_band) atomicAdd(a.counter + 6, n_band);

@@ -113,7 +113,7 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
     # writer puts j back once the group has been written (device threads finish out of order, so a counting semaphore over
     # round-robin sets would let a reader overwrite a set a lagging device still holds).  Result buffers follow the same
     # rule: one object per batch in flight, returned by the writer.
-    N_SETS = 5
+    N_SETS = 5                                      # (a sixth set would cover every stage at once; it costs 20 % more page-locked memory and start-up time for a stall that the timeline does not show)
     readers = [_lib.Reader(args.reads, n_sets=N_SETS, byte_range=(cuts[k], cuts[k + 1])) if n_ranges > 1
                else _lib.Reader(args.reads, n_sets=N_SETS) for k in range(n_ranges)]
     if n_ranges > 1 and any(r.range_lost() for r in readers):
@@ -128,7 +128,7 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
         for j in range(N_SETS):
             fs.put(j)
     free_results = queue.Queue()
-    for _k in range(3 * n_work + 2):
+    for _k in range(4 * n_work + 2):                # run -> fetch -> (queue of 2) -> write: four batches per worker can hold one
         free_results.put(_lib.ResultBuffers())
     parsed = [queue.Queue(maxsize=1) for _ in range(n_ranges)]
     to_write = [queue.Queue(maxsize=2) for _ in range(n_work)]
@@ -143,6 +143,7 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
 
     def reader_thread(k):                           # parse + splint/strand lookup of range k, ahead of its GPU
         rd = readers[k]
+        ks = None                                   # the buffer set this thread holds and has not handed on
         try:
             while not errors:
                 ks = free_sets[k].get()
@@ -151,12 +152,13 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                 t1 = time.perf_counter()
                 if rd.noqual():
                     # C3POa.py:167 averages ord(q) - 33 over the read's quality string and racon is run with -q 5: records
-                    # without qualities cannot go through the reference either (it raises on qual = None)
-                    raise SystemExit("C3POa: %s holds records without base qualities (FASTA); the consensus caller needs FASTQ" % args.reads)
+                    # without qualities cannot go through the reference either (it raises on qual = None).  An ordinary
+                    # exception, so that it lands in `errors` and run() re-raises it (SystemExit would end this thread silently)
+                    raise _lib.C3Error("C3POa: %s holds records without base qualities (FASTA); the consensus caller needs FASTQ" % args.reads)
                 if hb.n == 0:
                     with lock:
                         t["short"] += hb.n_short
-                    free_sets[k].put(ks)
+                    free_sets[k].put(ks); ks = None
                     break
                 if fused:
                     sid, st, na = np.zeros(hb.n, dtype=np.int16), b"?" * hb.n, 0
@@ -166,10 +168,13 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                     t["parse"] += t1 - t0; t["assign"] += time.perf_counter() - t1
                     t["reads"] += hb.n; t["batches"] += 1; t["short"] += hb.n_short; t["assigned"] += na
                 hb.range_index = k
-                parsed[k].put((hb, sid, st))
-        except Exception as e:                      # noqa: BLE001 -- re-raised by the caller's thread
+                parsed[k].put((hb, sid, st)); ks = None
+        except BaseException as e:                  # noqa: BLE001 -- re-raised by the caller's thread
             errors.append(e)
-        parsed[k].put(None)
+        finally:                                    # whatever happened: the worker of this range must see the end marker
+            if ks is not None:
+                free_sets[k].put(ks)
+            parsed[k].put(None)
 
     def device_thread(w):                           # one per GPU: c3_batch_run sizes its stages on the host, so it blocks
         dev = w % n_dev
@@ -306,6 +311,8 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
             except Exception as e:                  # noqa: BLE001
                 errors.append(e)
                 fetched[w].set()
+                free_results.put(rb)                # the buffers of a batch that is lost go back to their owners
+                free_sets[hb.range_index].put(hb.set_index)
                 continue
             fetched[w].set()
             with lock:

@@ -98,6 +98,10 @@ void c3_default_config(c3_config* cfg);
 const char* c3_version(void);
 /* GPUs visible to the process (0 without a GPU); -n of the CLI is clamped to it (C3POa.py:236 sized a process pool) */
 int c3_device_count(void);
+/* Creates the HIP context of device `device` on the calling thread and returns (hipSetDevice + an empty hipFree): the CLI calls it
+ * on a thread of its own per GPU at start-up so that the workers' c3_create finds the context ready (C3POa.py:236-248 paid the
+ * start-up of every worker process instead).  0 or a negative c3_status. */
+int c3_warm_device(int device);
 
 /* lifecycle.  Replaces the per-task worker process of C3POa.py:236 (mp.Pool, maxtasksperchild=1). */
 int c3_create(const c3_config* cfg, c3_handle** out);

@@ -26,6 +26,11 @@ int c3o_poa_last_scores(int32_t* out, int cap) { int n = g_nscores < cap ? g_nsc
 #define SRC 0
 #define SNK 1
 
+/* diagnostic row statistics (tools/poa_row_stats.py; single-threaded use only): what kinds of DP rows the alignments of a
+ * batch consist of, as the HIP kernel classifies them, and how far real cell values sit below their row's maximum */
+int64_t c3o_poa_rowstats[64];
+int c3o_poa_rowstats_on = 0;
+
 typedef struct {
   int32_t *H, *E1, *E2; uint32_t* D;
   int64_t ncell, cap;
@@ -178,6 +183,43 @@ static int poa_align(const c3o_graph* g, const uint8_t* q, int Q, const c3o_para
       D[c] |= ((uint32_t)hs << 26) | ((uint32_t)f1x << 30) | ((uint32_t)f2x << 31);
       if (h > best) { best = h; left = right = beg + c; }
       else if (h == best) right = beg + c;
+    }
+    if (c3o_poa_rowstats_on && v != SRC) {
+      int64_t* S = c3o_poa_rowstats;
+      int nin = g->n_in[v], dmax = 0, dmin = 1 << 30, pwmax = 0;
+      for (int k = 0; k < nin; ++k) {
+        int pi = g->index[g->in_from[v * K + k]];
+        if (idx - pi > dmax) dmax = idx - pi;
+        if (idx - pi < dmin) dmin = idx - pi;
+        if (m.rend[pi] - m.rbeg[pi] > pwmax) pwmax = m.rend[pi] - m.rbeg[pi];
+      }
+      int pwd = m.rend[idx - 1] - m.rbeg[idx - 1] + 1, sh = beg - m.rbeg[idx - 1];
+      S[0]++; S[1] += wd;
+      if (nin == 1 && dmax == 1 && wd <= 64 && pwd <= 64 && sh < 64) { S[2]++; S[8 + (sh < 0 ? 0 : sh > 3 ? 4 : sh + 0)]++; }   /* fast; shift histogram 8..12 */
+      else if (nin <= 4 && dmax < 4 && wd <= 128 && pwmax < 128) {
+        S[3]++;
+        if (wd > 64) S[5]++;
+        if (nin == 1) S[16 + (dmax == 1 ? 0 : dmax == 2 ? 1 : 2)]++;          /* 16: d=1 (wide), 17: d=2, 18: d=3 */
+        else if (nin == 2) S[19 + (dmax <= 2 ? 0 : 1)]++;                      /* 19: the two rows above, 20: other */
+        else S[21 + (nin - 3)]++;                                              /* 21: three, 22: four */
+      } else { S[4]++; if (nin > 4) S[24]++; else if (dmax >= 4) S[25]++; else S[26]++; }
+      S[28 + (wd <= 32 ? 0 : wd <= 48 ? 1 : wd <= 64 ? 2 : wd <= 96 ? 3 : wd <= 128 ? 4 : 5)]++;
+      /* lowest real value below the row maximum */
+      int lo = 0;
+      for (int c = 0; c < wd; ++c) {
+        if (H[c] > C3O_NEG / 2 && H[c] - best < lo) lo = H[c] - best;
+        if (E1[c] > C3O_NEG / 2 && E1[c] - best < lo) lo = E1[c] - best;
+        if (E2[c] > C3O_NEG / 2 && E2[c] - best < lo) lo = E2[c] - best;
+      }
+      if (lo < S[40]) S[40] = lo;
+      S[41 + (lo > -200 ? 0 : lo > -400 ? 1 : lo > -800 ? 2 : lo > -1600 ? 3 : 4)]++;
+      /* row maximum against the previous row's (rebasing step) */
+      if (idx >= 2 && pwd > 0) {
+        int pbest = INT_MIN; const int32_t* PH = m.H + m.roff[idx - 1];
+        for (int c = 0; c < pwd; ++c) if (PH[c] > pbest) pbest = PH[c];
+        int dd = best - pbest; if (dd < 0) dd = -dd;
+        if (dd > S[47]) S[47] = dd;
+      }
     }
     /* adaptive band hints for successors */
     for (int k = 0; k < g->n_out[v]; ++k) {

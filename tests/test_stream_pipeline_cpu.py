@@ -174,3 +174,63 @@ def test_result_fetcher_hands_back_the_previous_batch_in_order():
     last = f.drain()
     assert seen == [(k, k) for k in range(5)] and int(last[1][0]) == 5 and f.drain() is None
     f.close()
+
+
+def test_fasta_input_is_refused_with_a_message_not_a_hang(tmp_path, monkeypatch):
+    """records without qualities end the run with the reader's message (the reference dies on qual = None, C3POa.py:167); the
+    reader thread's error must reach run() and the worker of that range must still see the end marker -- a SystemExit raised
+    inside the thread used to vanish and leave the device thread waiting for ever"""
+    import threading
+    import pytest
+    recs = list(synth.generate("cfg1", n_reads=6))
+    fa = str(tmp_path / "reads.fasta")
+    with open(fa, "w") as fh:
+        for r in recs:
+            fh.write(">%s\n%s\n" % (r[0], r[1]))
+    out = str(tmp_path / "out") + "/"
+    os.makedirs(out)
+    monkeypatch.setattr(_lib, "Handle", FakeHandle)
+    args = types.SimpleNamespace(out_path=out, reads=fa, groupSize=1000, lencutoff=1000, mdistcutoff=500, zero=True, compress_output=False)
+    sd = {"Splint1": [synth.SPLINT1, revcomp(synth.SPLINT1)]}
+    box = {}
+
+    def go():
+        try:
+            stream.run(args, sd, {r[0]: ["Splint1", r[3]] for r in recs}, {"Splint1"}, 1)
+        except BaseException as e:                   # noqa: BLE001
+            box["err"] = e
+    th = threading.Thread(target=go, daemon=True)
+    th.start()
+    th.join(60)
+    assert not th.is_alive(), "stream.run hangs on FASTA input"
+    assert isinstance(box.get("err"), _lib.C3Error) and "FASTQ" in str(box["err"])
+
+
+def test_pinned_result_buffers_keep_a_replaced_block_until_the_next_fit(monkeypatch):
+    """a page-locked ResultBuffers that grows must not free the block its previous fit() handed out while a caller may still
+    read it (ResultFetcher alternates two buffers): the predecessor is released by the NEXT fit() or by close()"""
+    import ctypes as C
+    rb = _lib.ResultBuffers(pinned=False)
+    freed, blocks = [], []
+
+    class L:
+        @staticmethod
+        def c3_host_alloc(nbytes, pp):
+            b = C.create_string_buffer(int(nbytes))
+            blocks.append(b)
+            C.cast(pp, C.POINTER(C.c_void_p))[0] = C.addressof(b)
+            return 0
+
+        @staticmethod
+        def c3_host_free(p):
+            freed.append(p.value if hasattr(p, "value") else p)
+    rb.pinned, rb.lib = True, L
+    res, buf, coff = rb.fit(4, 64)
+    first = rb._p["buf"].value
+    buf[:4] = 7
+    rb.fit(4, 4096)                                  # grows: the first block must survive this call
+    assert first not in freed and bytes(buf[:4]) == b"\x07" * 4
+    rb.fit(4, 64)                                    # the next fit releases it
+    assert first in freed
+    rb.close()
+    assert len(freed) == len(blocks)
