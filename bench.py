@@ -52,6 +52,35 @@ WORKLOAD_TEXT = {
 }
 
 
+def kernel_src_sha():
+    """content hash of the kernel / library sources (the GPU box has no .git): ties a committed PMC summary to the kernels
+    it was measured on -- tools/collect_profiles.py stores the same hash"""
+    import glob
+    import hashlib
+    hsh = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "c3poa_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "c3poa_amd", "csrc", "*.h"))):
+        hsh.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
+def parity_sample(recs, n_unique, res, cbuf, coff, mdist, k=64, seed=1234):
+    """CHECKER (outside every timed region): the oracle on k random reads of the batch the last step processed; counts reads
+    whose status or consensus bytes differ from what the GPU delivered for them"""
+    from c3poa_amd import synth
+    from oracle import oracle_py as O
+    n = len(res)
+    idx = sorted(np.random.default_rng(seed).choice(n, size=min(k, n), replace=False).tolist())
+    rs = [recs[i % n_unique] for i in idx]
+    ores, ocons = O.process_batch(synth.SPLINT1, [(r[0], r[1]) for r in rs], [r[2] for r in rs],
+                                  params=O.default_params(mdistcutoff=mdist), threads=effective_cores())
+    raw = cbuf.tobytes()
+    bad = 0
+    for i, orr, oc in zip(idx, ores, ocons):
+        got = raw[coff[i]:coff[i + 1]].decode() if res["status"][i] == 0 else ""
+        bad += int(res["status"][i] != orr.status or got != oc)
+    return {"reads": len(idx), "mismatches": bad, "checker": "oracle/libc3oracle.so (status + consensus bytes), after the timed region"}
+
+
 def _gen_shard(args):
     cfg, start, count = args
     from c3poa_amd import synth
@@ -127,6 +156,7 @@ def parse_args(argv=None):
     ap.add_argument("--other-configs", default="auto",
                     help="comma list of further configs run for 3 steps after the headline (rank 0, N=1): 'auto' = cfg3,cfg4 "
                          "when the headline is cfg2 at full size, 'none' = skip")
+    ap.add_argument("--other-unique", type=int, default=0, help="distinct reads generated for each of the other configs (0 = all distinct, no tiling)")
     a = ap.parse_args(argv)
     if a.reads <= 0:
         a.reads = DEFAULT_READS.get(a.cfg, 100000)
@@ -158,7 +188,7 @@ def main():
     if rank == 0 and world == 1 and others != "none":
         for c in [x for x in others.split(",") if x]:
             t_ = time.time()
-            other_recs[c] = (make_reads(c, min(OTHER_UNIQUE, DEFAULT_READS[c]), 0, effective_cores()), time.time() - t_)
+            other_recs[c] = (make_reads(c, DEFAULT_READS[c] if a.other_unique <= 0 else min(a.other_unique, DEFAULT_READS[c]), 0, effective_cores()), time.time() - t_)
 
     import torch
     # test hook (tests/test_gpu_two_ranks.py): C3_BENCH_DEVICE_MAP="0,0" puts every rank on GPU 0 and the barrier / MAX go over
@@ -279,15 +309,21 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the number
         # comes from the committed rocprofv3 passes of THIS command when the workload matches
         traffic, tsrc = None, None
-        for tag in ("r03", "r02", "r01"):
+        sha = kernel_src_sha()
+        for tag in ("r04", "r03", "r02", "r01"):
             try:
                 name = "%s_pmc_traffic_%s_%dk.json" % (tag, a.cfg, a.reads // 1000)
                 pm = json.load(open(os.path.join(ROOT, "profiles", name)))
-                traffic = pm["kernels"][dom.replace("ms_", "k_")]["hbm_bytes_per_launch"]
-                tsrc = "profiles/%s (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024)" % name
-                break
+                t_ = pm["kernels"][dom.replace("ms_", "k_")]["hbm_bytes_per_launch"]
             except Exception:
                 continue
+            if pm.get("kernel_src_sha") == sha:
+                traffic = t_
+                tsrc = "profiles/%s (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024; kernel sources %s = this build)" % (name, sha)
+            else:               # measured on other kernels than the ones running here: not this run's traffic
+                tsrc = "none for this build (kernel sources %s; profiles/%s was measured on %s: %.4g bytes per launch)" % (
+                    sha, name, pm.get("kernel_src_sha", "an earlier round's kernels"), t_)
+            break
         out = {
             "metric": "R2C2 reads->consensus/sec", "value": round(value, 1), "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
@@ -317,8 +353,10 @@ def main():
         }
     h.close()
     host.close()
+    if rank == 0 and not a.no_cpu:
+        out["parity_sample"] = parity_sample(recs, n_unique, res, cbuf, coff, md)
     if rank == 0 and world == 1 and other_recs:
-        out["other_configs"] = {c: run_other_config(c, local_rank, *other_recs[c]) for c in other_recs}
+        out["other_configs"] = {c: run_other_config(c, local_rank, *other_recs[c], check=not a.no_cpu) for c in other_recs}
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(recs, md, a.cpu_seconds)
     if dist is not None:
@@ -328,12 +366,10 @@ def main():
         print(json.dumps(out))
 
 
-OTHER_UNIQUE = 20000
-
-
-def run_other_config(cfg, device, recs, gen_s, steps=3):
-    """the same pipelined step (stage || run -> results snapshot -> commit, fetch beside the next run) on another BASELINE config, per-GPU size, `unique` distinct
-    reads tiled: driver-clocked rates for cfg3 / cfg4 next to the cfg2 headline (parity of these shapes: tests/test_gpu_configs.py)"""
+def run_other_config(cfg, device, recs, gen_s, steps=3, check=True):
+    """the same pipelined step (stage || run -> results snapshot -> commit, fetch beside the next run) on another BASELINE config at its per-GPU size, every
+    read distinct (unless --other-unique tiles them): driver-clocked rates for cfg3 / cfg4 next to the cfg2 headline, each with an oracle check of 64
+    random reads of the batch after its timed region (full parity of these shapes: tests/test_gpu_configs.py)"""
     import torch
     from c3poa_amd import _lib, synth
     n = DEFAULT_READS[cfg]
@@ -377,8 +413,10 @@ def run_other_config(cfg, device, recs, gen_s, steps=3):
          "cells": int(tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish"]), "cells_polish_computed": int(tm["cells_polish_computed"]),
          "band_fallback_layers": int(tm["n_band_fallback"]), "band_layers": int(tm["n_band_layers"]), "windows_second_launch": int(tm["n_win_redo"]),
          "consensus_ok": int((res["status"] == 0).sum()), "identity_vs_truth_mean": round(float(np.mean(idents)), 5),
-         "data": "synthetic %s, %d distinct reads tiled x%d" % (cfg, nu, reps), "gen_s": round(gen_s, 1)}
+         "data": "synthetic %s, %d distinct reads%s" % (cfg, nu, "" if reps == 1 else " tiled x%d" % reps), "gen_s": round(gen_s, 1)}
     h.close(); host.close()
+    if check:
+        o["parity_sample"] = parity_sample(recs, nu, res, cbuf, coff, synth.CONFIGS[cfg]["mdist"])
     return o
 
 

@@ -20,6 +20,15 @@ def kname(raw):
     return k.replace("k_window<false>", "k_window").replace("k_window<true>", "k_window_second_launch")
 
 
+def kernel_src_sha(root):
+    """same hash as bench.py's kernel_src_sha(): the kernel sources these counters were measured on"""
+    import hashlib
+    hsh = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(root, "c3poa_amd", "csrc", "*.hip")) + glob.glob(os.path.join(root, "c3poa_amd", "csrc", "*.h"))):
+        hsh.update(os.path.basename(f).encode() + b"\0" + open(f, "rb").read())
+    return hsh.hexdigest()[:16]
+
+
 def counter_sum(d, name):
     acc, calls = defaultdict(float), defaultdict(int)
     for f in glob.glob(os.path.join(d, "*results.db")):          # rocprofv3 default output (rocpd sqlite)
@@ -61,7 +70,7 @@ def main():
                    "calibrated with tools/pmc_calibrate.py; WRITE_SIZE exact).",
            "calibration": {"source": "tools/pmc_calibrate.py under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on this pool (round 1)",
                            "bytes_read": 1073741824, "bytes_written": 1073741824, "FETCH_SIZE_KB": 524307.25, "WRITE_SIZE_KB": 1048576.0},
-           "workload": wl, "kernels": {}}
+           "workload": wl, "kernel_src_sha": kernel_src_sha(root), "kernels": {}}
     for k in sorted(set(fetch) | set(write), key=lambda k: -(2 * fetch.get(k, 0) + write.get(k, 0))):
         if not k.startswith("k_"):
             continue
