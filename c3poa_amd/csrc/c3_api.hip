@@ -16,7 +16,7 @@ extern "C" void c3k_launch_pairwise(const uint8_t*, int, const uint8_t*, int, co
 extern "C" void c3k_launch_match_index(const char*, const int*, int, int, const char*, const long long*, int*, hipStream_t);
 extern "C" void c3k_launch_peaks(const PeaksArgs*, int, hipStream_t);
 extern "C" int c3k_peaks_blocks_per_cu(void);
-extern "C" void c3k_launch_poa(const PoaArgs*, int, hipStream_t);
+extern "C" void c3k_launch_poa(const PoaArgs*, int, int, hipStream_t);
 extern "C" void c3k_launch_prep(const PrepArgs*, int, hipStream_t);
 extern "C" void c3k_launch_window(const WinArgs*, int, hipStream_t);
 extern "C" void c3k_launch_stitch(const StitchArgs*, int, hipStream_t);
@@ -165,6 +165,7 @@ struct c3_handle {
   DBuf d_raw, d_nraw, d_sum, d_work, d_bufA, d_bufB, d_cand, d_cst, d_msa, d_msa_off, d_msa_len;
   DBuf s_poa_i, s_poa_nk, s_poa_cells, s_poa_b, s_poa_sc, s_poa_desc, s_poa_jump, s_poa_path, d_overflow;      // POA scratch
   int n_poa_redo = 0;        // reads of the last run that needed the full-size second POA pass
+  int n_poa_redo16 = 0;      // ... of them: because a score left the 16-bit cells
   DBuf s_eH, s_eD, s_lw, d_wrec, d_wlay, d_wbase, d_wout;       // prep / windows
   DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc, s_win_h2, s_win_d2, d_wovf;
   DBuf s_zero_d, d_zinfo, d_zflag, d_zwork; std::vector<int> zwork;  // window scratch
@@ -577,12 +578,14 @@ static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, 
   a.bbase = h->s_poa_b.as<uint8_t>(); a.score = h->s_poa_sc.as<long long>();
   a.Ncap = Ncap; a.K = K; a.Pcap = Pcap; a.cells_cap = (int)cells; a.desc = h->s_poa_desc.as<uint4>(); a.jump = h->s_poa_jump.as<int>();
   a.pbase = h->s_poa_path.as<int>(); a.overflow = d_overflow;
+  if (const char* e = getenv("C3_DEBUG_POA_RBSPAN")) a.rb_span = std::max(3300, atoi(e));      // (>= the 400 units below the bias + a row's growth)
   a.draft = h->d_draft.as<uint8_t>(); a.tpos = h->d_tpos.as<int32_t>();
   a.msa_dbg = nullptr; a.msa_off = nullptr; a.msa_len = nullptr;
   if (h->debug_msa) { a.msa_dbg = h->d_msa.as<uint8_t>(); a.msa_off = h->d_msa_off.as<int64_t>(); a.msa_len = h->d_msa_len.as<int>(); }
   a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
   DBG("poa: nw=%d Ncap=%d K=%d cells=%lld slots=%d (%.1f MB per slot)%s\n", nw, Ncap, K, cells, slots, per_slot / 1048576.0, d_overflow ? "" : " [full-size pass]");
-  c3k_launch_poa(&a, slots, h->stream);
+  // the pass with an overflow list runs the 16-bit rows; the final pass (no list) the 32-bit rows only (C3_DEBUG_POA32: test hook, first pass too)
+  c3k_launch_poa(&a, slots, (d_overflow == nullptr || getenv("C3_DEBUG_POA32")) ? 1 : 0, h->stream);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -621,16 +624,16 @@ static int run_poa(c3_handle* h) {
   HIPCHK(h->d_overflow.ensure(sizeof(int) * (size_t)nw));
   HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));                       // work queue only: [2..3] already holds the zero-repeat cells
   HIPCHK(hipMemsetAsync(h->d_counter.as<char>() + 16, 0, 240, h->stream));       // [4] overflow count, phase counters
-  const bool two_pass = Ncap < Ncap_full || cells < cells_full;
+  const bool two_pass = true;          // (always: a read whose scores leave the 16-bit cells of the first pass is redone by the second, 32-bit one)
   int rc = launch_poa(h, h->d_work.as<int>(), nw, Ncap, K, Pcap, cells, two_pass ? h->d_overflow.as<int>() : nullptr, 24);
   if (rc) return rc;
-  h->n_poa_redo = 0;
+  h->n_poa_redo = 0; h->n_poa_redo16 = 0;
   if (two_pass) {
     int cnt[8];
     HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 32, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (cnt[4] > 0) {
-      h->n_poa_redo = cnt[4];
+      h->n_poa_redo = cnt[4]; h->n_poa_redo16 = cnt[5];
       HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
       if ((rc = launch_poa(h, h->d_overflow.as<int>(), cnt[4], Ncap_full, K, Pcap, cells_full, nullptr, 24))) return rc;
     }
@@ -793,7 +796,7 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
       HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 64, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       if (!h->work.empty()) h->tm.cells_poa = *(long long*)(cnt + 2);
-      h->tm.n_poa_redo = h->n_poa_redo;
+      h->tm.n_poa_redo = h->n_poa_redo; h->tm.n_poa_redo16 = h->n_poa_redo16;
       DBG("run: poa done\n");
       HIPCHK(hipEventElapsedTime(&ms, t3, t4)); h->tm.ms_poa = ms;
     }

@@ -23,6 +23,7 @@ struct PoaArgs {
   unsigned long long* phases; uint4* desc; int* jump;
   int* pbase;               // [slots][Pcap] node of every fused base
   int* overflow;            // first pass: reads whose scratch overflowed (count in counter[4]); nullptr in the final pass
+  int rb_span;              // 0 = default; test hook C3_DEBUG_POA_RBSPAN: width of the window a row maximum may move in before the 16-bit base follows it
 };
 struct WLayer { int qbeg, len, begin, end; };
 struct WinRec { int rid, w, n_layers, blen, tgs, out_len, polished, pad_; };

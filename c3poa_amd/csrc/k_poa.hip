@@ -30,7 +30,11 @@ struct Ctx {
   int* I; int* E; char* C; uint8_t* B8; long long* score_; uint4* desc_; int* jump_; int* path_;
   int K, n, Ncap, cells_cap;
   int osel;                  // which of the two order buffers is current (g_reorder writes the other one and flips)
+  int rb_span;               // RB_HI16 - RB_LO16 (smaller under the C3_DEBUG_POA_RBSPAN test hook: the base moves every few rows)
   const uint32_t* pk;        // packed read
+#ifdef C3_DEBUG_PUNT
+  unsigned long long* dbg;
+#endif
 #define CTX_I(name, k) __device__ __forceinline__ int* name() const { return I + (size_t)(k) * Ncap; }
   CTX_I(n_in, 0) CTX_I(n_out, 1) CTX_I(grp, 2) CTX_I(index, 5) CTX_I(gfirst, 6) CTX_I(glast, 7)
   CTX_I(rem, 8) CTX_I(mpl, 9) CTX_I(mpr, 10) CTX_I(rowm, 11) /* 3 ints per row: band begin, band end, cell offset (blocks 11..13) */ CTX_I(anchor, 14) CTX_I(col, 15)
@@ -138,21 +142,63 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 // latency only, and -- since gfx9 counts loads and stores in ONE in-order vmcnt -- the row loop
 // carries no vector loads on its common path (descriptors arrive 64 rows at a time and are broadcast
 // with v_readlane).  Rows with a successor more than PR-1 rows ahead, or wider than a ring slot,
-// also go to the global arena; the direction words always do (4 B per cell).
+// also go to the global arena (32-bit); the direction bytes always do.
+//
+// Round 4: the ring and the fast / near rows work on 16-BIT CELLS.  A cell is kept relative to a per-row base (the row's
+// own maximum; the absolute base of every ring row sits beside its band record), as a BIASED UNSIGNED key score*8 + 3 tag
+// bits: every value is a non-negative number below 2^16, so the cheap 16-bit VOP2 max (v_max_u16: 2.3 cycles against 4.2 for
+// the 32-bit max) and plain 32-bit adds / DPP max-scans can be mixed freely (a zero-extended unsigned key IS its 32-bit
+// value).  Measured with the oracle on the config shapes (tools/poa_row_stats.py): no reachable cell lies more than 391
+// below its row's maximum and consecutive row maxima differ by at most 38, against +-4095 of range.  Unreachable cells are a
+// low constant (NEG16); a ring row is padded with it on both sides, so a predecessor cell outside the predecessor's band
+// reads as unreachable WITHOUT any validity compare (clamped offset -> pad).  Exactness is guarded, not assumed: every stored
+// H must be either plainly reachable (>= GLO16) or plainly unreachable (<= ZHI16); a read with a value in between (a
+// reachable score that fell out of range, or a chain of unreachable cells that drifted up) is handed to the second pass,
+// whose kernel instance (W32) computes every row with the 32-bit general row and no ring at all.
 #ifndef C3_NEAR
 #define C3_NEAR 1
 #endif
-#define PW 128      // ring slot width (cells)
-#define PR 4        // ring rows
+#define PW 128      // ring slot width (cells): two chunks of 64
+#define PR 6        // ring rows (a predecessor up to 5 rows back is read from LDS: 99.7 % of them at cfg4)
+#define PADL 3      // unreachable cells on both sides of a ring row
+#define PADR 3
+#define PWT (PADL + PW + PADR)
 #define PQW 112     // packed query words kept in LDS (1792 bases); longer subreads read the packed read
-struct PoaLds { int H[PR][PW], E1[PR][PW], E2[PR][PW]; int4 meta[PR] /* band begin, end, leftmost / rightmost argmax */; unsigned qpk[PQW]; };
+struct PoaLds { unsigned short H[PR][PWT], E1[PR][PWT], E2[PR][PWT]; int4 meta[PR] /* band begin, end, leftmost / rightmost argmax */; int base8[8] /* absolute base * 8 of the row */; unsigned qpk[PQW]; };
 __shared__ PoaLds L;     // file scope: accesses stay in the LDS address space (ds_*, lgkmcnt only)
+#define POA_LDS_INTS ((int)(3 * PR * PWT * sizeof(unsigned short) / sizeof(int)))      // the three rings as scratch of the graph phases
 
-// scores are carried as score*512 (+ a 9-bit tag while candidates compete): one v_max per candidate
-// implements "highest score, first candidate in order".  Unreachable cells use -(2^20) score units.
+// general rows (and the global arena): scores are carried as score*512 (+ a 9-bit tag while candidates compete): one v_max per
+// candidate implements "highest score, first candidate in order".  Unreachable cells use -(2^20) score units.
 #define S9(x) ((x) * 512)
 #define NEGS (-(1 << 29))
 #define NEG2S (-(1 << 30))
+// fast / near rows and the ring: biased unsigned 16-bit keys, (score - row base) * 8 + BIAS16 (+ 3 tag bits while candidates compete)
+#define S3(x) ((x) * 8)
+#define BIAS16 32768
+#define NEG16 6000          // unreachable
+#define NEG2_16 2000        // "no left neighbour" of the horizontal states / idle lanes of the scans
+#define FLOOR16 5000        // stored H never sinks below this (a chain of unreachable cells loses ~9 a row to the rebasing)
+#define ZHI16 12000         // a stored H up to here is unreachable ...
+#define GLO16 24864         // ... from here on reachable (990 score units below the row maximum); in between: not representable
+#define ZLO16 20768         // conversion threshold between the two (E1 / E2 sit up to 25 units below an H)
+#define RB_LO16 (BIAS16 - 400 * 8)   // a row whose maximum leaves [RB_LO16, RB_HI16] moves its base to the maximum (about every 300 rows: the
+#define RB_HI16 (BIAS16 + 1600 * 8)  // score grows by at most 5 a row); all other rows keep the base of the row before them
+// (volatile: hipcc sinks a plain asm that feeds one arm of a select into an EXEC-masked branch -- two scalar branches per row)
+#ifdef C3_EXP_ASMNV
+#define C3_ASMV
+#else
+#define C3_ASMV volatile
+#endif
+__device__ __forceinline__ int maxu16(int a, int b) { int d; asm C3_ASMV("v_max_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ int minu16(int a, int b) { int d; asm C3_ASMV("v_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ int cv_16to9(int v, int b8) { return v >= ZLO16 ? (int)((unsigned)(v - BIAS16 + b8) << 6) : NEGS; }
+__device__ __forceinline__ int cv_9to16(int x9, int b8, int& bad) {
+  if (x9 <= NEGS / 2) return NEG16;
+  const int r = (x9 >> 6) - b8 + BIAS16;
+  if (r < GLO16 - 4096 || r > 60000) bad = 1;
+  return r;
+}
 
 // direction word (device-internal): mp[0..7] | e1code[8..16] | e2code[17..25] | hts[26..27] | hs[28..29]
 // | f1x[30] | f2x[31];  e?code = 2*pred + ext;  hts: 0 M, 1 E1, 2 E2;  hs: 0 Ht, 1 F1, 2 F2
@@ -163,7 +209,7 @@ __shared__ PoaLds L;     // file scope: accesses stay in the LDS address space (
 // the first, a target outside the chunk is already final (one gather from hops[]), and the chains inside a chunk are
 // resolved by pointer doubling between lanes (ds_bpermute, at most six rounds).  Replaces log2(n) rounds of pointer jumping
 // over four node arrays in memory by four dependent memory levels per chunk.
-// descriptor A: x = node, y = unused, z = base | nin<<8 | far<<16 | (nin>4)<<17 | fast-row candidate<<18 | sink<<19, w = qr = Q - rem;
+// descriptor A: x = node, y = ring slots (position mod PR) of the first four predecessors, 4 bits each, z = base | nin<<8 | far<<16 | (nin>4)<<17 | fast-row candidate<<18 | sink<<19, w = qr = Q - rem;
 // descriptor B: positions of the first four predecessors.  hops[] (by position) lives in col() (free until the MSA columns).
 __device__ void poa_sweep_desc(Ctx& c, int lane, int Q, bool qlds) {
   const int n = c.n;
@@ -195,7 +241,8 @@ __device__ void poa_sweep_desc(Ctx& c, int lane, int Q, bool qlds) {
     }
     if (live) {
       hops[idx] = d;
-      uint4 A; A.x = (unsigned)v; A.y = 0;
+      uint4 A; A.x = (unsigned)v;
+      A.y = (p[0] % PR) | ((p[1] % PR) << 4) | ((p[2] % PR) << 8) | ((p[3] % PR) << 12);
       A.z = (unsigned)c.base()[v] | ((unsigned)min(nin, 255) << 8) | (far << 16) | ((unsigned)(nin > 4) << 17);
       // bit 18: candidate for the fast row (one predecessor, the row above; query in LDS); bit 19: the sink (no DP row)
       A.z |= ((unsigned)(qlds && nin == 1 && (int)p[0] == idx - 1 && v != SRC && v != SNK) << 18) | ((unsigned)(v == SNK) << 19);
@@ -208,14 +255,31 @@ __device__ void poa_sweep_desc(Ctx& c, int lane, int Q, bool qlds) {
 }
 
 // banded global alignment of subread [qb, qb+Q) against the graph; ops are written BACKWARDS
-// into opn/opq, returns their count (or <0 on failure)
+// into opn/opq, returns their count (or <0 on failure: -4 scratch too small, -5 a value that 16-bit cells cannot hold)
+// W32 (second pass): every row is a general row on 32-bit cells from the global arena, the ring is not used
+// DEF: the scoring is abPOA's default with match 5 (what the reference runs: bin/determine_consensus.py:30) -- every score is an
+// immediate operand then; otherwise they are read from the parameters (SGPRs, most of them spilled into VGPR lanes: one
+// v_readlane per use in the row loop)
+template <bool W32, bool DEF>
 __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, long long* cells PHA) {
   const int K = c.K, n = c.n;
-  const int mt9 = S9(P.poa_match), mm9 = S9(-P.poa_mismatch);
-  const int e1_9 = S9(P.e1), e2_9 = S9(P.e2), o1_9 = S9(P.o1), o2_9 = S9(P.o2), oe1_9 = S9(P.o1 + P.e1), oe2_9 = S9(P.o2 + P.e2);
+  const int mt8 = DEF ? S3(5) : S3(P.poa_match), mm8 = DEF ? S3(-4) : S3(-P.poa_mismatch);
+  const int e1_8 = DEF ? S3(2) : S3(P.e1), e2_8 = DEF ? S3(1) : S3(P.e2), o1_8 = DEF ? S3(4) : S3(P.o1), o2_8 = DEF ? S3(24) : S3(P.o2);
+  const int oe1_8 = o1_8 + e1_8, oe2_8 = o2_8 + e2_8;
+  // (the general row's score*512 constants: derived where that row needs them)
+#define mt9 (mt8 << 6)
+#define mm9 (mm8 * 64)
+#define e1_9 (e1_8 << 6)
+#define e2_9 (e2_8 << 6)
+#define o1_9 (o1_8 << 6)
+#define o2_9 (o2_8 << 6)
+#define oe1_9 (oe1_8 << 6)
+#define oe2_9 (oe2_8 << 6)
   const int w = wave_first(P.band_b + (int)(P.band_f * (double)Q));
-  const int le1 = e1_9 * lane, le2 = e2_9 * lane;                   // the F scans run in lane coordinates: e*(j-beg) = e*lane
-  const int lo1 = le1 + o1_9, lo2 = le2 + o2_9;
+  const int le1_8 = e1_8 * lane, le2_8 = e2_8 * lane;               // the F scans run in lane coordinates: e*(j-beg) = e*lane
+#define le1 (le1_8 << 6)
+#define le2 (le2_8 << 6)
+  const int lo1_8 = le1_8 + o1_8, lo2_8 = le2_8 + o2_8;
   const bool qlds = Q <= PQW * 16;
   poa_sweep_desc(c, lane, Q, qlds);
   // the subread, 2-bit packed and re-aligned to its first base, goes to LDS: the row loop must not
@@ -227,6 +291,8 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       L.qpk[i] = __builtin_amdgcn_alignbit(w1, w0, (unsigned)(b0 & 15) * 2);
     }
   }
+  // every ring cell starts unreachable (the pads stay so: rows only write their PW cells)
+  if (!W32) { unsigned* r32 = (unsigned*)&L.H[0][0]; for (int i = lane; i < POA_LDS_INTS; i += 64) r32[i] = NEG16 | (NEG16 << 16); }
   WSYNC();
   PH_MARK(0)
   // Row loop.  The scalar ALU is ONE per CU (measured: 0.96 scalar instructions per cycle per CU against 1.5-1.7 vector
@@ -234,32 +300,44 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   // cell counter -- live in VECTOR registers (every lane holds the same number) and the band arithmetic runs on the vector
   // ALU; the scalar unit only sees the loop, one descriptor test and two branches per row.
   int u_beg = 0, u_end = -1, u_left = 0, u_right = 0, u_ncell = 0;                    // previous row / cells used so far
-  int pH = NEGS, pE1 = NEGS, pE2 = NEGS;                                              // its cells, lane = band column
+  int u_b8 = 0;                                                                        // ... and its base (absolute score * 8)
+  int pH = NEG16, pE1 = NEG16, pE2 = NEG16;                                           // its 16-bit cells, lane = band column
   bool pv_ok = false;                                                                  // ... valid: the row above, <= 64 cells
+  int gacc = 0xffff;                                                                   // guard: lowest (stored H - ZHI16 - 1) mod 2^16 per lane
+  int punt = 0;                                                                        // a value the 16-bit cells cannot hold was seen
   const int lane4 = lane * 4;
+  unsigned short* const LH = &L.H[0][0]; unsigned short* const LE1 = &L.E1[0][0]; unsigned short* const LE2 = &L.E2[0][0];
+#ifdef C3_EXP_SBAND
+#define UNI(x)                                   /* experiment: band arithmetic of the fast row on the scalar unit */
+#else
 #define UNI(x) asm volatile("" : "+v"(x))       /* keep a uniform value in a vector register (no instruction) */
+#endif
 #ifdef C3_PHASE_PROF
   unsigned long long row_t0 = __builtin_readcyclecounter();
 #endif
+  int slot = PR - 1;                                                                   // ring slot of the row: position mod PR
   for (int ib = 0; ib < n; ib += 64) {
   uint4 dA = c.descA()[min(ib + lane, n - 1)], dB = c.descB()[min(ib + lane, n - 1)];
   asm volatile("" : "+v"(dA.x), "+v"(dA.y), "+v"(dA.z), "+v"(dA.w), "+v"(dB.x), "+v"(dB.y), "+v"(dB.z), "+v"(dB.w));   // wait here, not in the row loop
   const int cnt = min(64, n - ib);
   for (int li = 0; li < cnt; ++li) {
     const int idx = ib + li;
+    slot = slot == PR - 1 ? 0 : slot + 1;
     const int fl = __builtin_amdgcn_readlane(dA.z, li);
     if ((fl >> 19) & 1) { pv_ok = false; continue; }                                  // the sink has no row
     const int qr = __builtin_amdgcn_readlane(dA.w, li);
     const int vb = fl & 0xff;
-    const bool far = (fl >> 16) & 1;
+    const bool far = W32 || ((fl >> 16) & 1);
     // ---- FAST ROW: one predecessor = the previous row, whose H/E1/E2 are still in this wave's REGISTERS (lane = band
     // column).  The predecessor cells arrive by lane permutes (no LDS round trip through memory on the dependent chain),
     // the row maximum is taken from Ht in parallel with the two F scans (an F value is always strictly below some Ht to
     // its left, so max H == max Ht and both are attained in the same columns), and every tie order is a tag in the low
-    // bits of the compared keys, so the direction cell is 1 byte of masked key bits
+    // bits of the compared keys.  No validity compares: idle lanes of the previous row hold NEG16, and the row only qualifies
+    // when no ACTIVE lane's permute wraps around the wave (wd + shift <= 64; lane 0's diagonal source, lane 63 of the previous
+    // row, must be idle when the band did not move)
     // (DIRECTION BYTE, all rows): bit0 E1 opened (0 = extended), bit1 E2 opened, bits2-3 Ht source (2 M, 1 E1, 0 E2),
     // bits4-5 H source (2 Ht, 1 F1, 0 F2), bit6 F1 extended, bit7 F2 extended.
-    if (((fl >> 18) & 1) && pv_ok) {
+    if (!W32 && ((fl >> 18) & 1) && pv_ok) {
       UNI(u_beg); UNI(u_end); UNI(u_left); UNI(u_right); UNI(u_ncell);
       const bool nonempty = u_end >= u_beg;
       const int mplv = nonempty ? u_left + 1 : INT32_MAX / 2, mprv = nonempty ? u_right + 1 : 0;
@@ -268,8 +346,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       end = max(end, beg - 1);
       const int wd = end - beg + 1, sh = beg - u_beg;
       // (64 cells of head room instead of wd: the stores below are not masked)
-      if (__builtin_amdgcn_ballot_w64((unsigned)(wd - 1) < 64u && sh < 64 && u_ncell + 64 <= c.cells_cap) != 0) {
-        const int slot = idx & (PR - 1);
+      if (__builtin_amdgcn_ballot_w64(((int)((unsigned)(wd - 1) < 64u) & (int)(wd + sh <= 64) & ((int)(sh >= 1) | (int)(u_end - u_beg < 63)) & (int)(u_ncell + 64 <= c.cells_cap)) != 0) != 0) {
         const int ro = u_ncell;
         const int j = beg + lane;
         const bool act = lane < wd;
@@ -278,47 +355,62 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         const unsigned qw_ = L.qpk[min(jq >> 4, PQW - 1)];
         // previous row moved to this row's columns: hp = H[i-1][j] sits sh lanes to the right, hd = H[i-1][j-1] one less
         const int a_p = lane4 + sh * 4, a_d = a_p - 4;
-        const int hd_ = __builtin_amdgcn_ds_bpermute(a_d, pH), hp_ = __builtin_amdgcn_ds_bpermute(a_p, pH);
-        const int e1_ = __builtin_amdgcn_ds_bpermute(a_p, pE1), e2_ = __builtin_amdgcn_ds_bpermute(a_p, pE2);
-        const bool vp = j <= u_end, vd = a_d >= 0;                              // (j - 1 <= u_end always: end <= u_end + 1)
-        const int hd = vd ? hd_ : NEGS, hp = vp ? hp_ : NEGS, e1p = vp ? e1_ : NEGS, e2p = vp ? e2_ : NEGS;
+        const int hd = __builtin_amdgcn_ds_bpermute(a_d, pH), hp = __builtin_amdgcn_ds_bpermute(a_p, pH);
+        const int e1p = __builtin_amdgcn_ds_bpermute(a_p, pE1), e2p = __builtin_amdgcn_ds_bpermute(a_p, pE2);
         const int qc = (int)((qw_ >> ((jq & 15) * 2)) & 3);
-        const int M9 = hd + ((vb == qc) ? mt9 + 8 : mm9 + 8);                   // tag 2 in bits 2-3
-        const int E1t = max(hp - (oe1_9 - 1), e1p - e1_9);                     // bit 0 set: opened (open wins ties)
-        const int E2t = max(hp - (oe2_9 - 2), e2p - e2_9);                     // bit 1 set: opened
-        const int E1c = E1t & ~511, E2c = E2t & ~511;
-        const int k2 = max(max(M9, E1c + 4), E2c);
-        const int ht9 = k2 & ~511;
-        const int htm = act ? ht9 : NEG2S;
+        const int M = hd + ((vb == qc) ? mt8 + 2 : mm8 + 2);                   // Ht source in bits 0-1: M 2, E1 1, E2 0
+        const int E1t = maxu16(hp - (oe1_8 - 1), e1p - e1_8);                  // bit 0 set: opened (open wins ties)
+        const int E2t = maxu16(hp - (oe2_8 - 2), e2p - e2_8);                  // bit 1 set: opened
+        const int E1c = E1t & ~7, E2c = E2t & ~7;
+        const int k2 = maxu16(maxu16(M, E1c + 1), E2c);
+        const int ht = k2 & ~7;
+        const int htm = act ? ht : NEG2_16;
         // F[j] = max_{k<j} Ht[k] - o - e*(j-k): scanned in lane coordinates (the e*beg term cancels)
-        int s1 = htm + le1, s2 = htm + le2, s3 = htm;
+        int s1 = htm + le1_8, s2 = htm + le2_8, s3 = htm;
         wave_scan_max3(s1, s2, s3);
-        const int px1 = wave_shr1(s1, NEG2S), px2 = wave_shr1(s2, NEG2S);
-        const int htl = wave_shr1(htm, NEGS);
-        const int f1 = px1 - lo1, f2 = px2 - lo2;
-        const int k3 = max(max(ht9 + 32, f1 + 16), f2);
-        const int h9 = k3 & ~511;
-        unsigned d = ((unsigned)E1t & 1u) | ((unsigned)E2t & 2u) | ((unsigned)k2 & 12u) | ((unsigned)k3 & 48u);
-        d |= (((unsigned)(htl - oe1_9 - f1)) >> 25) & 64u;                      // f1 > its "open" candidate: extended
-        d |= (((unsigned)(htl - oe2_9 - f2)) >> 24) & 128u;
-        pH = act ? h9 : NEGS; pE1 = act ? E1c : NEGS; pE2 = act ? E2c : NEGS;
-        // unmasked stores: lanes past the band write cells that the next rows overwrite / that no reader ever selects
-        c.D8()[(unsigned)(ro + lane)] = (uint8_t)d;
-        L.H[slot][lane] = h9; L.E1[slot][lane] = E1c; L.E2[slot][lane] = E2c;
-        const int rb = __builtin_amdgcn_readlane(s3, 63);
+        const int px1 = wave_shr1(s1, NEG2_16), px2 = wave_shr1(s2, NEG2_16);
+        const int htl = wave_shr1(htm, NEG16);
+        const int f1 = px1 - lo1_8, f2 = px2 - lo2_8;
+        const int k3 = maxu16(maxu16(ht + 2, f1 + 1), f2);                     // H source in bits 0-1: Ht 2, F1 1, F2 0
+        const int h = k3 & ~7;
+        unsigned d = ((unsigned)E1t & 1u) | ((unsigned)E2t & 2u) | (((unsigned)k2 & 3u) << 2) | (((unsigned)k3 & 3u) << 4);
+        d |= (((unsigned)(htl - oe1_8 - f1)) >> 25) & 64u;                      // f1 > its "open" candidate: extended
+        d |= (((unsigned)(htl - oe2_8 - f2)) >> 24) & 128u;
+        const int rb = __builtin_amdgcn_readlane(s3, 63);                       // row maximum (of Ht == of H)
         // first / last column holding the row maximum: columns are beg + lane, so one ballot replaces two reductions
         const unsigned long long mxm = __ballot(htm == rb);
         const int left = beg + __builtin_ctzll(mxm), right = beg + (63 - __builtin_clzll(mxm));
+        // the row leaves relative to its own maximum; idle lanes unreachable
+        pH = maxu16(act ? h : NEG16, FLOOR16); pE1 = act ? E1c : NEG16; pE2 = act ? E2c : NEG16;      // (select first: NEG16 > FLOOR16)
+        int nb8 = u_b8;
+        if ((unsigned)(rb - RB_LO16) > (unsigned)c.rb_span) {         // rare: the base follows the row maximum
+          // (saturating: an unreachable cell sits far below any base shift and must stay at the floor, not wrap around)
+          const int m1 = rb - BIAS16, fl1 = FLOOR16 + max(m1, 0);
+          nb8 += m1; punt |= (int)(rb < GLO16);
+          pH = act ? maxu16(h, fl1) - m1 : NEG16; pE1 = act ? maxu16(E1c, fl1) - m1 : NEG16; pE2 = act ? maxu16(E2c, fl1) - m1 : NEG16;
+        }
+        gacc = minu16(gacc, pH - (ZHI16 + 1));
+#ifdef C3_DEBUG_PUNT
+        if (pH > ZHI16 && pH < GLO16) { atomicAdd(c.dbg + 8, 1ull); atomicMax(c.dbg + 9, ((unsigned long long)(65535 - pH) << 40) | ((unsigned long long)idx << 16) | ((unsigned long long)lane << 8) | (unsigned long long)(wd & 255)); atomicMax(c.dbg + 10, ((unsigned long long)(65535 - pH) << 40) | ((unsigned long long)(unsigned short)rb << 16) | (unsigned)(sh & 255) << 8 | (unsigned)(u_end - u_beg + 1)); }
+#endif
+        // unmasked stores: lanes past the band write cells that the next rows overwrite / that no reader ever selects
+        c.D8()[(unsigned)(ro + lane)] = (uint8_t)d;
+        { const int cb = slot * PWT + PADL + lane;
+          LH[cb] = (unsigned short)pH; LE1[cb] = (unsigned short)pE1; LE2[cb] = (unsigned short)pE2;
+#ifndef C3_EXP_NOFILL
+          LH[cb + 64] = NEG16; LE1[cb + 64] = NEG16; LE2[cb + 64] = NEG16;      // (a one-chunk row: its second chunk reads as unreachable)
+#endif
+        }
         if (lane == 0) {
-          L.meta[slot] = make_int4(beg, end, left, right);
+          L.meta[slot] = make_int4(beg, end, left, right); L.base8[slot] = nb8;
           int off = 3 * idx; UNI(off);
           int* rm = c.rowm() + off; rm[0] = beg; rm[1] = end; rm[2] = ro;                 // type 0: byte cells, one predecessor
         }
         if (far) {
-          if (act) { c.H()[ro + lane] = h9; c.E1()[ro + lane] = E1c; c.E2()[ro + lane] = E2c; }
+          if (act) { c.H()[ro + lane] = cv_16to9(pH, nb8); c.E1()[ro + lane] = cv_16to9(pE1, nb8); c.E2()[ro + lane] = cv_16to9(pE2, nb8); }
           if (lane == 0) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
         }
-        u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ro + wd;
+        u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ro + wd; u_b8 = nb8;
 #ifdef C3_PHASE_PROF
         { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[8] += t_ - row_t0; row_t0 = t_; }
 #endif
@@ -330,30 +422,36 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     const bool ovf = (fl >> 17) & 1;
     const int p0 = __builtin_amdgcn_readlane(dB.x, li), p1 = __builtin_amdgcn_readlane(dB.y, li);
     const int p2 = __builtin_amdgcn_readlane(dB.z, li), p3 = __builtin_amdgcn_readlane(dB.w, li);
+    const int psl = __builtin_amdgcn_readlane(dA.y, li);
+    const int ps0 = psl & 15, ps1 = (psl >> 4) & 15, ps2 = (psl >> 8) & 15, ps3 = (psl >> 12) & 15;      // their ring slots
 #define PRED_IDX(k) ((k) == 0 ? p0 : (k) == 1 ? p1 : (k) == 2 ? p2 : (k) == 3 ? p3 : c.index()[c.in_from()[EI(v, (k))]])
+#define PRED_SLOT(k) ((k) == 0 ? ps0 : (k) == 1 ? ps1 : (k) == 2 ? ps2 : ps3)
     int ncell = wave_first(u_ncell);
     // ---- NEAR ROW: up to four predecessors, every one of them among the last PR-1 rows (so its cells and band record are in
     // the LDS ring) -- the usual member of an aligned block and the node after it -- and a band of at most 64 (one chunk) or
-    // 128 columns (two chunks: the rows whose nominal column has drifted away from the predecessors' maxima).  Branch free: the
-    // ring records and the predecessor cells are read unconditionally (clamped addresses), an absent predecessor is given an
-    // empty band far to the right so that every mask derived from it is false, the band arithmetic runs on the vector ALU
-    // (uniform values), and one ballot decides whether the row qualifies.  Tie order by tags exactly as in the general row
-    // below; direction byte + predecessor byte.  One instance per (predecessor count, chunk count).
-    if (C3_NEAR && !ovf && qlds && v != SRC && idx - p0 < PR && (nin < 2 || idx - p1 < PR) && (nin < 3 || idx - p2 < PR) && (nin < 4 || idx - p3 < PR)) {
+    // 128 columns (two chunks: the rows whose nominal column has drifted away from the predecessors' maxima).  Branch free and
+    // free of validity compares: a predecessor cell is read at a clamped offset, outside the predecessor's band that is a pad
+    // or an idle cell and holds NEG16; an absent predecessor is given a band far to the right, so all of its reads land in the
+    // left pad.  The bases of the predecessor rows differ by a few score units: the differences ride in the per-predecessor
+    // constants that carry the tie-order tags anyway.  Tie order by tags exactly as in the general row below; direction byte +
+    // predecessor byte.  One instance per (predecessor count, chunk count).
+    if (!W32 && C3_NEAR && !ovf && qlds && v != SRC && idx - p0 < PR && (nin < 2 || idx - p1 < PR) && (nin < 3 || idx - p2 < PR) && (nin < 4 || idx - p3 < PR)) {
       auto near_body = [&](auto NPc, auto NCHc) -> bool {
       constexpr int NP = decltype(NPc)::value, NCH = decltype(NCHc)::value;
       UNI(u_ncell);
       const int BIGB = 1 << 28;
-      int4 m_[NP];
+      int4 m_[NP]; int b8_[NP], sl_[NP];
 #pragma unroll
-      for (int k = 0; k < NP; ++k) m_[k] = L.meta[(k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3) & (PR - 1)];
-      int pb_[NP], pe_[NP];
-      int mplv = INT32_MAX / 2, mprv = 0, minb = INT32_MAX, maxe = INT32_MIN, wmax = 0;
+      for (int k = 0; k < NP; ++k) { sl_[k] = k < nin ? PRED_SLOT(k) : 0; m_[k] = L.meta[sl_[k]]; b8_[k] = L.base8[sl_[k]]; }
+      int pb_[NP], dk_[NP];
+      int mplv = INT32_MAX / 2, mprv = 0, minb = INT32_MAX, maxe = INT32_MIN, wmax = 0, dabs = 0;
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         const bool has = k < nin;                                             // scalar condition, used as a select mask
         const int b = has ? m_[k].x : BIGB, e = has ? m_[k].y : -BIGB;
-        pb_[k] = b; pe_[k] = e;
+        pb_[k] = b;
+        dk_[k] = has ? b8_[k] - b8_[0] : 0;                                   // this predecessor's cells against the first one's base
+        dabs = max(dabs, max(dk_[k], -dk_[k]));
         minb = min(minb, b); maxe = max(maxe, e + 1); wmax = max(wmax, e - b);
         const bool ne = e >= b;
         mplv = ne ? min(mplv, m_[k].z + 1) : mplv; mprv = ne ? max(mprv, m_[k].w + 1) : mprv;
@@ -362,11 +460,21 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       int end = min(min(Q, max(mprv, qr) + w), maxe);
       end = max(end, beg - 1);
       const int wd = end - beg + 1;
-      if (__builtin_amdgcn_ballot_w64((unsigned)(wd - 1) < (unsigned)(64 * NCH) && wmax < PW && u_ncell + 64 * NCH <= c.cells_cap) == 0) return false;
-      const int slot = idx & (PR - 1);
+      if (__builtin_amdgcn_ballot_w64(((int)((unsigned)(wd - 1) < (unsigned)(64 * NCH)) & (int)(wmax < PW) & (int)(dabs < 2048) & (int)(u_ncell + 64 * NCH <= c.cells_cap)) != 0) == 0) return false;
       const int ro = u_ncell;
-      int carry1 = NEG2S, carry2 = NEG2S, prev_ht = NEGS;                       // scan carries from the first chunk
-      int best = INT32_MIN, left = 0, right = 0;
+      const int W8 = wave_first(b8_[0]);
+      // per predecessor: base difference + tie-order tag of each candidate (first predecessor wins: highest tag; open before extend)
+      int cM[NP], c1o[NP], c1x[NP], c2o[NP], c2x[NP], sb_[NP];
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        cM[k] = dk_[k] + (3 - k);
+        c1o[k] = dk_[k] - oe1_8 + (7 - 2 * k); c1x[k] = dk_[k] - e1_8 + (6 - 2 * k);
+        c2o[k] = dk_[k] - oe2_8 + (7 - 2 * k); c2x[k] = dk_[k] - e2_8 + (6 - 2 * k);
+        sb_[k] = sl_[k] * PWT + PADL - pb_[k];                                // ring index of column 0 of this predecessor
+      }
+      int carry1 = 0, carry2 = 0, prev_ht = NEG16;                              // scan carries from the first chunk
+      int best = 0, left = 0, right = 0;
+      int cH[NCH], cE1[NCH], cE2[NCH];
 #pragma unroll
       for (int ch = 0; ch < NCH; ++ch) {
         const int c0 = 64 * ch;
@@ -377,81 +485,105 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         int hd_[NP], hp_[NP], e1_[NP], e2_[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-          const int sl = (k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3) & (PR - 1);
-          const int o = j - pb_[k];
-          const int oc = min(max(o, 0), PW - 1), om = min(max(o - 1, 0), PW - 1);
-          hd_[k] = L.H[sl][om]; hp_[k] = L.H[sl][oc]; e1_[k] = L.E1[sl][oc]; e2_[k] = L.E2[sl][oc];
+          // offset in the predecessor's row, clamped into [-2, PW+1]: everything outside the row's cells is a pad
+          const int lo_ = sl_[k] * PWT + PADL - 2, hi_ = sl_[k] * PWT + PADL + PW + 1;
+          const int ix = min(max(j + sb_[k], lo_), hi_);
+          hd_[k] = LH[ix - 1]; hp_[k] = LH[ix]; e1_[k] = LE1[ix]; e2_[k] = LE2[ix];
         }
-        int kM = INT32_MIN, kE1 = INT32_MIN, kE2 = INT32_MIN;
+        int kM = 0, kE1 = 0, kE2 = 0;
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-          const bool vd = j - 1 >= pb_[k] && j - 1 <= pe_[k], vp = j >= pb_[k] && j <= pe_[k];       // (j - 1 >= b >= 0 implies j > 0)
-          const int hd = vd ? hd_[k] : NEGS, hp = vp ? hp_[k] : NEGS, e1p = vp ? e1_[k] : NEGS, e2p = vp ? e2_[k] : NEGS;
-          kM = max(kM, hd + (511 - k));
-          kE1 = max(kE1, max(hp - oe1_9 + (511 - 2 * k), e1p - e1_9 + (510 - 2 * k)));
-          kE2 = max(kE2, max(hp - oe2_9 + (511 - 2 * k), e2p - e2_9 + (510 - 2 * k)));
+          kM = maxu16(kM, hd_[k] + cM[k]);
+          kE1 = maxu16(kE1, maxu16(hp_[k] + c1o[k], e1_[k] + c1x[k]));
+          kE2 = maxu16(kE2, maxu16(hp_[k] + c2o[k], e2_[k] + c2x[k]));
         }
         const int qc = (int)((qw_ >> ((jq & 15) * 2)) & 3);
-        const int M9 = (j > 0) ? (kM & ~511) + ((vb == qc) ? mt9 : mm9) : NEGS;
-        const int E1c = kE1 & ~511, E2c = kE2 & ~511;
-        const int k2 = max(max(M9 + 2, E1c + 1), E2c);
-        const int ht9 = k2 & ~511;
-        const unsigned mp = 511u - ((unsigned)kM & 511u), c1 = 511u - ((unsigned)kE1 & 511u), c2 = 511u - ((unsigned)kE2 & 511u);
+        const int M = (kM & ~7) + ((vb == qc) ? mt8 + 2 : mm8 + 2);            // (column 0 has no diagonal: its source is the left pad)
+        const int E1c = kE1 & ~7, E2c = kE2 & ~7;
+        const int k2 = maxu16(maxu16(M, E1c + 1), E2c);
+        const int ht = k2 & ~7;
+        const unsigned mp = 3u - ((unsigned)kM & 3u), c1 = 7u - ((unsigned)kE1 & 7u), c2 = 7u - ((unsigned)kE2 & 7u);
         unsigned d = ((~c1) & 1u) | (((~c2) & 1u) << 1) | (((unsigned)k2 & 3u) << 2);
         const unsigned pby = mp | ((c1 >> 1) << 2) | ((c2 >> 1) << 4);
-        const int htm = act ? ht9 : NEG2S;
-        const int cl1 = le1 + e1_9 * c0, cl2 = le2 + e2_9 * c0;               // e * (column - beg)
+        const int htm = act ? ht : NEG2_16;
+        const int cl1 = le1_8 + e1_8 * c0, cl2 = le2_8 + e2_8 * c0;           // e * (column - beg)
         int s1 = htm + cl1, s2 = htm + cl2, s3 = htm;
         wave_scan_max3(s1, s2, s3);
-        const int px1 = max(wave_shr1(s1, NEG2S), carry1), px2 = max(wave_shr1(s2, NEG2S), carry2);
+        const int px1 = max(wave_shr1(s1, NEG2_16), carry1), px2 = max(wave_shr1(s2, NEG2_16), carry2);
         const int htl = wave_shr1(htm, prev_ht);
-        const int f1 = px1 - o1_9 - cl1, f2 = px2 - o2_9 - cl2;               // column beg: NEG2S - ... (never wins)
+        const int f1 = px1 - o1_8 - cl1, f2 = px2 - o2_8 - cl2;               // column beg: NEG2_16 - ... (never wins)
         if (NCH > 1) { carry1 = max(carry1, wave_bcast(s1, 63)); carry2 = max(carry2, wave_bcast(s2, 63)); prev_ht = wave_bcast(htm, 63); }
-        const int k3 = max(max(ht9 + 2, f1 + 1), f2);
-        const int h9 = k3 & ~511;
+        const int k3 = maxu16(maxu16(ht + 2, f1 + 1), f2);
+        const int h = k3 & ~7;
         d |= (((unsigned)k3 & 3u) << 4);
-        d |= (((unsigned)(htl - oe1_9 - f1)) >> 25) & 64u;                      // f1 > its "open" candidate: extended
-        d |= (((unsigned)(htl - oe2_9 - f2)) >> 24) & 128u;
-        if (ch == 0) { pH = act ? h9 : NEGS; pE1 = act ? E1c : NEGS; pE2 = act ? E2c : NEGS; }
+        d |= (((unsigned)(htl - oe1_8 - f1)) >> 25) & 64u;                      // f1 > its "open" candidate: extended
+        d |= (((unsigned)(htl - oe2_8 - f2)) >> 24) & 128u;
         // unmasked stores (see the fast row); every near row keeps a predecessor byte (type 1), also with one predecessor
         c.D8()[(unsigned)(ro + c0 + lane)] = (uint8_t)d; c.P8()[(unsigned)(ro + c0 + lane)] = (uint8_t)pby;
-        L.H[slot][c0 + lane] = h9; L.E1[slot][c0 + lane] = E1c; L.E2[slot][c0 + lane] = E2c;
-        if (far) { if (act) { c.H()[ro + c0 + lane] = h9; c.E1()[ro + c0 + lane] = E1c; c.E2()[ro + c0 + lane] = E2c; } }
+        cH[ch] = h; cE1[ch] = E1c; cE2[ch] = E2c;
         const int cmx = __builtin_amdgcn_readlane(s3, 63);                      // maximum of Ht over the chunk (== maximum of H)
         const unsigned long long mxm = __ballot(htm == cmx);
         if (NCH == 1 || cmx > best) { best = cmx; left = beg + c0 + __builtin_ctzll(mxm); right = beg + c0 + (63 - __builtin_clzll(mxm)); }
         else if (cmx == best && mxm) right = beg + c0 + (63 - __builtin_clzll(mxm));
       }
+      // the row leaves relative to its own maximum
+      int nb8 = W8;
+      if ((unsigned)(best - RB_LO16) > (unsigned)c.rb_span) {       // rare (see the fast row): the base follows the row maximum, saturating
+        const int m1 = best - BIAS16, fl1 = FLOOR16 + max(m1, 0);
+        nb8 += m1; punt |= (int)(best < GLO16);
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) { cH[ch] = maxu16(cH[ch], fl1) - m1; cE1[ch] = maxu16(cE1[ch], fl1) - m1; cE2[ch] = maxu16(cE2[ch], fl1) - m1; }
+      }
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) {
+        const bool act = 64 * ch + lane < wd;
+        const int vH = maxu16(act ? cH[ch] : NEG16, FLOOR16), vE1 = act ? cE1[ch] : NEG16, vE2 = act ? cE2[ch] : NEG16;
+        gacc = minu16(gacc, vH - (ZHI16 + 1));
+#ifdef C3_DEBUG_PUNT
+        if (vH > ZHI16 && vH < GLO16) { atomicAdd(c.dbg + 11, 1ull); atomicMax(c.dbg + 12, ((unsigned long long)(65535 - vH) << 40) | ((unsigned long long)idx << 16) | ((unsigned long long)lane << 8) | (unsigned long long)(wd & 255)); }
+#endif
+        const int cb = slot * PWT + PADL + 64 * ch + lane;
+        LH[cb] = (unsigned short)vH; LE1[cb] = (unsigned short)vE1; LE2[cb] = (unsigned short)vE2;
+        if (NCH == 1) { LH[cb + 64] = NEG16; LE1[cb + 64] = NEG16; LE2[cb + 64] = NEG16; }
+        if (ch == 0) { pH = vH; pE1 = vE1; pE2 = vE2; }
+        if (far) { if (act) { c.H()[ro + 64 * ch + lane] = cv_16to9(vH, nb8); c.E1()[ro + 64 * ch + lane] = cv_16to9(vE1, nb8); c.E2()[ro + 64 * ch + lane] = cv_16to9(vE2, nb8); } }
+      }
       pv_ok = NCH == 1;
       if (lane == 0) {
-        L.meta[slot] = make_int4(beg, end, left, right);
+        L.meta[slot] = make_int4(beg, end, left, right); L.base8[slot] = nb8;
         int off = 3 * idx; UNI(off);
         int* rm = c.rowm() + off; rm[0] = beg; rm[1] = end | (1 << 28); rm[2] = ro;
         if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
       }
-      u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ro + wd;
+#ifdef C3_EXP_SBAND
+      u_beg = wave_first(beg); u_end = wave_first(end); u_left = wave_first(left); u_right = wave_first(right); u_ncell = wave_first(ro + wd); u_b8 = nb8;
+#else
+      u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ro + wd; u_b8 = nb8;
+#endif
 #ifdef C3_PHASE_PROF
       { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[10] += t_ - row_t0; row_t0 = t_; }
 #endif
       return true;
       };
-      typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 4> I4;
-      bool handled = nin == 1 ? near_body(I1{}, I1{}) : nin == 2 ? near_body(I2{}, I1{}) : near_body(I4{}, I1{});
-      if (!handled) handled = nin == 1 ? near_body(I1{}, I2{}) : nin == 2 ? near_body(I2{}, I2{}) : near_body(I4{}, I2{});
+      typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 3> I3; typedef std::integral_constant<int, 4> I4;
+      bool handled = nin == 1 ? near_body(I1{}, I1{}) : nin == 2 ? near_body(I2{}, I1{}) : nin == 3 ? near_body(I3{}, I1{}) : near_body(I4{}, I1{});
+      if (!handled) handled = nin == 1 ? near_body(I1{}, I2{}) : nin == 2 ? near_body(I2{}, I2{}) : nin == 3 ? near_body(I3{}, I2{}) : near_body(I4{}, I2{});
       if (handled) continue;
     }
-    // ---- GENERAL ROW.  Adaptive band: gather the hints of the predecessors (abPOA scatters them to the successors).  The
-    // ring metadata of the first four predecessors is fetched in ONE LDS round trip (one 16-byte read each, issued
-    // together) and pinned to scalars; predecessors that left the ring (or a fifth, sixth ... one) take global loads.
+    // ---- GENERAL ROW (32-bit cells).  Adaptive band: gather the hints of the predecessors (abPOA scatters them to the
+    // successors).  The ring metadata of the first four predecessors is fetched in ONE LDS round trip (one 16-byte read each,
+    // issued together) and pinned to scalars; predecessors that left the ring (or a fifth, sixth ... one) take global loads.
+    // Ring cells are converted on the way in (16-bit relative -> score*512) and on the way out.
     int beg, end;
     int pb_[4] = {0, 0, 0, 0}, pe_[4] = {-1, -1, -1, -1};          // band of predecessor k (k < 4)
+    int rb8_[4] = {0, 0, 0, 0};                                      // ... the base of its ring row
     bool ring_[4] = {false, false, false, false};                    // ... and whether its cells are in the LDS ring
     if (v == SRC) { beg = 0; end = min(Q, max(qr, 0) + w); }
     else {
       int mplv = INT32_MAX / 2, mprv = 0, minb = INT32_MAX, maxe = INT32_MIN;
-      int4 m_[4];
+      int4 m_[4]; int b8m_[4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) m_[k] = L.meta[(k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3) & (PR - 1)];
+      for (int k = 0; k < 4; ++k) { m_[k] = L.meta[PRED_SLOT(k)]; b8m_[k] = L.base8[PRED_SLOT(k)]; }
       asm volatile("" : "+v"(m_[0].x), "+v"(m_[1].x), "+v"(m_[2].x), "+v"(m_[3].x));     // the LDS loads happen HERE, together
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -459,20 +591,20 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
           const int pi = k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3;
           int b = m_[k].x, e = m_[k].y, l = m_[k].z, r = m_[k].w;
           // (written as an override, not as if/else: a select between an LDS and a global POINTER becomes a flat load)
-          if (idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1] & 0x0fffffff; l = c.mpl()[pi]; r = c.mpr()[pi]; }
+          if (W32 || idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1] & 0x0fffffff; l = c.mpl()[pi]; r = c.mpr()[pi]; }
           b = wave_first(b); e = wave_first(e); l = wave_first(l); r = wave_first(r);
-          pb_[k] = b; pe_[k] = e; ring_[k] = idx - pi < PR && e - b + 1 <= PW;
+          pb_[k] = b; pe_[k] = e; ring_[k] = !W32 && idx - pi < PR && e - b + 1 <= PW; rb8_[k] = wave_first(b8m_[k]);
           minb = min(minb, b); maxe = max(maxe, e + 1);
           if (e >= b) { mplv = min(mplv, l + 1); mprv = max(mprv, r + 1); }
         }
       }
       for (int k = 4; k < nin; ++k) {
         const int pi = PRED_IDX(k);
-        const int sl = pi & (PR - 1);
+        const int sl = pi % PR;
         int4 m = L.meta[sl];
         asm volatile("" : "+v"(m.x), "+v"(m.y), "+v"(m.z), "+v"(m.w));
         int b = m.x, e = m.y, l = m.z, r = m.w;
-        if (idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1] & 0x0fffffff; l = c.mpl()[pi]; r = c.mpr()[pi]; }
+        if (W32 || idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1] & 0x0fffffff; l = c.mpl()[pi]; r = c.mpr()[pi]; }
         minb = min(minb, b); maxe = max(maxe, e + 1);
         if (e >= b) { mplv = min(mplv, l + 1); mprv = max(mprv, r + 1); }
       }
@@ -486,15 +618,16 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     if (end < beg) end = beg - 1;
     const int wd = end - beg + 1;
     if (ncell + wd > c.cells_cap) return -4;
-    const int slot = idx & (PR - 1);
-    const bool inl = wd <= PW, toglobal = far || !inl;             // wd is scalar (beg / end pinned above)
+    const bool inl = !W32 && wd <= PW, toglobal = far || !inl;     // wd is scalar (beg / end pinned above)
     const int ro = ncell;
     const int ty = ovf ? 2 : (nin >= 2 ? 1 : 0);                   // cell format: byte / byte + predecessor byte / 32-bit word
     ncell += wd;
     int best = INT32_MIN, bl = 0, br = 0;        // per-lane running row maximum
     int carry1 = NEG2S, carry2 = NEG2S;          // scan carries over previous chunks
     int prev_ht = NEGS;
-    int gH = NEGS, gE1 = NEGS, gE2 = NEGS;       // the row's cells (first chunk) for a fast successor
+    int gH = NEG16, gE1 = NEG16, gE2 = NEG16;    // the row's 16-bit cells (first chunk) for a fast successor
+    int Wg = 0;                                  // the base its ring cells are kept against: the maximum of its first chunk
+    int bad = 0;
     for (int c0 = 0; c0 < wd; c0 += 64) {
       const int j = beg + c0 + lane;
       const bool act = j <= end;
@@ -506,10 +639,10 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         int hd_[4], hp_[4], e1_[4], e2_[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-          const int sl = (k == 0 ? p0 : k == 1 ? p1 : k == 2 ? p2 : p3) & (PR - 1);
+          const int sl = PRED_SLOT(k);
           const int o = j - pb_[k];
-          const int oc = min(max(o, 0), PW - 1), om = min(max(o - 1, 0), PW - 1);
-          hd_[k] = L.H[sl][om]; hp_[k] = L.H[sl][oc]; e1_[k] = L.E1[sl][oc]; e2_[k] = L.E2[sl][oc];
+          const int oc = sl * PWT + PADL + min(max(o, 0), PW - 1), om = sl * PWT + PADL + min(max(o - 1, 0), PW - 1);
+          hd_[k] = LH[om]; hp_[k] = LH[oc]; e1_[k] = LE1[oc]; e2_[k] = LE2[oc];
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -519,7 +652,8 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
             const bool vd = j > 0 && j - 1 >= b && j - 1 <= e, vp = j >= b && j <= e;
             int hd = NEGS, hp = NEGS, e1p = NEGS, e2p = NEGS;
             if (ring_[k]) {
-              hd = vd ? hd_[k] : NEGS; hp = vp ? hp_[k] : NEGS; e1p = vp ? e1_[k] : NEGS; e2p = vp ? e2_[k] : NEGS;
+              hd = vd ? cv_16to9(hd_[k], rb8_[k]) : NEGS; hp = vp ? cv_16to9(hp_[k], rb8_[k]) : NEGS;
+              e1p = vp ? cv_16to9(e1_[k], rb8_[k]) : NEGS; e2p = vp ? cv_16to9(e2_[k], rb8_[k]) : NEGS;
             } else {
               const int po = c.rowm()[3 * pi + 2];
               if (vd) hd = c.H()[po + (j - 1 - b)];
@@ -533,14 +667,14 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         for (int k = 4; k < nin; ++k) {
           const int pi = PRED_IDX(k);
           int hd = NEGS, hp = NEGS, e1p = NEGS, e2p = NEGS;
-          const int sl = pi & (PR - 1);
-          int4 m = L.meta[sl];
-          asm volatile("" : "+v"(m.x), "+v"(m.y));
+          const int sl = pi % PR;
+          int4 m = L.meta[sl]; int pb8 = L.base8[sl];
+          asm volatile("" : "+v"(m.x), "+v"(m.y), "+v"(pb8));
           int b = m.x, e = m.y;
-          if (idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1] & 0x0fffffff; }
-          if (idx - pi < PR && e - b + 1 <= PW) {
-            if (j > 0 && j - 1 >= b && j - 1 <= e) hd = L.H[sl][j - 1 - b];
-            if (j >= b && j <= e) { hp = L.H[sl][j - b]; e1p = L.E1[sl][j - b]; e2p = L.E2[sl][j - b]; }
+          if (W32 || idx - pi >= PR) { b = c.rowm()[3 * pi]; e = c.rowm()[3 * pi + 1] & 0x0fffffff; }
+          if (!W32 && idx - pi < PR && e - b + 1 <= PW) {
+            if (j > 0 && j - 1 >= b && j - 1 <= e) hd = cv_16to9(LH[sl * PWT + PADL + j - 1 - b], pb8);
+            if (j >= b && j <= e) { hp = cv_16to9(LH[sl * PWT + PADL + j - b], pb8); e1p = cv_16to9(LE1[sl * PWT + PADL + j - b], pb8); e2p = cv_16to9(LE2[sl * PWT + PADL + j - b], pb8); }
           } else {
             const int po = c.rowm()[3 * pi + 2];
             if (j > 0 && j - 1 >= b && j - 1 <= e) hd = c.H()[po + (j - 1 - b)];
@@ -580,36 +714,52 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       const int h9 = k3 & ~511;
       d |= (((unsigned)k3 & 3u) << 4) | (f1x << 6) | (f2x << 7);
       dw |= ((unsigned)(2 - (k3 & 3)) << 28) | (f1x << 30) | (f2x << 31);
-      if (c0 == 0) { gH = act ? h9 : NEGS; gE1 = act ? E1v : NEGS; gE2 = act ? E2v : NEGS; }
+      // row maximum == maximum of Ht, attained in the same columns (see the fast row)
+      const int cmx = wave_bcast(s3, 63);
+      // base of the row's ring cells: the running base (that of the row before it in the order) -- a general row between rows
+      // that share a base must not start a new one, or every row next to it sees predecessors on different bases and turns
+      // general too; only when its own maximum does not fit that base does it take the maximum (as the other rows do)
+      if (c0 == 0) { Wg = u_b8; const int r_ = (cmx >> 6) - Wg + BIAS16; if (cmx > NEGS / 2 && (unsigned)(r_ - RB_LO16) > (unsigned)c.rb_span) Wg = cmx >> 6; }
       if (act) {
         const int ci = c0 + lane;
         if (ty == 2) c.D()[ro + ci] = dw;
         else { c.D8()[(unsigned)(ro + ci)] = (uint8_t)d; if (ty == 1) c.P8()[(unsigned)(ro + ci)] = (uint8_t)pby; }
-        if (inl) { L.H[slot][ci] = h9; L.E1[slot][ci] = E1v; L.E2[slot][ci] = E2v; }
         if (toglobal) { c.H()[ro + ci] = h9; c.E1()[ro + ci] = E1v; c.E2()[ro + ci] = E2v; }
       }
-      // row maximum == maximum of Ht, attained in the same columns (see the fast row)
-      const int cmx = wave_bcast(s3, 63);
+      if (inl) {
+        // ring cells: 16 bits against the base Wg; idle lanes unreachable (every lane stores)
+        const int vH = act ? cv_9to16(h9, Wg, bad) : NEG16, vE1 = act ? cv_9to16(E1v, Wg, bad) : NEG16, vE2 = act ? cv_9to16(E2v, Wg, bad) : NEG16;
+        const int cb = slot * PWT + PADL + c0 + lane;
+        LH[cb] = (unsigned short)vH; LE1[cb] = (unsigned short)vE1; LE2[cb] = (unsigned short)vE2;
+        if (wd <= 64) { LH[cb + 64] = NEG16; LE1[cb + 64] = NEG16; LE2[cb + 64] = NEG16; }
+        if (c0 == 0) { gH = vH; gE1 = vE1; gE2 = vE2; }
+      }
       if (cmx > best) { best = cmx; const unsigned long long mm = __ballot(htm == cmx); bl = beg + c0 + __builtin_ctzll(mm); br = beg + c0 + 63 - __builtin_clzll(mm); }
       else if (cmx == best) { const unsigned long long mm = __ballot(htm == cmx); if (mm) br = beg + c0 + 63 - __builtin_clzll(mm); }
     }
+    if (!W32 && __builtin_amdgcn_ballot_w64(bad != 0) != 0) punt |= 2;
     // leftmost / rightmost argmax -> band hints read by the successors
     const int left = wd > 0 ? bl : 0, right = wd > 0 ? br : 0;
     if (lane == 0) {
-      L.meta[slot] = make_int4(beg, end, left, right);
+      L.meta[slot] = make_int4(beg, end, left, right); L.base8[slot] = Wg;
       { int* rm = c.rowm() + 3 * idx; rm[0] = beg; rm[1] = end | (ty << 28); rm[2] = ro; }
       if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
     }
-    u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ncell;
+    u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ncell; u_b8 = Wg;
 #ifdef C3_PHASE_PROF
     { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[11] += t_ - row_t0; row_t0 = t_; }
 #endif
-    pH = gH; pE1 = gE1; pE2 = gE2; pv_ok = wd <= 64;
+    pH = gH; pE1 = gE1; pE2 = gE2; pv_ok = inl && wd <= 64;
   }
   }
   WSYNC();
   *cells += wave_first(u_ncell);
   PH_MARK(1)
+  // a read with a value outside what the 16-bit cells represent exactly goes to the 32-bit pass (never seen on the config shapes)
+#ifdef C3_DEBUG_PUNT
+  if (!W32 && lane == 0) { if (punt) atomicAdd(c.dbg + 14, 1ull); if (__builtin_amdgcn_ballot_w64((unsigned)(gacc & 0xffff) < (unsigned)(GLO16 - ZHI16 - 1)) != 0) atomicAdd(c.dbg + 15, 1ull); }
+#endif
+  if (!W32 && (punt != 0 || __builtin_amdgcn_ballot_w64((unsigned)(gacc & 0xffff) < (unsigned)(GLO16 - ZHI16 - 1)) != 0)) return -5;
   // ---- end cell: best predecessor of the sink at column Q (first maximum in in-edge order)
   int bi = -1, bs = INT32_MIN;
   for (int k = 0; k < c.n_in()[SNK]; ++k) {
@@ -631,7 +781,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   int rc = 0;
   {
     uint8_t* WD = (uint8_t*)&L.H[0][0];          // [64][32] direction-byte windows
-    uint8_t* WP = (uint8_t*)&L.E1[0][0];         // [64][32] predecessor-byte windows
+    uint8_t* WP = WD + 64 * 32;                  // [64][32] predecessor-byte windows (the three rings are contiguous: 4.7 KB)
     int i = bi, j = Q, st = 0;   // st: 0 H, 1 Ht, 2 E1, 3 E2, 4 F1, 5 F2
     while (!(i == 0 && j == 0) && rc == 0) {
       const int it = i, jt = j;
@@ -726,6 +876,16 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   PH_MARK(2)
   return rc;
 }
+#undef mt9
+#undef mm9
+#undef e1_9
+#undef e2_9
+#undef o1_9
+#undef o2_9
+#undef oe1_9
+#undef oe2_9
+#undef le1
+#undef le2
 
 // fuse the aligned subread into the graph, parallel over its bases: vq[q] = graph row node aligned to
 // base q (-1 = insertion).  Every graph node is touched by at most one base, so targets, new-node
@@ -779,7 +939,7 @@ __device__ int poa_fuse(Ctx& c, bool first, int qb, int Q, int* path, int lane P
   WSYNC();
   c.n = nn;
   PH_MARK(3)
-  g_reorder(c, n_old, lane, &L.H[0][0], 3 * PR * PW);      // H, E1, E2 rings are contiguous and idle after the traceback
+  g_reorder(c, n_old, lane, (int*)&L.H[0][0], POA_LDS_INTS);      // H, E1, E2 rings are contiguous and idle after the traceback
   PH_MARK(4)
   return 0;
 }
@@ -836,7 +996,13 @@ extern "C" void c3k_launch_pairwise(const uint8_t* rows, int ncol, const uint8_t
 // 6 waves/SIMD (80 VGPRs, 26 spilled outside the row loop) with a 4-row LDS ring (6.7 KB per wave, 24 waves per CU):
 // 59.4 ms per 32768 cfg2 reads against 67.8 ms at 4 waves/SIMD with the 8-row ring -- the row loop is a dependent
 // chain (scan -> next row), so resident waves are what hides its latency.
-__global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
+// W32 = false: the first pass (16-bit ring, fast / near rows); W32 = true: the second pass for reads whose scratch overflowed the
+// typical size or whose scores left the 16-bit range -- 32-bit general rows only
+#ifndef C3_POA_WAVES
+#define C3_POA_WAVES 6
+#endif
+template <bool W32, bool DEF>
+__global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
   const int lane = wave_lane();
   const int slot = blockIdx.x;
   Ctx c;
@@ -844,7 +1010,10 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
   c.I = a.ibase + (size_t)slot * C3_POA_NI * N; c.path_ = a.pbase + (size_t)slot * a.Pcap; c.E = a.ebase + (size_t)slot * 3 * N * a.K;
   c.C = a.cellsb + (size_t)slot * 18 * (size_t)a.cells_cap; c.B8 = a.bbase + (size_t)slot * 5 * N;
   c.score_ = a.score + (size_t)slot * N; c.desc_ = a.desc + (size_t)slot * 2 * N; c.jump_ = a.jump + (size_t)slot * C3_JUMP_LEVELS * N;
-  c.K = a.K; c.Ncap = a.Ncap; c.cells_cap = a.cells_cap; c.osel = 0;
+  c.K = a.K; c.Ncap = a.Ncap; c.cells_cap = a.cells_cap; c.osel = 0; c.rb_span = a.rb_span > 0 ? a.rb_span : RB_HI16 - RB_LO16;
+#ifdef C3_DEBUG_PUNT
+  c.dbg = a.phases;
+#endif
   PH_DECL
 
   for (;;) {
@@ -861,7 +1030,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
     int32_t* tpos = a.tpos + off;
     const uint8_t* qual = a.b.qual + off;
     long long cells = 0;
-    int C = 0, fail = 0;
+    int C = 0, fail = 0; bool punted = false;
     if (ns == 1) {
       const int qb = info->sub_beg[0]; C = info->sub_end[0] - qb;
       for (int k = lane; k < C; k += 64) { draft[k] = (uint8_t)c3_code_at(c.pk, qb + k); tpos[qb + k] = k; }
@@ -878,7 +1047,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
       int poff = 0;
       for (int s = 0; s < ns && !fail; ++s) {
         const int qb = wave_first(info->sub_beg[s]), Q = wave_first(info->sub_end[s]) - qb;
-        if (s > 0) { const int rc = poa_align(c, a.p, qb, Q, lane, &cells PHP); if (rc < 0) { fail = rc == -4 ? 2 : 1; break; } }
+        if (s > 0) { const int rc = poa_align<W32, DEF>(c, a.p, qb, Q, lane, &cells PHP); if (rc < 0) { fail = (rc == -4 || rc == -5) ? 2 : 1; punted = rc == -5; break; } }
         if (poa_fuse(c, s == 0, qb, Q, c.path() + poff, lane PHP) < 0) { fail = 2; break; }                 // node capacity
         poff += Q;
       }
@@ -1045,7 +1214,7 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
     // TYPICAL alignment (more resident waves); such reads are queued and redone by a second launch with worst-case scratch
     const bool redo = fail == 2 && a.overflow != nullptr;
     if (lane == 0) {
-      if (redo) a.overflow[atomicAdd(a.counter + 4, 1)] = rid;
+      if (redo) { a.overflow[atomicAdd(a.counter + 4, 1)] = rid; if (punted) atomicAdd(a.counter + 5, 1); }
       else {
         info->draft_len = C;
         if (fail) { info->status = C3_ST_LIMIT; info->draft_len = 0; }
@@ -1058,6 +1227,9 @@ __global__ __launch_bounds__(64, 6) void k_poa(PoaArgs a) {
   PH_FLUSH(a.phases)
 }
 
-extern "C" void c3k_launch_poa(const PoaArgs* a, int slots, hipStream_t stream) {
-  hipLaunchKernelGGL(k_poa, dim3(slots), dim3(64), 0, stream, *a);
+extern "C" void c3k_launch_poa(const PoaArgs* a, int slots, int wide32, hipStream_t stream) {
+  const C3Params& p = a->p;
+  const bool def = p.poa_match == 5 && p.poa_mismatch == 4 && p.o1 == 4 && p.e1 == 2 && p.o2 == 24 && p.e2 == 1;
+  if (wide32) { if (def) hipLaunchKernelGGL((k_poa<true, true>), dim3(slots), dim3(64), 0, stream, *a); else hipLaunchKernelGGL((k_poa<true, false>), dim3(slots), dim3(64), 0, stream, *a); }
+  else { if (def) hipLaunchKernelGGL((k_poa<false, true>), dim3(slots), dim3(64), 0, stream, *a); else hipLaunchKernelGGL((k_poa<false, false>), dim3(slots), dim3(64), 0, stream, *a); }
 }

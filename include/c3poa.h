@@ -90,6 +90,7 @@ typedef struct {
   int64_t n_band_layers, n_band_fallback;   /* window layers aligned in a band and accepted / redone unbanded after a failed certificate */
   int64_t n_band_mismatch;                  /* C3_DEBUG_BAND=verify only: accepted band layers whose traceback differs from the full matrix's (must be 0) */
   int64_t n_win_redo;                       /* windows with a layer beyond the first launch's DP scratch, redone by the full-size second launch of k_window */
+  int64_t n_poa_redo16;                     /* of n_poa_redo: reads handed to the 32-bit second POA pass because a score did not fit the 16-bit cells of the first (0 on the config shapes) */
 } c3_timing;
 
 typedef struct c3_handle c3_handle;
