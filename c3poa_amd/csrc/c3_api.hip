@@ -16,7 +16,7 @@ extern "C" void c3k_launch_pairwise(const uint8_t*, int, const uint8_t*, int, co
 extern "C" void c3k_launch_match_index(const char*, const int*, int, int, const char*, const long long*, int*, hipStream_t);
 extern "C" void c3k_launch_peaks(const PeaksArgs*, int, hipStream_t);
 extern "C" int c3k_peaks_blocks_per_cu(void);
-extern "C" void c3k_launch_poa(const PoaArgs*, int, int, hipStream_t);
+extern "C" void c3k_launch_poa(const PoaArgs*, int, int, int, hipStream_t);
 extern "C" void c3k_launch_prep(const PrepArgs*, int, hipStream_t);
 extern "C" void c3k_launch_window(const WinArgs*, int, hipStream_t);
 extern "C" void c3k_launch_stitch(const StitchArgs*, int, hipStream_t);
@@ -560,14 +560,19 @@ static int fetch_summary(c3_handle* h) {
 }
 
 // one launch of k_poa over `nw` reads of `d_work` with the given capacities
-static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, int Pcap, long long cells, int* d_overflow, int waves_per_cu) {
+static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, int Pcap, long long cells, int* d_overflow, int waves_per_cu, int wide_ring) {
   const size_t N = (size_t)Ncap;
-  const int NI = 18;      // int arrays of N (c3_args.h)
-  cells = (cells + 15) & ~15LL;                   // every per-slot arena (18 bytes per cell) starts 16-byte aligned
-  const size_t per_slot = N * (NI * 4 + 8 + 5 + 32 + 4 * C3_JUMP_LEVELS) + N * K * 12 + (size_t)cells * 18 + (size_t)Pcap * 4;
+  const int NI = 19;      // int arrays of N (c3_args.h)
+  cells = (cells + 15) & ~15LL;                   // every per-slot arena starts 16-byte aligned
+  cells = (cells + 63) & ~63LL;
+  // far arena (32-bit cells of rows with a successor beyond the LDS ring, rows wider than a ring slot, rows with > 4 predecessors):
+  // a quarter of the cells in the first pass (a few per cent are used), all of them in the 32-bit pass, where every row is far
+  const bool w32 = d_overflow == nullptr || getenv("C3_DEBUG_POA32");
+  const long long far = w32 ? cells : cells >> 2;
+  const size_t per_slot = N * (NI * 4 + 8 + 5 + 32 + 4 * C3_JUMP_LEVELS) + N * K * 12 + (size_t)cells * 2 + (size_t)far * 16 + (size_t)Pcap * 4;
   const int slots = auto_slots(h, h->cfg.slots_poa, per_slot, nw, waves_per_cu);
   HIPCHK(h->s_poa_i.ensure(sizeof(int) * N * NI * slots)); HIPCHK(h->s_poa_nk.ensure(sizeof(int) * N * K * 3 * slots));
-  HIPCHK(h->s_poa_cells.ensure((size_t)cells * 18 * slots + 256)); HIPCHK(h->s_poa_b.ensure(N * 5 * slots)); HIPCHK(h->s_poa_sc.ensure(sizeof(long long) * N * slots));
+  HIPCHK(h->s_poa_cells.ensure(((size_t)cells * 2 + (size_t)far * 16) * slots + 256)); HIPCHK(h->s_poa_b.ensure(N * 5 * slots)); HIPCHK(h->s_poa_sc.ensure(sizeof(long long) * N * slots));
   HIPCHK(h->s_poa_desc.ensure(sizeof(uint4) * 2 * N * slots));
   HIPCHK(h->s_poa_jump.ensure(sizeof(int) * C3_JUMP_LEVELS * N * slots));
   HIPCHK(h->s_poa_path.ensure(sizeof(int) * (size_t)Pcap * slots));
@@ -585,7 +590,7 @@ static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, 
   a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
   DBG("poa: nw=%d Ncap=%d K=%d cells=%lld slots=%d (%.1f MB per slot)%s\n", nw, Ncap, K, cells, slots, per_slot / 1048576.0, d_overflow ? "" : " [full-size pass]");
   // the pass with an overflow list runs the 16-bit rows; the final pass (no list) the 32-bit rows only (C3_DEBUG_POA32: test hook, first pass too)
-  c3k_launch_poa(&a, slots, (d_overflow == nullptr || getenv("C3_DEBUG_POA32")) ? 1 : 0, h->stream);
+  c3k_launch_poa(&a, slots, w32 ? 1 : 0, wide_ring, h->stream);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -625,7 +630,12 @@ static int run_poa(c3_handle* h) {
   HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));                       // work queue only: [2..3] already holds the zero-repeat cells
   HIPCHK(hipMemsetAsync(h->d_counter.as<char>() + 16, 0, 240, h->stream));       // [4] overflow count, phase counters
   const bool two_pass = true;          // (always: a read whose scores leave the 16-bit cells of the first pass is redone by the second, 32-bit one)
-  int rc = launch_poa(h, h->d_work.as<int>(), nw, Ncap, K, Pcap, cells, two_pass ? h->d_overflow.as<int>() : nullptr, 24);
+  // ring geometry of the first pass: subreads beyond the LDS query copy (1792 bases) or with bands beyond two 64-column chunks
+  // (w = band_b + band_f * Q; a row holds 2w+1 columns + the drift of its predecessors' maxima) take the WIDE instance
+  // (4 ring rows of 192 cells, sliding query window); C3_DEBUG_POA_WIDE = 0 / 1 forces one (test hook)
+  int wide_ring = (max_q > 1792 || 2 * w + 1 + 24 > 128) ? 1 : 0;
+  if (const char* e_ = getenv("C3_DEBUG_POA_WIDE")) wide_ring = atoi(e_) ? 1 : 0;
+  int rc = launch_poa(h, h->d_work.as<int>(), nw, Ncap, K, Pcap, cells, two_pass ? h->d_overflow.as<int>() : nullptr, 24, wide_ring);
   if (rc) return rc;
   h->n_poa_redo = 0; h->n_poa_redo16 = 0;
   if (two_pass) {
@@ -635,7 +645,7 @@ static int run_poa(c3_handle* h) {
     if (cnt[4] > 0) {
       h->n_poa_redo = cnt[4]; h->n_poa_redo16 = cnt[5];
       HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
-      if ((rc = launch_poa(h, h->d_overflow.as<int>(), cnt[4], Ncap_full, K, Pcap, cells_full, nullptr, 24))) return rc;
+      if ((rc = launch_poa(h, h->d_overflow.as<int>(), cnt[4], Ncap_full, K, Pcap, cells_full, nullptr, 24, 0))) return rc;
     }
   }
   if (!h->zwork.empty()) {             // zero-repeat rescue, second half: stitch left + overlap consensus + right

@@ -15,8 +15,8 @@ struct PeaksArgs {
 struct PoaArgs {
   C3Batch b; C3Info* info; C3Params p; int* counter; const int* work; int n_work;
   // per-slot scratch, one block per kind (the kernel derives every array from these bases: few live SGPRs):
-  //   ibase: 18*Ncap ints  (n_in n_out grp order order2 index gfirst glast rem mpl mpr rowm[3N] anchor col col2t nxt)
-  //   ebase: 3*Ncap*K ints (in_from out_to out_w);  cellsb: 18*cells_cap bytes (H E1 E2, 32-bit cells D, direction bytes D8, predecessor bytes P8);  bbase: 5*Ncap bytes (base rows2[4N])
+  //   ibase: 19*Ncap ints  (n_in n_out grp order order2 index gfirst glast rem mpl mpr rowm[3N] anchor col col2t nxt foff)
+  //   ebase: 3*Ncap*K ints (in_from out_to out_w);  cellsb: 2*cells_cap bytes (direction bytes D8, predecessor bytes P8) + 16 * (cells_cap >> 2) bytes (first pass; >> 0 in the 32-bit pass) of 32-bit cells H E1 E2 D for the few rows that keep them;  bbase: 5*Ncap bytes (base rows2[4N])
   int* ibase; int* ebase; char* cellsb; uint8_t* bbase; long long* score;
   int Ncap, K, Pcap, cells_cap;
   uint8_t* draft; int32_t* tpos; uint8_t* msa_dbg; const int64_t* msa_off; int* msa_len;

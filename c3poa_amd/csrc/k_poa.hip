@@ -19,7 +19,7 @@
 // adjacency slot k of node v.  Slot-major (all first edges, then all second edges, ...): nearly every node has one or two
 // edges, so the arrays a wave actually touches are contiguous runs of Ncap ints instead of one 64-byte line per node
 #define EI(v, k) ((size_t)(k) * (size_t)c.Ncap + (size_t)(v))
-#define C3_POA_NI 18       // int arrays of Ncap per slot in Ctx::I
+#define C3_POA_NI 19       // int arrays of Ncap per slot in Ctx::I
 #define SRC 0
 #define SNK 1
 
@@ -29,6 +29,7 @@
 struct Ctx {
   int* I; int* E; char* C; uint8_t* B8; long long* score_; uint4* desc_; int* jump_; int* path_;
   int K, n, Ncap, cells_cap;
+  int far_shift;             // far arena (32-bit H, E1, E2, direction words of the FEW rows that keep them): cells_cap >> far_shift cells, behind the byte cells
   int osel;                  // which of the two order buffers is current (g_reorder writes the other one and flips)
   int rb_span;               // RB_HI16 - RB_LO16 (smaller under the C3_DEBUG_POA_RBSPAN test hook: the base moves every few rows)
   const uint32_t* pk;        // packed read
@@ -38,19 +39,23 @@ struct Ctx {
 #define CTX_I(name, k) __device__ __forceinline__ int* name() const { return I + (size_t)(k) * Ncap; }
   CTX_I(n_in, 0) CTX_I(n_out, 1) CTX_I(grp, 2) CTX_I(index, 5) CTX_I(gfirst, 6) CTX_I(glast, 7)
   CTX_I(rem, 8) CTX_I(mpl, 9) CTX_I(mpr, 10) CTX_I(rowm, 11) /* 3 ints per row: band begin, band end, cell offset (blocks 11..13) */ CTX_I(anchor, 14) CTX_I(col, 15)
-  CTX_I(col2t, 16) CTX_I(nxt, 17)
+  CTX_I(col2t, 16) CTX_I(nxt, 17) CTX_I(foff, 18) /* per row: offset of its cells in the far arena (far / wide / many-predecessor rows only) */
 #undef CTX_I
   __device__ __forceinline__ int* order() const { return I + (size_t)(3 + osel) * Ncap; }
   __device__ __forceinline__ int* order2() const { return I + (size_t)(4 - osel) * Ncap; }
   __device__ __forceinline__ int* in_from() const { return E; }
   __device__ __forceinline__ int* out_to() const { return E + (size_t)Ncap * K; }
   __device__ __forceinline__ int* out_w() const { return E + 2 * (size_t)Ncap * K; }
-  __device__ __forceinline__ int32_t* H() const { return (int32_t*)C; }
-  __device__ __forceinline__ int32_t* E1() const { return (int32_t*)(C + 4 * (size_t)cells_cap); }
-  __device__ __forceinline__ int32_t* E2() const { return (int32_t*)(C + 8 * (size_t)cells_cap); }
-  __device__ __forceinline__ uint32_t* D() const { return (uint32_t*)(C + 12 * (size_t)cells_cap); }
-  __device__ __forceinline__ uint8_t* D8() const { return (uint8_t*)(C + 16 * (size_t)cells_cap); }     // direction bytes (rows of <= 4 predecessors)
-  __device__ __forceinline__ uint8_t* P8() const { return (uint8_t*)(C + 17 * (size_t)cells_cap); }     // predecessor bytes (rows of 2..4 predecessors)
+  // 32-bit cells: only rows with a successor beyond the LDS ring (or the sink), rows wider than a ring slot and rows with more than
+  // four predecessors keep them -- a few per cent of the cells; they have an arena and a cell counter of their own (round 4: the
+  // arena used to reserve 16 bytes for EVERY cell, 42 of 44 MB per slot with 6 kb subreads, and the slots no longer fitted)
+  __device__ __forceinline__ int far_cap() const { return cells_cap >> far_shift; }
+  __device__ __forceinline__ int32_t* H() const { return (int32_t*)(C + 2 * (size_t)cells_cap); }
+  __device__ __forceinline__ int32_t* E1() const { return (int32_t*)(C + 2 * (size_t)cells_cap + 4 * (size_t)far_cap()); }
+  __device__ __forceinline__ int32_t* E2() const { return (int32_t*)(C + 2 * (size_t)cells_cap + 8 * (size_t)far_cap()); }
+  __device__ __forceinline__ uint32_t* D() const { return (uint32_t*)(C + 2 * (size_t)cells_cap + 12 * (size_t)far_cap()); }
+  __device__ __forceinline__ uint8_t* D8() const { return (uint8_t*)C; }                                 // direction bytes (rows of <= 4 predecessors)
+  __device__ __forceinline__ uint8_t* P8() const { return (uint8_t*)(C + (size_t)cells_cap); }           // predecessor bytes (rows of 2..4 predecessors)
   __device__ __forceinline__ uint8_t* base() const { return B8; }
   __device__ __forceinline__ uint8_t* rows2() const { return B8 + (size_t)Ncap; }
   __device__ __forceinline__ long long* score() const { return score_; }
@@ -158,15 +163,30 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 #ifndef C3_NEAR
 #define C3_NEAR 1
 #endif
-#define PW 128      // ring slot width (cells): two chunks of 64
-#define PR 6        // ring rows (a predecessor up to 5 rows back is read from LDS: 99.7 % of them at cfg4)
+// Ring geometry, two instances of the kernel (same LDS footprint): NARROW = 6 rows of 128 cells (two chunks of 64; a predecessor
+// up to 5 rows back is read from LDS: 99.7 % of them at cfg4) for subreads up to 1792 bases, whose bands stay below 128 columns,
+// with the whole packed subread in LDS; WIDE = 3 rows of 256 cells (up to four chunks) with a SLIDING query window of 960
+// bases for longer subreads (w = 10 + Q/100: a 6 kb insert has bands of 145-250 columns; its graphs hold 3-5 subreads, so a
+// predecessor is rarely more than two rows back).  The LDS footprint decides the kernel's speed beyond what the wave count
+// explains (measured: 5.6 KB per wave 37.2 ms, 6.6 KB 39.5 ms per 32 768 cfg2 reads, 24 waves per CU fitting both ways), so
+// the WIDE geometry is cut to what the NARROW one needs anyway.
 #define PADL 3      // unreachable cells on both sides of a ring row
 #define PADR 3
-#define PWT (PADL + PW + PADR)
-#define PQW 112     // packed query words kept in LDS (1792 bases); longer subreads read the packed read
-struct PoaLds { unsigned short H[PR][PWT], E1[PR][PWT], E2[PR][PWT]; int4 meta[PR] /* band begin, end, leftmost / rightmost argmax */; int base8[8] /* absolute base * 8 of the row */; unsigned qpk[PQW]; };
+#ifndef C3_NARROW_PR
+#define C3_NARROW_PR 6
+#endif
+#define RING_CELLS_N (C3_NARROW_PR * (PADL + 128 + PADR))      // 804
+#ifndef C3_WIDE_PW
+#define C3_WIDE_PW 256
+#endif
+#define RING_CELLS_W (3 * (PADL + C3_WIDE_PW + PADR))      // 786
+#define PQW_N 112   // NARROW: packed query words in LDS (1792 bases = the whole subread); they sit behind its (smaller) rings
+#define PQW_W 60    // WIDE: a window of 960 bases that follows the band (60 words: the struct is 6656 bytes = 13 LDS granules of 512, 24 waves per CU)
+struct PoaLds { unsigned short ring[3 * (RING_CELLS_W > RING_CELLS_N + PQW_N * 2 / 3 + 2 ? RING_CELLS_W : RING_CELLS_N + PQW_N * 2 / 3 + 2)]; int4 meta[6] /* band begin, end, leftmost / rightmost argmax */; int base8[8] /* absolute base * 8 of the row */; unsigned qpk[PQW_W]; };
 __shared__ PoaLds L;     // file scope: accesses stay in the LDS address space (ds_*, lgkmcnt only)
-#define POA_LDS_INTS ((int)(3 * PR * PWT * sizeof(unsigned short) / sizeof(int)))      // the three rings as scratch of the graph phases
+static_assert(sizeof(PoaLds) <= 6656, "24 waves per CU need <= 13 LDS granules of 512 bytes per wave");
+static_assert(3 * RING_CELLS_N * 2 + PQW_N * 4 <= sizeof(L.ring), "the NARROW query copy must fit behind the NARROW rings");
+#define POA_LDS_INTS ((int)(3 * RING_CELLS_N * sizeof(unsigned short) / sizeof(int)))      // ring bytes used as scratch by the graph phases (the smaller geometry's: 4.7 KB)
 
 // general rows (and the global arena): scores are carried as score*512 (+ a 9-bit tag while candidates compete): one v_max per
 // candidate implements "highest score, first candidate in order".  Unreachable cells use -(2^20) score units.
@@ -178,12 +198,13 @@ __shared__ PoaLds L;     // file scope: accesses stay in the LDS address space (
 #define BIAS16 32768
 #define NEG16 6000          // unreachable
 #define NEG2_16 2000        // "no left neighbour" of the horizontal states / idle lanes of the scans
-#define FLOOR16 5000        // stored H never sinks below this (a chain of unreachable cells loses ~9 a row to the rebasing)
+#define FLOOR16 5000        // stored H never sinks below this (a chain of mismatching unreachable cells loses 4 a row)
 #define ZHI16 12000         // a stored H up to here is unreachable ...
-#define GLO16 24864         // ... from here on reachable (990 score units below the row maximum); in between: not representable
-#define ZLO16 20768         // conversion threshold between the two (E1 / E2 sit up to 25 units below an H)
-#define RB_LO16 (BIAS16 - 400 * 8)   // a row whose maximum leaves [RB_LO16, RB_HI16] moves its base to the maximum (about every 300 rows: the
-#define RB_HI16 (BIAS16 + 1600 * 8)  // score grows by at most 5 a row); all other rows keep the base of the row before them
+#define GLO16 14400         // ... from here on reachable; in between: not representable
+#define ZLO16 13200         // conversion threshold between the two (E1 / E2 sit up to 25 units below an H)
+#define RB_LO16 (BIAS16 - 400 * 8)   // a row whose maximum leaves [RB_LO16, RB_HI16] moves its base to the maximum (about every 600 rows: the
+#define RB_HI16 (BIAS16 + 3000 * 8)  // score grows by at most 5 a row); all other rows keep the base of the row before them.  A reachable
+                                     // cell may sit (RB_LO16 - GLO16) / 8 = 1896 units below its row maximum (measured: 391 at cfg2-cfg4, 760 with 6 kb inserts)
 // (volatile: hipcc sinks a plain asm that feeds one arm of a select into an EXEC-masked branch -- two scalar branches per row)
 #ifdef C3_EXP_ASMNV
 #define C3_ASMV
@@ -196,7 +217,7 @@ __device__ __forceinline__ int cv_16to9(int v, int b8) { return v >= ZLO16 ? (in
 __device__ __forceinline__ int cv_9to16(int x9, int b8, int& bad) {
   if (x9 <= NEGS / 2) return NEG16;
   const int r = (x9 >> 6) - b8 + BIAS16;
-  if (r < GLO16 - 4096 || r > 60000) bad = 1;
+  if (r < GLO16 || r > 62000) bad = 1;
   return r;
 }
 
@@ -211,7 +232,7 @@ __device__ __forceinline__ int cv_9to16(int x9, int b8, int& bad) {
 // over four node arrays in memory by four dependent memory levels per chunk.
 // descriptor A: x = node, y = ring slots (position mod PR) of the first four predecessors, 4 bits each, z = base | nin<<8 | far<<16 | (nin>4)<<17 | fast-row candidate<<18 | sink<<19, w = qr = Q - rem;
 // descriptor B: positions of the first four predecessors.  hops[] (by position) lives in col() (free until the MSA columns).
-__device__ void poa_sweep_desc(Ctx& c, int lane, int Q, bool qlds) {
+__device__ void poa_sweep_desc(Ctx& c, int lane, int Q, bool qlds, const int PR) {
   const int n = c.n;
   int* hops = c.col();
   for (int c0 = ((n - 1) >> 6) << 6; c0 >= 0; c0 -= 64) {
@@ -260,8 +281,12 @@ __device__ void poa_sweep_desc(Ctx& c, int lane, int Q, bool qlds) {
 // DEF: the scoring is abPOA's default with match 5 (what the reference runs: bin/determine_consensus.py:30) -- every score is an
 // immediate operand then; otherwise they are read from the parameters (SGPRs, most of them spilled into VGPR lanes: one
 // v_readlane per use in the row loop)
-template <bool W32, bool DEF>
+template <bool W32, bool DEF, bool WIDE>
 __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, long long* cells PHA) {
+  constexpr int PR = WIDE ? 3 : C3_NARROW_PR, PW = WIDE ? C3_WIDE_PW : 128, PWT = PADL + PW + PADR, NCHMAX = PW / 64;
+  constexpr int RING_CELLS = WIDE ? RING_CELLS_W : RING_CELLS_N, PQW = WIDE ? PQW_W : PQW_N;
+  static_assert(PR * PWT == RING_CELLS, "ring geometry");
+  unsigned* const Lqpk = WIDE ? &L.qpk[0] : (unsigned*)&L.ring[3 * RING_CELLS_N];
   const int K = c.K, n = c.n;
   const int mt8 = DEF ? S3(5) : S3(P.poa_match), mm8 = DEF ? S3(-4) : S3(-P.poa_mismatch);
   const int e1_8 = DEF ? S3(2) : S3(P.e1), e2_8 = DEF ? S3(1) : S3(P.e2), o1_8 = DEF ? S3(4) : S3(P.o1), o2_8 = DEF ? S3(24) : S3(P.o2);
@@ -280,19 +305,22 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
 #define le1 (le1_8 << 6)
 #define le2 (le2_8 << 6)
   const int lo1_8 = le1_8 + o1_8, lo2_8 = le2_8 + o2_8;
-  const bool qlds = Q <= PQW * 16;
-  poa_sweep_desc(c, lane, Q, qlds);
+  const bool qlds = WIDE || Q <= PQW_N * 16;
+  poa_sweep_desc(c, lane, Q, qlds, PR);
   // the subread, 2-bit packed and re-aligned to its first base, goes to LDS: the row loop must not
-  // touch global memory for it (a vector load would wait for every older row store)
-  if (qlds) {
-    for (int i = lane; i * 16 < Q; i += 64) {
-      const long long b0 = (long long)qb + 16 * i;
+  // touch global memory for it (a vector load would wait for every older row store).  WIDE: a window of PQW * 16 bases
+  // from base qwb on; it follows the band (the row loop moves it, rarely: once per ~1400 rows)
+  int qwb = 0;
+  auto stage_query = [&](int from) {
+    for (int i = lane; i < PQW && from + 16 * i < Q; i += 64) {
+      const long long b0 = (long long)qb + from + 16 * i;
       const unsigned w0 = c.pk[b0 >> 4], w1 = c.pk[(b0 >> 4) + 1];
-      L.qpk[i] = __builtin_amdgcn_alignbit(w1, w0, (unsigned)(b0 & 15) * 2);
+      Lqpk[i] = __builtin_amdgcn_alignbit(w1, w0, (unsigned)(b0 & 15) * 2);
     }
-  }
+  };
+  if (qlds) stage_query(0);
   // every ring cell starts unreachable (the pads stay so: rows only write their PW cells)
-  if (!W32) { unsigned* r32 = (unsigned*)&L.H[0][0]; for (int i = lane; i < POA_LDS_INTS; i += 64) r32[i] = NEG16 | (NEG16 << 16); }
+  if (!W32) { unsigned* r32 = (unsigned*)&L.ring[0]; for (int i = lane; i < 3 * RING_CELLS / 2; i += 64) r32[i] = NEG16 | (NEG16 << 16); }
   WSYNC();
   PH_MARK(0)
   // Row loop.  The scalar ALU is ONE per CU (measured: 0.96 scalar instructions per cycle per CU against 1.5-1.7 vector
@@ -301,12 +329,13 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   // ALU; the scalar unit only sees the loop, one descriptor test and two branches per row.
   int u_beg = 0, u_end = -1, u_left = 0, u_right = 0, u_ncell = 0;                    // previous row / cells used so far
   int u_b8 = 0;                                                                        // ... and its base (absolute score * 8)
+  int u_nfar = 0;                                                                      // cells used in the far arena
   int pH = NEG16, pE1 = NEG16, pE2 = NEG16;                                           // its 16-bit cells, lane = band column
   bool pv_ok = false;                                                                  // ... valid: the row above, <= 64 cells
   int gacc = 0xffff;                                                                   // guard: lowest (stored H - ZHI16 - 1) mod 2^16 per lane
   int punt = 0;                                                                        // a value the 16-bit cells cannot hold was seen
   const int lane4 = lane * 4;
-  unsigned short* const LH = &L.H[0][0]; unsigned short* const LE1 = &L.E1[0][0]; unsigned short* const LE2 = &L.E2[0][0];
+  unsigned short* const LH = &L.ring[0]; unsigned short* const LE1 = &L.ring[RING_CELLS]; unsigned short* const LE2 = &L.ring[2 * RING_CELLS];
 #ifdef C3_EXP_SBAND
 #define UNI(x)                                   /* experiment: band arithmetic of the fast row on the scalar unit */
 #else
@@ -328,6 +357,10 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     const int qr = __builtin_amdgcn_readlane(dA.w, li);
     const int vb = fl & 0xff;
     const bool far = W32 || ((fl >> 16) & 1);
+    if (WIDE && qr + w + 72 > qwb + PQW * 16 && qwb + PQW * 16 < Q) {                // the band nears the end of the query window: move it
+      qwb = max(0, qr - w - 320) & ~15;
+      WSYNC(); stage_query(qwb); WSYNC();
+    }
     // ---- FAST ROW: one predecessor = the previous row, whose H/E1/E2 are still in this wave's REGISTERS (lane = band
     // column).  The predecessor cells arrive by lane permutes (no LDS round trip through memory on the dependent chain),
     // the row maximum is taken from Ht in parallel with the two F scans (an F value is always strictly below some Ht to
@@ -346,13 +379,13 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       end = max(end, beg - 1);
       const int wd = end - beg + 1, sh = beg - u_beg;
       // (64 cells of head room instead of wd: the stores below are not masked)
-      if (__builtin_amdgcn_ballot_w64(((int)((unsigned)(wd - 1) < 64u) & (int)(wd + sh <= 64) & ((int)(sh >= 1) | (int)(u_end - u_beg < 63)) & (int)(u_ncell + 64 <= c.cells_cap)) != 0) != 0) {
+      if (__builtin_amdgcn_ballot_w64(((int)((unsigned)(wd - 1) < 64u) & (int)(wd + sh <= 64) & ((int)(sh >= 1) | (int)(u_end - u_beg < 63)) & (int)(u_ncell + 64 <= c.cells_cap) & (int)(!far || u_nfar + 64 <= c.far_cap()) & (int)(!WIDE || (max(beg - 1, 0) >= qwb && end <= qwb + PQW * 16))) != 0) != 0) {
         const int ro = u_ncell;
         const int j = beg + lane;
         const bool act = lane < wd;
         // query base of column j (LDS copy; issued first, consumed after the permutes)
-        const int jq = max(j - 1, 0);
-        const unsigned qw_ = L.qpk[min(jq >> 4, PQW - 1)];
+        const int jq = max(j - 1, 0) - (WIDE ? qwb : 0);
+        const unsigned qw_ = Lqpk[min(jq >> 4, PQW - 1)];
         // previous row moved to this row's columns: hp = H[i-1][j] sits sh lanes to the right, hd = H[i-1][j-1] one less
         const int a_p = lane4 + sh * 4, a_d = a_p - 4;
         const int hd = __builtin_amdgcn_ds_bpermute(a_d, pH), hp = __builtin_amdgcn_ds_bpermute(a_p, pH);
@@ -397,9 +430,8 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         c.D8()[(unsigned)(ro + lane)] = (uint8_t)d;
         { const int cb = slot * PWT + PADL + lane;
           LH[cb] = (unsigned short)pH; LE1[cb] = (unsigned short)pE1; LE2[cb] = (unsigned short)pE2;
-#ifndef C3_EXP_NOFILL
-          LH[cb + 64] = NEG16; LE1[cb + 64] = NEG16; LE2[cb + 64] = NEG16;      // (a one-chunk row: its second chunk reads as unreachable)
-#endif
+#pragma unroll
+          for (int f = 1; f < NCHMAX; ++f) { LH[cb + 64 * f] = NEG16; LE1[cb + 64 * f] = NEG16; LE2[cb + 64 * f] = NEG16; }      // (a one-chunk row: its other chunks read as unreachable)
         }
         if (lane == 0) {
           L.meta[slot] = make_int4(beg, end, left, right); L.base8[slot] = nb8;
@@ -407,8 +439,10 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
           int* rm = c.rowm() + off; rm[0] = beg; rm[1] = end; rm[2] = ro;                 // type 0: byte cells, one predecessor
         }
         if (far) {
-          if (act) { c.H()[ro + lane] = cv_16to9(pH, nb8); c.E1()[ro + lane] = cv_16to9(pE1, nb8); c.E2()[ro + lane] = cv_16to9(pE2, nb8); }
-          if (lane == 0) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
+          const int fo = wave_first(u_nfar);
+          if (act) { c.H()[fo + lane] = cv_16to9(pH, nb8); c.E1()[fo + lane] = cv_16to9(pE1, nb8); c.E2()[fo + lane] = cv_16to9(pE2, nb8); }
+          if (lane == 0) { c.mpl()[idx] = left; c.mpr()[idx] = right; c.foff()[idx] = fo; }
+          u_nfar = fo + wave_first(wd);
         }
         u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ro + wd; u_b8 = nb8;
 #ifdef C3_PHASE_PROF
@@ -460,7 +494,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       int end = min(min(Q, max(mprv, qr) + w), maxe);
       end = max(end, beg - 1);
       const int wd = end - beg + 1;
-      if (__builtin_amdgcn_ballot_w64(((int)((unsigned)(wd - 1) < (unsigned)(64 * NCH)) & (int)(wmax < PW) & (int)(dabs < 2048) & (int)(u_ncell + 64 * NCH <= c.cells_cap)) != 0) == 0) return false;
+      if (__builtin_amdgcn_ballot_w64(((int)((unsigned)(wd - 1) < (unsigned)(64 * NCH)) & (int)(wmax < PW) & (int)(dabs < 2048) & (int)(u_ncell + 64 * NCH <= c.cells_cap) & (int)(!far || u_nfar + 64 * NCH <= c.far_cap()) & (int)(!WIDE || (max(beg - 1, 0) >= qwb && end <= qwb + PQW * 16))) != 0) == 0) return false;
       const int ro = u_ncell;
       const int W8 = wave_first(b8_[0]);
       // per predecessor: base difference + tie-order tag of each candidate (first predecessor wins: highest tag; open before extend)
@@ -480,8 +514,8 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         const int c0 = 64 * ch;
         const int j = beg + c0 + lane;
         const bool act = c0 + lane < wd;
-        const int jq = max(j - 1, 0);
-        const unsigned qw_ = L.qpk[min(jq >> 4, PQW - 1)];
+        const int jq = max(j - 1, 0) - (WIDE ? qwb : 0);
+        const unsigned qw_ = Lqpk[min(jq >> 4, PQW - 1)];
         int hd_[NP], hp_[NP], e1_[NP], e2_[NP];
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
@@ -544,17 +578,21 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
 #endif
         const int cb = slot * PWT + PADL + 64 * ch + lane;
         LH[cb] = (unsigned short)vH; LE1[cb] = (unsigned short)vE1; LE2[cb] = (unsigned short)vE2;
-        if (NCH == 1) { LH[cb + 64] = NEG16; LE1[cb + 64] = NEG16; LE2[cb + 64] = NEG16; }
+        if (ch == NCH - 1) {
+#pragma unroll
+          for (int f = 1; f <= NCHMAX - NCH; ++f) { LH[cb + 64 * f] = NEG16; LE1[cb + 64 * f] = NEG16; LE2[cb + 64 * f] = NEG16; }      // the chunks this row does not have
+        }
         if (ch == 0) { pH = vH; pE1 = vE1; pE2 = vE2; }
-        if (far) { if (act) { c.H()[ro + 64 * ch + lane] = cv_16to9(vH, nb8); c.E1()[ro + 64 * ch + lane] = cv_16to9(vE1, nb8); c.E2()[ro + 64 * ch + lane] = cv_16to9(vE2, nb8); } }
+        if (far) { if (act) { c.H()[u_nfar + 64 * ch + lane] = cv_16to9(vH, nb8); c.E1()[u_nfar + 64 * ch + lane] = cv_16to9(vE1, nb8); c.E2()[u_nfar + 64 * ch + lane] = cv_16to9(vE2, nb8); } }
       }
-      pv_ok = NCH == 1;
+      pv_ok = NCH == 1;                          // (WIDE: never -- its instances start at two chunks)
       if (lane == 0) {
         L.meta[slot] = make_int4(beg, end, left, right); L.base8[slot] = nb8;
         int off = 3 * idx; UNI(off);
         int* rm = c.rowm() + off; rm[0] = beg; rm[1] = end | (1 << 28); rm[2] = ro;
-        if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
+        if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; c.foff()[idx] = u_nfar; }
       }
+      if (far) u_nfar = wave_first(u_nfar) + wave_first(wd);
 #ifdef C3_EXP_SBAND
       u_beg = wave_first(beg); u_end = wave_first(end); u_left = wave_first(left); u_right = wave_first(right); u_ncell = wave_first(ro + wd); u_b8 = nb8;
 #else
@@ -566,8 +604,11 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       return true;
       };
       typedef std::integral_constant<int, 1> I1; typedef std::integral_constant<int, 2> I2; typedef std::integral_constant<int, 3> I3; typedef std::integral_constant<int, 4> I4;
-      bool handled = nin == 1 ? near_body(I1{}, I1{}) : nin == 2 ? near_body(I2{}, I1{}) : nin == 3 ? near_body(I3{}, I1{}) : near_body(I4{}, I1{});
-      if (!handled) handled = nin == 1 ? near_body(I1{}, I2{}) : nin == 2 ? near_body(I2{}, I2{}) : nin == 3 ? near_body(I3{}, I2{}) : near_body(I4{}, I2{});
+      // chunk counts tried: 1, 2 (NARROW) / 2, 3, 4 (WIDE: long subreads have no bands below 64 columns to speak of)
+      typedef std::integral_constant<int, WIDE ? 2 : 1> CA; typedef std::integral_constant<int, WIDE ? 3 : 2> CB; typedef std::integral_constant<int, 4> CC;
+      bool handled = nin == 1 ? near_body(I1{}, CA{}) : nin == 2 ? near_body(I2{}, CA{}) : nin == 3 ? near_body(I3{}, CA{}) : near_body(I4{}, CA{});
+      if (!handled) handled = nin == 1 ? near_body(I1{}, CB{}) : nin == 2 ? near_body(I2{}, CB{}) : nin == 3 ? near_body(I3{}, CB{}) : near_body(I4{}, CB{});
+      if (WIDE && C3_WIDE_PW >= 256) { if (!handled && nin <= 2) handled = nin == 1 ? near_body(I1{}, CC{}) : near_body(I2{}, CC{}); }      // (four chunks: one or two predecessors only)
       if (handled) continue;
     }
     // ---- GENERAL ROW (32-bit cells).  Adaptive band: gather the hints of the predecessors (abPOA scatters them to the
@@ -617,8 +658,17 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     beg = wave_first(beg); end = wave_first(end);
     if (end < beg) end = beg - 1;
     const int wd = end - beg + 1;
+#ifdef C3_DEBUG_PUNT
+    if (ncell + wd > c.cells_cap && lane == 0) atomicAdd(c.dbg + 12, 1ull);
+#endif
     if (ncell + wd > c.cells_cap) return -4;
     const bool inl = !W32 && wd <= PW, toglobal = far || !inl;     // wd is scalar (beg / end pinned above)
+    const bool qrow = qlds && (!WIDE || (max(beg - 1, 0) >= qwb && end <= qwb + PQW * 16));      // the row's query bases are in the LDS window
+    const int fo = wave_first(u_nfar);                               // its cells in the far arena (when it keeps 32-bit cells / direction words)
+#ifdef C3_DEBUG_PUNT
+    if ((toglobal || ovf) && fo + wd > c.far_cap() && lane == 0) { atomicAdd(c.dbg + 13, 1ull); atomicMax(c.dbg + 11, ((unsigned long long)(unsigned)fo << 32) | (unsigned)c.far_cap()); }
+#endif
+    if (toglobal || ovf) { if (fo + wd > c.far_cap()) return -4; u_nfar = fo + wd; }
     const int ro = ncell;
     const int ty = ovf ? 2 : (nin >= 2 ? 1 : 0);                   // cell format: byte / byte + predecessor byte / 32-bit word
     ncell += wd;
@@ -655,7 +705,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
               hd = vd ? cv_16to9(hd_[k], rb8_[k]) : NEGS; hp = vp ? cv_16to9(hp_[k], rb8_[k]) : NEGS;
               e1p = vp ? cv_16to9(e1_[k], rb8_[k]) : NEGS; e2p = vp ? cv_16to9(e2_[k], rb8_[k]) : NEGS;
             } else {
-              const int po = c.rowm()[3 * pi + 2];
+              const int po = c.foff()[pi];
               if (vd) hd = c.H()[po + (j - 1 - b)];
               if (vp) { hp = c.H()[po + (j - b)]; e1p = c.E1()[po + (j - b)]; e2p = c.E2()[po + (j - b)]; }
             }
@@ -676,7 +726,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
             if (j > 0 && j - 1 >= b && j - 1 <= e) hd = cv_16to9(LH[sl * PWT + PADL + j - 1 - b], pb8);
             if (j >= b && j <= e) { hp = cv_16to9(LH[sl * PWT + PADL + j - b], pb8); e1p = cv_16to9(LE1[sl * PWT + PADL + j - b], pb8); e2p = cv_16to9(LE2[sl * PWT + PADL + j - b], pb8); }
           } else {
-            const int po = c.rowm()[3 * pi + 2];
+            const int po = c.foff()[pi];
             if (j > 0 && j - 1 >= b && j - 1 <= e) hd = c.H()[po + (j - 1 - b)];
             if (j >= b && j <= e) { hp = c.H()[po + (j - b)]; e1p = c.E1()[po + (j - b)]; e2p = c.E2()[po + (j - b)]; }
           }
@@ -685,7 +735,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
           kE2 = max(kE2, max(hp - oe2_9 + (511 - 2 * k), e2p - e2_9 + (510 - 2 * k)));
         }
         int qc = 7;
-        if (act && j > 0) qc = qlds ? (int)((L.qpk[(j - 1) >> 4] >> (((j - 1) & 15) * 2)) & 3) : c3_code_at(c.pk, qb + j - 1);
+        if (act && j > 0) qc = qrow ? (int)((Lqpk[(j - 1 - (WIDE ? qwb : 0)) >> 4] >> (((j - 1) & 15) * 2)) & 3) : c3_code_at(c.pk, qb + j - 1);
         const int M9 = (j > 0) ? (kM & ~511) + ((vb == qc) ? mt9 : mm9) : NEGS;
         E1v = kE1 & ~511; E2v = kE2 & ~511;
         const int k2 = max(max(M9 + 2, E1v + 1), E2v);
@@ -722,16 +772,16 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       if (c0 == 0) { Wg = u_b8; const int r_ = (cmx >> 6) - Wg + BIAS16; if (cmx > NEGS / 2 && (unsigned)(r_ - RB_LO16) > (unsigned)c.rb_span) Wg = cmx >> 6; }
       if (act) {
         const int ci = c0 + lane;
-        if (ty == 2) c.D()[ro + ci] = dw;
+        if (ty == 2) c.D()[fo + ci] = dw;
         else { c.D8()[(unsigned)(ro + ci)] = (uint8_t)d; if (ty == 1) c.P8()[(unsigned)(ro + ci)] = (uint8_t)pby; }
-        if (toglobal) { c.H()[ro + ci] = h9; c.E1()[ro + ci] = E1v; c.E2()[ro + ci] = E2v; }
+        if (toglobal) { c.H()[fo + ci] = h9; c.E1()[fo + ci] = E1v; c.E2()[fo + ci] = E2v; }
       }
       if (inl) {
         // ring cells: 16 bits against the base Wg; idle lanes unreachable (every lane stores)
         const int vH = act ? cv_9to16(h9, Wg, bad) : NEG16, vE1 = act ? cv_9to16(E1v, Wg, bad) : NEG16, vE2 = act ? cv_9to16(E2v, Wg, bad) : NEG16;
         const int cb = slot * PWT + PADL + c0 + lane;
         LH[cb] = (unsigned short)vH; LE1[cb] = (unsigned short)vE1; LE2[cb] = (unsigned short)vE2;
-        if (wd <= 64) { LH[cb + 64] = NEG16; LE1[cb + 64] = NEG16; LE2[cb + 64] = NEG16; }
+        if (c0 + 64 >= wd) { for (int f = 64; c0 + f < PW; f += 64) { LH[cb + f] = NEG16; LE1[cb + f] = NEG16; LE2[cb + f] = NEG16; } }      // the chunks this row does not have
         if (c0 == 0) { gH = vH; gE1 = vE1; gE2 = vE2; }
       }
       if (cmx > best) { best = cmx; const unsigned long long mm = __ballot(htm == cmx); bl = beg + c0 + __builtin_ctzll(mm); br = beg + c0 + 63 - __builtin_clzll(mm); }
@@ -744,6 +794,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       L.meta[slot] = make_int4(beg, end, left, right); L.base8[slot] = Wg;
       { int* rm = c.rowm() + 3 * idx; rm[0] = beg; rm[1] = end | (ty << 28); rm[2] = ro; }
       if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; }
+      if (toglobal || ovf) c.foff()[idx] = fo;
     }
     u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ncell; u_b8 = Wg;
 #ifdef C3_PHASE_PROF
@@ -765,7 +816,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   for (int k = 0; k < c.n_in()[SNK]; ++k) {
     const int pi = c.index()[c.in_from()[EI(SNK, k)]];
     const int pb = c.rowm()[3 * pi], pe = c.rowm()[3 * pi + 1] & 0x0fffffff;
-    const int hh = (Q < pb || Q > pe) ? NEGS : c.H()[c.rowm()[3 * pi + 2] + (Q - pb)];
+    const int hh = (Q < pb || Q > pe) ? NEGS : c.H()[c.foff()[pi] + (Q - pb)];
     if (hh > bs) { bs = hh; bi = pi; }
   }
   if (bi < 0 || bs <= NEGS / 2) return -1;
@@ -780,7 +831,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
   int* vq = c.mpl();
   int rc = 0;
   {
-    uint8_t* WD = (uint8_t*)&L.H[0][0];          // [64][32] direction-byte windows
+    uint8_t* WD = (uint8_t*)&L.ring[0];          // [64][32] direction-byte windows
     uint8_t* WP = WD + 64 * 32;                  // [64][32] predecessor-byte windows (the three rings are contiguous: 4.7 KB)
     int i = bi, j = Q, st = 0;   // st: 0 H, 1 Ht, 2 E1, 3 E2, 4 F1, 5 F2
     while (!(i == 0 && j == 0) && rc == 0) {
@@ -837,7 +888,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
           // outside the window (the path drifted off the diagonal of this block) or a row of 32-bit words: direct loads
           const int cb = wave_bcast(b, cl), cro = wave_bcast(ro, cl);
           if (cty == 2) {
-            const unsigned wv = c.D()[cro + (j - cb)];
+            const unsigned wv = c.D()[c.foff()[i] + (j - cb)];
             mp = wv & 0xff; c1 = (wv >> 8) & 0x1ff; c2 = (wv >> 17) & 0x1ff; hts = (wv >> 26) & 3; hs = (wv >> 28) & 3; f1x = (wv >> 30) & 1; f2x = wv >> 31;
           } else {
             const unsigned db = c.D8()[(unsigned)(cro + (j - cb))];
@@ -939,7 +990,7 @@ __device__ int poa_fuse(Ctx& c, bool first, int qb, int Q, int* path, int lane P
   WSYNC();
   c.n = nn;
   PH_MARK(3)
-  g_reorder(c, n_old, lane, (int*)&L.H[0][0], POA_LDS_INTS);      // H, E1, E2 rings are contiguous and idle after the traceback
+  g_reorder(c, n_old, lane, (int*)&L.ring[0], POA_LDS_INTS);      // H, E1, E2 rings are contiguous and idle after the traceback
   PH_MARK(4)
   return 0;
 }
@@ -1001,14 +1052,15 @@ extern "C" void c3k_launch_pairwise(const uint8_t* rows, int ncol, const uint8_t
 #ifndef C3_POA_WAVES
 #define C3_POA_WAVES 6
 #endif
-template <bool W32, bool DEF>
+template <bool W32, bool DEF, bool WIDE>
 __global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
   const int lane = wave_lane();
   const int slot = blockIdx.x;
   Ctx c;
   const size_t N = (size_t)a.Ncap;
   c.I = a.ibase + (size_t)slot * C3_POA_NI * N; c.path_ = a.pbase + (size_t)slot * a.Pcap; c.E = a.ebase + (size_t)slot * 3 * N * a.K;
-  c.C = a.cellsb + (size_t)slot * 18 * (size_t)a.cells_cap; c.B8 = a.bbase + (size_t)slot * 5 * N;
+  c.far_shift = W32 ? 0 : 2;
+  c.C = a.cellsb + (size_t)slot * (2 * (size_t)a.cells_cap + 16 * (size_t)(a.cells_cap >> c.far_shift)); c.B8 = a.bbase + (size_t)slot * 5 * N;
   c.score_ = a.score + (size_t)slot * N; c.desc_ = a.desc + (size_t)slot * 2 * N; c.jump_ = a.jump + (size_t)slot * C3_JUMP_LEVELS * N;
   c.K = a.K; c.Ncap = a.Ncap; c.cells_cap = a.cells_cap; c.osel = 0; c.rb_span = a.rb_span > 0 ? a.rb_span : RB_HI16 - RB_LO16;
 #ifdef C3_DEBUG_PUNT
@@ -1047,7 +1099,7 @@ __global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
       int poff = 0;
       for (int s = 0; s < ns && !fail; ++s) {
         const int qb = wave_first(info->sub_beg[s]), Q = wave_first(info->sub_end[s]) - qb;
-        if (s > 0) { const int rc = poa_align<W32, DEF>(c, a.p, qb, Q, lane, &cells PHP); if (rc < 0) { fail = (rc == -4 || rc == -5) ? 2 : 1; punted = rc == -5; break; } }
+        if (s > 0) { const int rc = poa_align<W32, DEF, WIDE>(c, a.p, qb, Q, lane, &cells PHP); if (rc < 0) { fail = (rc == -4 || rc == -5) ? 2 : 1; punted = rc == -5; break; } }
         if (poa_fuse(c, s == 0, qb, Q, c.path() + poff, lane PHP) < 0) { fail = 2; break; }                 // node capacity
         poff += Q;
       }
@@ -1167,6 +1219,7 @@ __global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
               if (live) { scp[idx] = acc; hpp[idx] = hp; nxp[idx] = np; onf[idx] = 0; }
               WSYNC();
             }
+            unsigned* const Lf = (unsigned*)&L.ring[0];                          // 64 flag words (the rings are idle here)
             C = hpp[0] - 1;                                                     // SRC sits at position 0: hops to the sink - 1 = consensus length
             if (lane == 0) onf[0] = 1;
             WSYNC();
@@ -1177,11 +1230,11 @@ __global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
               const int np = live ? nxp[idx] : -1;
               int J = (np >= c0 && np < c0 + 64) ? np - c0 : -1;                  // successor lane inside the chunk
               for (int r = 0; r < 6; ++r) {
-                L.qpk[lane] = 0;
+                Lf[lane] = 0;
                 WSYNC();
-                if (on && J >= 0) L.qpk[J] = 1;
+                if (on && J >= 0) Lf[J] = 1;
                 WSYNC();
-                on |= (int)L.qpk[lane];
+                on |= (int)Lf[lane];
                 const int J2 = __builtin_amdgcn_ds_bpermute(max(J, 0) << 2, J);
                 J = J >= 0 ? J2 : -1;
                 WSYNC();
@@ -1227,9 +1280,12 @@ __global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
   PH_FLUSH(a.phases)
 }
 
-extern "C" void c3k_launch_poa(const PoaArgs* a, int slots, int wide32, hipStream_t stream) {
+extern "C" void c3k_launch_poa(const PoaArgs* a, int slots, int wide32, int wide_ring, hipStream_t stream) {
   const C3Params& p = a->p;
   const bool def = p.poa_match == 5 && p.poa_mismatch == 4 && p.o1 == 4 && p.e1 == 2 && p.o2 == 24 && p.e2 == 1;
-  if (wide32) { if (def) hipLaunchKernelGGL((k_poa<true, true>), dim3(slots), dim3(64), 0, stream, *a); else hipLaunchKernelGGL((k_poa<true, false>), dim3(slots), dim3(64), 0, stream, *a); }
-  else { if (def) hipLaunchKernelGGL((k_poa<false, true>), dim3(slots), dim3(64), 0, stream, *a); else hipLaunchKernelGGL((k_poa<false, false>), dim3(slots), dim3(64), 0, stream, *a); }
+#define C3_POA_LAUNCH(W, D, R) hipLaunchKernelGGL((k_poa<W, D, R>), dim3(slots), dim3(64), 0, stream, *a)
+  if (wide32) { if (def) C3_POA_LAUNCH(true, true, false); else C3_POA_LAUNCH(true, false, false); }
+  else if (wide_ring) { if (def) C3_POA_LAUNCH(false, true, true); else C3_POA_LAUNCH(false, false, true); }
+  else { if (def) C3_POA_LAUNCH(false, true, false); else C3_POA_LAUNCH(false, false, false); }
+#undef C3_POA_LAUNCH
 }

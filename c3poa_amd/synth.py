@@ -22,6 +22,9 @@ CONFIGS = {
     "cfg3": dict(reads=1000000, seed=3, insert=1000, n_lo=2, n_hi=10, k0=108, k1=108, mdist=500),
     "cfg4": dict(reads=100000, seed=4, insert=1256, n_lo=12, n_hi=12, k0=618, k1=618, mdist=1500),
     "cfg5": dict(reads=10000000, seed=5, insert=1216, n_lo=3, n_hi=3, k0=108, k1=108, mdist=500),
+    # not a BASELINE config: long cDNA inserts (real R2C2 libraries hold 2-6 kb molecules; abPOA has no length limit,
+    # bin/determine_consensus.py:30-47).  Insert drawn per read from the list; 3-5 repeats; reads of 10-32 kb
+    "cfgL": dict(reads=20000, seed=6, insert=(3000, 6000), n_lo=3, n_hi=5, k0=108, k1=108, mdist=500),
 }
 
 _ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -78,7 +81,8 @@ def generate(cfg="cfg2", n_reads=None, seed=None, splint=SPLINT1, start=0):
     for i in range(start, start + total):
         rng = np.random.default_rng([sd, i])
         n = int(rng.integers(c["n_lo"], c["n_hi"] + 1))
-        seq, qual, strand, truth = make_read(rng, splint, c["insert"], n, c["k0"], c["k1"])
+        ins = c["insert"] if isinstance(c["insert"], int) else int(c["insert"][int(rng.integers(0, len(c["insert"])))])
+        seq, qual, strand, truth = make_read(rng, splint, ins, n, c["k0"], c["k1"])
         yield ("r%08d" % i, seq, qual, strand, truth)
 
 

@@ -195,6 +195,10 @@ static int poa_align(const c3o_graph* g, const uint8_t* q, int Q, const c3o_para
       }
       int pwd = m.rend[idx - 1] - m.rbeg[idx - 1] + 1, sh = beg - m.rbeg[idx - 1];
       S[0]++; S[1] += wd;
+      { int f6 = 0, f4 = 0;
+        for (int k = 0; k < g->n_out[v]; ++k) { int t = g->out_to[v * K + k]; int dd = (t == SNK) ? 99 : g->index[t] - idx; if (dd > 5) f6 = 1; if (dd > 3) f4 = 1; }
+        if (f6) S[56] += wd;
+        if (f4) S[57] += wd; }
       if (nin == 1 && dmax == 1 && wd <= 64 && pwd <= 64 && sh < 64 && !(wd + sh <= 64 && (sh >= 1 || pwd <= 63))) S[54]++;     /* fast in round 3, not under the round-4 no-wrap rule */
       if (nin == 1 && dmax == 1 && wd <= 64 && pwd <= 64 && sh < 64) { S[2]++; S[8 + (sh < 0 ? 0 : sh > 3 ? 4 : sh + 0)]++; }   /* fast; shift histogram 8..12 */
       else if (nin <= 4 && dmax < 4 && wd <= 128 && pwmax < 128) {
@@ -205,6 +209,7 @@ static int poa_align(const c3o_graph* g, const uint8_t* q, int Q, const c3o_para
         else S[21 + (nin - 3)]++;                                              /* 21: three, 22: four */
       } else { S[4]++; if (nin > 4) S[24]++; else if (dmax >= 4) { S[25]++; S[48 + (dmax < 6 ? 0 : dmax < 8 ? 1 : dmax < 12 ? 2 : dmax < 16 ? 3 : 4)]++; } else S[26]++; }
       S[28 + (wd <= 32 ? 0 : wd <= 48 ? 1 : wd <= 64 ? 2 : wd <= 96 ? 3 : wd <= 128 ? 4 : 5)]++;
+      if (wd > 128) S[58 + (wd <= 160 ? 0 : wd <= 192 ? 1 : wd <= 256 ? 2 : 3)]++;
       /* lowest real value below the row maximum */
       int lo = 0;
       for (int c = 0; c < wd; ++c) {

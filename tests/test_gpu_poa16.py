@@ -90,3 +90,26 @@ def test_msa_rows_survive_a_moving_base():
             os.environ.pop("C3_DEBUG_POA_RBSPAN", None)
         else:
             os.environ["C3_DEBUG_POA_RBSPAN"] = old
+
+
+@pytest.mark.parametrize("cfg,n,envs", [
+    ("cfgL", 10, ({}, {"C3_DEBUG_POA_WIDE": "0"}, {"C3_DEBUG_POA_RBSPAN": "3300"})),       # 3 kb / 6 kb inserts: WIDE ring by default
+    ("cfg2", 64, ({"C3_DEBUG_POA_WIDE": "1"},)),                                            # the WIDE instance on ordinary reads
+    ("cfg4", 12, ({"C3_DEBUG_POA_WIDE": "1"},)),
+])
+def test_long_subreads_and_the_wide_ring(cfg, n, envs):
+    """subreads beyond the 1792-base LDS query copy / bands beyond 128 columns (abPOA has no length limit,
+    bin/determine_consensus.py:30-47): the WIDE kernel instance (4 ring rows of 192 cells, three-chunk near rows, a query window
+    that follows the band) equals the oracle, and so does the NARROW instance on the same reads (everything through its general
+    rows); no read is handed to the 32-bit pass"""
+    recs = _ragged(list(synth.generate(cfg, n_reads=n)), seed=9)
+    md = synth.CONFIGS[cfg]["mdist"]
+    ores, ocons = O.process_batch(synth.SPLINT1, [(r[1], r[2]) for r in recs], [r[3] for r in recs],
+                                  params=O.default_params(mdistcutoff=md), threads=8)
+    cells = sum(int(r.cells_poa) for r in ores)
+    assert any(r.n_sub >= 3 for r in ores)
+    for env in envs:
+        res, cons, t = _run(recs, md, env)
+        for i in range(n):
+            assert res[i]["status"] == ores[i].status and cons[i] == ocons[i], (cfg, env, i)
+        assert t["cells_poa"] == cells and t["n_poa_redo16"] == 0, (cfg, env, t["n_poa_redo16"])

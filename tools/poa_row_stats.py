@@ -24,7 +24,9 @@ print("  near rows: 1 pred d=1(wide) %.1f%%, d=2 %.1f%%, d=3 %.1f%%; 2 preds (ro
       % tuple(100 * x / max(s[3], 1) for x in s[16:23]))
 print("  general rows: >4 preds %.1f%%, far pred %.1f%%, wide %.1f%%" % tuple(100 * x / max(s[4], 1) for x in s[24:27]))
 print("  far predecessor distance 4-5 %.1f%% 6-7 %.1f%% 8-11 %.1f%% 12-15 %.1f%% 16+ %.1f%%" % tuple(100 * x / max(s[25], 1) for x in s[48:53]))
+print("  cells of rows with a successor beyond the ring: %.2f%% with 6 ring rows, %.2f%% with 4" % (100 * s[56] / max(s[1], 1), 100 * s[57] / max(s[1], 1)))
 print("  band width <=32 %.1f%% <=48 %.1f%% <=64 %.1f%% <=96 %.1f%% <=128 %.1f%% >128 %.1f%%" % tuple(100 * x / rows for x in s[28:34]))
+print("  rows wider than 128: <=160 %.1f%% <=192 %.1f%% <=256 %.1f%% >256 %.1f%% (of all rows)" % tuple(100 * x / rows for x in s[58:62]))
 print("  lowest real cell below its row maximum: %d; rows by that depth >-200 %.2f%% >-400 %.2f%% >-800 %.2f%% >-1600 %.3f%% below %.4f%%"
       % ((s[40],) + tuple(100 * x / rows for x in s[41:46])))
 print("  largest step of the row maximum between consecutive rows: %d" % s[47])
