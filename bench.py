@@ -42,13 +42,14 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 # per-GPU reads per step: BASELINE.json configs (cfg3: 1M reads over 8 GPUs)
-DEFAULT_READS = {"cfg1": 1000, "cfg2": 100000, "cfg3": 125000, "cfg4": 100000, "cfg5": 131072}
+DEFAULT_READS = {"cfg1": 1000, "cfg2": 100000, "cfg3": 125000, "cfg4": 100000, "cfg5": 131072, "cfgL": 20000}
 WORKLOAD_TEXT = {
     "cfg1": "5 kb, 3x1.5 kb repeats (plumbing case)",
     "cfg2": "5 kb, 3x1.5 kb repeats, Splint1, 10% error",
     "cfg3": "mixed 2-10 subreads, 1 kb insert (1M reads read-sharded over 8 GPUs -> 125k per GPU)",
     "cfg4": "20 kb, 12 subreads, -d 1500 (wide adaptive band)",
     "cfg5": "cfg2 shape, one GPU batch of the streamed CLI",
+    "cfgL": "not a BASELINE config: long inserts (3 / 6 kb, 3-5 repeats, reads of 10-32 kb) -- the subread-length axis",
 }
 
 
@@ -154,7 +155,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--other-configs", default="auto",
-                    help="comma list of further configs run for 3 steps after the headline (rank 0, N=1): 'auto' = cfg3,cfg4 "
+                    help="comma list of further configs run for 3 steps after the headline (rank 0, N=1): 'auto' = cfg3,cfg4,cfgL "
                          "when the headline is cfg2 at full size, 'none' = skip")
     ap.add_argument("--other-unique", type=int, default=0, help="distinct reads generated for each of the other configs (0 = all distinct, no tiling)")
     a = ap.parse_args(argv)
@@ -183,7 +184,7 @@ def main():
     # inputs of the other configs too (rank 0, N=1): the fork pool must run before anything touches the GPU
     others = a.other_configs
     if others == "auto":
-        others = "cfg3,cfg4" if (a.cfg == "cfg2" and a.reads >= 100000) else "none"
+        others = "cfg3,cfg4,cfgL" if (a.cfg == "cfg2" and a.reads >= 100000) else "none"
     other_recs = {}
     if rank == 0 and world == 1 and others != "none":
         for c in [x for x in others.split(",") if x]:
@@ -348,6 +349,8 @@ def main():
                          "cells_polish_full_matrix": int(tm["cells_polish"]), "cells_polish_computed": int(tm["cells_polish_computed"]),
                          "band_layers": int(tm["n_band_layers"]), "band_fallback_layers": int(tm["n_band_fallback"]),
                          "windows": int(tm["n_windows"]), "windows_second_launch": int(tm["n_win_redo"]),
+                         "cells_poa": int(tm["cells_poa"]), "poa_gcells_per_s": round(tm["cells_poa"] / (avg["ms_poa"] * 1e-3) / 1e9, 1),
+                         "poa_second_pass_reads": int(tm["n_poa_redo"]), "poa_reads_beyond_16bit": int(tm["n_poa_redo16"]),
                          "gcups": round(cells / (sum(avg.values()) * 1e-3) / 1e9, 2)},
             "gen_s": round(t_gen, 1),
         }
@@ -412,6 +415,8 @@ def run_other_config(cfg, device, recs, gen_s, steps=3, check=True):
          "kernel_ms": {k: round(float(np.mean(v)), 2) for k, v in kms.items()},
          "cells": int(tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish"]), "cells_polish_computed": int(tm["cells_polish_computed"]),
          "band_fallback_layers": int(tm["n_band_fallback"]), "band_layers": int(tm["n_band_layers"]), "windows_second_launch": int(tm["n_win_redo"]),
+         "cells_poa": int(tm["cells_poa"]), "poa_gcells_per_s": round(tm["cells_poa"] / (float(np.mean(kms["ms_poa"])) * 1e-3) / 1e9, 1),
+         "poa_second_pass_reads": int(tm["n_poa_redo"]), "poa_reads_beyond_16bit": int(tm["n_poa_redo16"]),
          "consensus_ok": int((res["status"] == 0).sum()), "identity_vs_truth_mean": round(float(np.mean(idents)), 5),
          "data": "synthetic %s, %d distinct reads%s" % (cfg, nu, "" if reps == 1 else " tiled x%d" % reps), "gen_s": round(gen_s, 1)}
     h.close(); host.close()

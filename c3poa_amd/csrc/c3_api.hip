@@ -560,14 +560,14 @@ static int fetch_summary(c3_handle* h) {
 }
 
 // one launch of k_poa over `nw` reads of `d_work` with the given capacities
-static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, int Pcap, long long cells, int* d_overflow, int waves_per_cu, int wide_ring) {
+static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, int Pcap, long long cells, int* d_overflow, int* d_overflow16, int waves_per_cu, int wide_ring) {
   const size_t N = (size_t)Ncap;
   const int NI = 19;      // int arrays of N (c3_args.h)
   cells = (cells + 15) & ~15LL;                   // every per-slot arena starts 16-byte aligned
   cells = (cells + 63) & ~63LL;
   // far arena (32-bit cells of rows with a successor beyond the LDS ring, rows wider than a ring slot, rows with > 4 predecessors):
   // a quarter of the cells in the first pass (a few per cent are used), all of them in the 32-bit pass, where every row is far
-  const bool w32 = d_overflow == nullptr || getenv("C3_DEBUG_POA32");
+  const bool w32 = d_overflow16 == nullptr || getenv("C3_DEBUG_POA32");      // the pass that takes the reads beyond 16 bits (test hook: every pass)
   const long long far = w32 ? cells : cells >> 2;
   const size_t per_slot = N * (NI * 4 + 8 + 5 + 32 + 4 * C3_JUMP_LEVELS) + N * K * 12 + (size_t)cells * 2 + (size_t)far * 16 + (size_t)Pcap * 4;
   const int slots = auto_slots(h, h->cfg.slots_poa, per_slot, nw, waves_per_cu);
@@ -582,13 +582,13 @@ static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, 
   a.ibase = h->s_poa_i.as<int>(); a.ebase = h->s_poa_nk.as<int>(); a.cellsb = h->s_poa_cells.as<char>();
   a.bbase = h->s_poa_b.as<uint8_t>(); a.score = h->s_poa_sc.as<long long>();
   a.Ncap = Ncap; a.K = K; a.Pcap = Pcap; a.cells_cap = (int)cells; a.desc = h->s_poa_desc.as<uint4>(); a.jump = h->s_poa_jump.as<int>();
-  a.pbase = h->s_poa_path.as<int>(); a.overflow = d_overflow;
+  a.pbase = h->s_poa_path.as<int>(); a.overflow = d_overflow; a.overflow16 = d_overflow16;
   if (const char* e = getenv("C3_DEBUG_POA_RBSPAN")) a.rb_span = std::max(3300, atoi(e));      // (>= the 400 units below the bias + a row's growth)
   a.draft = h->d_draft.as<uint8_t>(); a.tpos = h->d_tpos.as<int32_t>();
   a.msa_dbg = nullptr; a.msa_off = nullptr; a.msa_len = nullptr;
   if (h->debug_msa) { a.msa_dbg = h->d_msa.as<uint8_t>(); a.msa_off = h->d_msa_off.as<int64_t>(); a.msa_len = h->d_msa_len.as<int>(); }
   a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
-  DBG("poa: nw=%d Ncap=%d K=%d cells=%lld slots=%d (%.1f MB per slot)%s\n", nw, Ncap, K, cells, slots, per_slot / 1048576.0, d_overflow ? "" : " [full-size pass]");
+  DBG("poa: nw=%d Ncap=%d K=%d cells=%lld slots=%d (%.1f MB per slot)%s\n", nw, Ncap, K, cells, slots, per_slot / 1048576.0, d_overflow ? "" : (d_overflow16 ? " [full-size pass]" : " [32-bit pass]"));
   // the pass with an overflow list runs the 16-bit rows; the final pass (no list) the 32-bit rows only (C3_DEBUG_POA32: test hook, first pass too)
   c3k_launch_poa(&a, slots, w32 ? 1 : 0, wide_ring, h->stream);
   HIPCHK(hipGetLastError());
@@ -626,26 +626,35 @@ static int run_poa(c3_handle* h) {
     HIPCHK(hipMemsetAsync(h->d_msa_len.p, 0, sizeof(int) * h->n, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
   }
-  HIPCHK(h->d_overflow.ensure(sizeof(int) * (size_t)nw));
+  HIPCHK(h->d_overflow.ensure(sizeof(int) * 2 * (size_t)nw));
   HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));                       // work queue only: [2..3] already holds the zero-repeat cells
   HIPCHK(hipMemsetAsync(h->d_counter.as<char>() + 16, 0, 240, h->stream));       // [4] overflow count, phase counters
-  const bool two_pass = true;          // (always: a read whose scores leave the 16-bit cells of the first pass is redone by the second, 32-bit one)
   // ring geometry of the first pass: subreads beyond the LDS query copy (1792 bases) or with bands beyond two 64-column chunks
   // (w = band_b + band_f * Q; a row holds 2w+1 columns + the drift of its predecessors' maxima) take the WIDE instance
   // (4 ring rows of 192 cells, sliding query window); C3_DEBUG_POA_WIDE = 0 / 1 forces one (test hook)
   int wide_ring = (max_q > 1792 || 2 * w + 1 + 24 > 128) ? 1 : 0;
   if (const char* e_ = getenv("C3_DEBUG_POA_WIDE")) wide_ring = atoi(e_) ? 1 : 0;
-  int rc = launch_poa(h, h->d_work.as<int>(), nw, Ncap, K, Pcap, cells, two_pass ? h->d_overflow.as<int>() : nullptr, 24, wide_ring);
+  // pass 1: scratch for the typical alignment.  Its two lists: reads the scratch was too small for -> pass 2 (the same kernel, worst-case
+  // scratch); reads with a score beyond the 16-bit cells (from either pass) -> pass 3 (the 32-bit instance, worst-case scratch)
+  int* ovA = h->d_overflow.as<int>(); int* ovB = h->d_overflow.as<int>() + nw;
+  int rc = launch_poa(h, h->d_work.as<int>(), nw, Ncap, K, Pcap, cells, ovA, ovB, 24, wide_ring);
   if (rc) return rc;
   h->n_poa_redo = 0; h->n_poa_redo16 = 0;
-  if (two_pass) {
+  {
     int cnt[8];
     HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 32, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     if (cnt[4] > 0) {
-      h->n_poa_redo = cnt[4]; h->n_poa_redo16 = cnt[5];
+      h->n_poa_redo = cnt[4];
       HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
-      if ((rc = launch_poa(h, h->d_overflow.as<int>(), cnt[4], Ncap_full, K, Pcap, cells_full, nullptr, 24, 0))) return rc;
+      if ((rc = launch_poa(h, ovA, cnt[4], Ncap_full, K, Pcap, cells_full, nullptr, ovB, 24, wide_ring))) return rc;
+      HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 32, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    if (cnt[5] > 0) {
+      h->n_poa_redo += cnt[5]; h->n_poa_redo16 = cnt[5];
+      HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
+      if ((rc = launch_poa(h, ovB, cnt[5], Ncap_full, K, Pcap, cells_full, nullptr, nullptr, 24, 0))) return rc;
     }
   }
   if (!h->zwork.empty()) {             // zero-repeat rescue, second half: stitch left + overlap consensus + right

@@ -22,7 +22,8 @@ struct PoaArgs {
   uint8_t* draft; int32_t* tpos; uint8_t* msa_dbg; const int64_t* msa_off; int* msa_len;
   unsigned long long* phases; uint4* desc; int* jump;
   int* pbase;               // [slots][Pcap] node of every fused base
-  int* overflow;            // first pass: reads whose scratch overflowed (count in counter[4]); nullptr in the final pass
+  int* overflow;            // reads whose scratch overflowed (count in counter[4]): redone with worst-case scratch; nullptr in the passes that have it
+  int* overflow16;          // reads with a score beyond the 16-bit cells (count in counter[5]): redone by the 32-bit instance; nullptr in that pass
   int rb_span;              // 0 = default; test hook C3_DEBUG_POA_RBSPAN: width of the window a row maximum may move in before the 16-bit base follows it
 };
 struct WLayer { int qbeg, len, begin, end; };

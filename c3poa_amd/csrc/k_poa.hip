@@ -1265,9 +1265,14 @@ __global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
     PH_MARK(7)
     // fail == 2: the scratch of this slot was too small (cells / nodes).  The first pass runs with scratch sized for the
     // TYPICAL alignment (more resident waves); such reads are queued and redone by a second launch with worst-case scratch
-    const bool redo = fail == 2 && a.overflow != nullptr;
+    // a read the slot's scratch was too small for is redone by the same kernel with worst-case scratch (list `overflow`); one whose
+    // scores left the 16-bit cells by the 32-bit instance (list `overflow16`); a pass without the list a read needs ends it
+    // (a read that still does not fit in pass 2 -- its far arena is a quarter of the cells -- goes on to the 32-bit pass, whose arenas are complete)
+    const bool to16 = punted || a.overflow == nullptr;
+    int* const olist = to16 ? a.overflow16 : a.overflow;
+    const bool redo = fail == 2 && olist != nullptr;
     if (lane == 0) {
-      if (redo) { a.overflow[atomicAdd(a.counter + 4, 1)] = rid; if (punted) atomicAdd(a.counter + 5, 1); }
+      if (redo) olist[atomicAdd(a.counter + (to16 ? 5 : 4), 1)] = rid;
       else {
         info->draft_len = C;
         if (fail) { info->status = C3_ST_LIMIT; info->draft_len = 0; }
