@@ -70,6 +70,28 @@ def configReader(path, configIn):
 _WARMERS = []            # context-warming threads of main(); joined before a one-shot process leaves
 
 
+def early_warm(n_threads):
+    """The HIP context of every GPU in use takes 1.1-1.3 s to create and everything else waits for it: start it on threads of
+    their own BEFORE numpy and the package are imported (0.3-0.5 s), with nothing but ctypes -- the library is loaded here and
+    found loaded by c3poa_amd._lib later.  Returns silently when there is no library or no GPU (main() reports that)."""
+    import ctypes
+    import threading
+    lib_path = os.environ.get("C3POA_LIB", os.path.join(PATH, "c3poa_amd", "lib", "libc3poa_hip.so"))
+    try:
+        lib = ctypes.CDLL(lib_path)
+        lib.c3_warm_device.argtypes = [ctypes.c_int]
+    except (OSError, AttributeError):
+        return
+    if os.environ.get("C3_DEVICE_MAP"):
+        devs = sorted(set(int(x) for x in os.environ["C3_DEVICE_MAP"].split(",")))
+    else:
+        devs = list(range(max(1, n_threads)))                            # (an ordinal beyond the visible GPUs returns an error code at once)
+    for dev in devs:
+        th = threading.Thread(target=lib.c3_warm_device, args=(dev,), daemon=True)
+        th.start()
+        _WARMERS.append(th)
+
+
 def main(args, one_shot=False):
     """one_shot: the process ends right after this call (the command line): the page-locked reader buffers are then left to
     process teardown instead of being unpinned one by one (1.2 s per 5 GB)"""
@@ -100,10 +122,11 @@ def main(args, one_shot=False):
     import threading
     dmap_ = [int(x) for x in os.environ["C3_DEVICE_MAP"].split(",")] if os.environ.get("C3_DEVICE_MAP") else list(range(n_dev))
 
-    warmers = [threading.Thread(target=_lib.warm_device, args=(dev,), daemon=True) for dev in sorted(set(dmap_[:n_dev]))]
-    for th in warmers:                                                       # (context only: a failure is reported by the worker's own c3_create)
-        th.start()
-    _WARMERS.extend(warmers)
+    if not _WARMERS:                                                         # (the command line has started them before its imports: early_warm)
+        warmers = [threading.Thread(target=_lib.warm_device, args=(dev,), daemon=True) for dev in sorted(set(dmap_[:n_dev]))]
+        for th in warmers:                                                   # (context only: a failure is reported by the worker's own c3_create)
+            th.start()
+        _WARMERS.extend(warmers)
     align_psl = tmp_dir + "splint_to_read_alignments.psl"
     have_psl = os.path.exists(align_psl) and os.stat(align_psl).st_size > 0
     if not have_psl and getattr(args, "splint_finder", "gpu") == "gpu":
@@ -152,6 +175,7 @@ if __name__ == "__main__":
     if not args.reads or not args.splint_file:
         print("Reads (--reads/-r) and splint (--splint_file/-s) are required", file=sys.stderr)
         sys.exit(1)
+    early_warm(args.numThreads)
     main(args, one_shot=True)
     for th_ in _WARMERS:                          # never leave while a thread is still inside HIP initialisation
         th_.join()

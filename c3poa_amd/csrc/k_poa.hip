@@ -843,7 +843,9 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       const int e = et & 0x0fffffff, ty = (int)((unsigned)et >> 28);
       const bool adj = rk >= 1 && ((A.z >> 8) & 0xff) == 1 && (int)B.x == rk - 1;       // one predecessor, the row above
       // window of 32 cells, 4-byte aligned in the arena, around column jt - lane (clamped into the slot's arena)
-      int a0 = ro + (jt - lane - 12 - b);
+      // (the path can only fall BEHIND the diagonal of the block -- a row it skips, a sibling or a vertical gap, costs a lane and no
+      // column -- except for inserted bases; so the window starts 8 columns before the diagonal and reaches 23 beyond it)
+      int a0 = ro + (jt - lane - 8 - b);
       a0 = min(max(a0, 0), c.cells_cap - 32) & ~3;
       const int w0 = a0 - ro + b;                                                          // column of window byte 0
       {
@@ -880,6 +882,24 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         // the current cell (i, j) sits in lane cl
         const int cl = it - i;
         if (!wave_bcast((int)inb, cl)) { rc = -2; break; }
+        // ---- an M move through a row that broke the run (its predecessor is not the row above, or it has several): H <- Ht <- M
+        // again, only the predecessor differs.  Taken here with a handful of lane reads instead of the state machine below (at cfg4
+        // half of the path's rows are of this kind)
+        if (st == 0 && j > 0 && wave_bcast((int)hit, cl)) {
+          const unsigned db = (unsigned)wave_bcast((int)d, cl);
+          if (((db >> 2) & 15u) == 10u) {
+            const unsigned mp1 = wave_bcast(ty, cl) == 1 ? ((unsigned)wave_bcast((int)pq, cl) & 3u) : 0u;
+            const int pr = wave_bcast(mp1 == 0 ? (int)B.x : mp1 == 1 ? (int)B.y : mp1 == 2 ? (int)B.z : (int)B.w, cl);
+            const int v1 = wave_bcast((int)A.x, cl);
+            if (lane == 0) vq[j - 1] = v1;
+            i = pr; --j;
+            if (i == 0 && j == 0) break;
+            if (i < 0) { rc = -2; break; }
+            const int drift1 = (jt - j) - (it - i);
+            if (it - i >= 64 || drift1 > 4 || drift1 < -20) break;
+            continue;
+          }
+        }
         const int v = wave_bcast((int)A.x, cl);
         const int cty = wave_bcast(ty, cl);
         const int p0 = wave_bcast((int)B.x, cl), p1 = wave_bcast((int)B.y, cl), p2 = wave_bcast((int)B.z, cl), p3 = wave_bcast((int)B.w, cl);
@@ -918,7 +938,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         if (i < 0 || j < 0) { rc = -2; break; }
         // leave the block when the row is no longer in it, or when the path has drifted too far from the block's diagonal
         const int drift = (jt - j) - (it - i);
-        if (it - i >= 64 || drift > 8 || drift < -8) break;
+        if (it - i >= 64 || drift > 4 || drift < -20) break;
       }
       WSYNC();
     }
