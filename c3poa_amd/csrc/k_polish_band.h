@@ -462,6 +462,9 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
 // in LDS, not from memory.  rq[q] = DP row aligned to query base q, 0 = insertion.
 // (a real call, like the rows: inlined into k_window the eleven-column tables pushed the kernel's register allocation over
 // the edge -- 130 more bytes of scratch per lane, every reload a vector load that waits for all older stores)
+#ifndef WB_TB_SHIFT
+#define WB_TB_SHIFT 3     /* columns the traceback windows of a block sit to the right of its diagonal */
+#endif
 __device__ __attribute__((noinline)) void win_traceback_band(int* cI, int* cE, uint8_t* cD, uint4* crdesc, int cK, int cn, int cNcap, int CB_, int R_, int Q_, int r_,
                                                              int mw_, int big_, unsigned long long* prof_) {
   WCtx c;
@@ -521,14 +524,14 @@ __device__ __attribute__((noinline)) void win_traceback_band(int* cI, int* cE, u
         const int rm = min(g * RPW + RPW / 2 + 1, rt);
         const int km = min(rt - rm, 63);
         const int lom = km == 0 ? lo_t : lo_t - (__popcll(sd0 >> (64 - km)) + 2 * __popcll(sd1 >> (64 - km)));
-        const int om = min(max(jt - km - lom, 0), BW - 1);
+        const int om = min(max(jt - km - lom + WB_TB_SHIFT, 0), BW - 1);       // (+: a path falls BEHIND its block's diagonal -- a skipped row costs a lane and no column)
         const int l0 = min(max(((om * cdiv) >> 16) - LW / 2, 0), 64 - LW);
         WD[s] = DW[(size_t)g * 64 + l0 + ln];
         if (ln == 0) WL0[wi] = l0;
       }
     }
     // ---- predecessor-index bytes of this lane's row (rows with several predecessors only)
-    const int oe = min(max(jt - lane - lok, 0), BW - 1);
+    const int oe = min(max(jt - lane - lok + WB_TB_SHIFT, 0), BW - 1);
     const int pl0 = min(max(((oe * cdiv) >> 16) - 1, 0), 60);
     if (rowv && !two) {
       const unsigned* src = PX + (size_t)rk * 64 + pl0;
@@ -600,7 +603,7 @@ __device__ __attribute__((noinline)) void win_traceback_band(int* cI, int* cE, u
       }
       if (r <= 0 || j <= 0) break;
       const int drift = (jt - j) - (rt - r);
-      if (rt - r >= 64 || drift > 5 || drift < -5) break;
+      if (rt - r >= 64 || drift > 5 - WB_TB_SHIFT || drift < -5 - WB_TB_SHIFT) break;
     }
 #ifdef C3_PHASE_PROF
     prof[3] += __builtin_readcyclecounter() - tb_t1;

@@ -11,9 +11,16 @@ for P in "$P1" "$P2"; do
   i=$((i+1))
   timeout 300 rocprofv3 --kernel-trace --pmc $P -d $R/p$i -o b -- python3 tools/phase_prof.py $N $CFG > $R/p$i.log 2>&1
 done
-python3 - <<PY
-import sqlite3, glob
+python3 - <<PY | tee $R/summary.txt
+import sqlite3, glob, ast
 from collections import defaultdict
+tm = {}
+try:
+    tm = ast.literal_eval([l for l in open("$R/p1.log").read().splitlines() if l.startswith("{'ms_")][0])
+except Exception:
+    pass
+print("# tools/pmc_sq.sh $N $CFG: rocprofv3 --kernel-trace --pmc (two passes of 8 SQ counters) on python3 tools/phase_prof.py $N $CFG (shipped build)")
+print("# counted DP cells of the batch: poa %s, polish full matrices %s, polish computed %s" % (tm.get("cells_poa"), tm.get("cells_polish"), tm.get("cells_polish_computed")))
 val = defaultdict(dict); dur = {}
 for f in glob.glob("$R/p*/*results.db"):
     db = sqlite3.connect(f)
@@ -25,4 +32,8 @@ for n, d in sorted(val.items(), key=lambda t: -dur.get(t[0], 0)):
     wc = d.get("SQ_WAVE_CYCLES", 1.0)
     print("%-10s %.1f ms" % (n, dur[n] / 1e6), " ".join("%s=%.3g" % (k.replace("SQ_", ""), v) for k, v in sorted(d.items())))
     print("           per wave-cycle: " + " ".join("%s=%.3f" % (k.replace("SQ_", ""), d[k] / wc) for k in sorted(d) if k != "SQ_WAVE_CYCLES"))
+    cells = tm.get("cells_poa") if n.startswith("k_poa") else tm.get("cells_polish_computed") if n.startswith("k_window") else None
+    if cells and "SQ_INSTS_VALU" in d:
+        print("           per counted cell: %.3f vector wave-instructions (= %.0f lane operations), %.3f scalar instructions" % (
+            d["SQ_INSTS_VALU"] / cells, 64 * d["SQ_INSTS_VALU"] / cells, d.get("SQ_INSTS_SALU", 0) / cells))
 PY
