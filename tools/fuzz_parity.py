@@ -70,8 +70,9 @@ for i in range(len(reads)):
                 i, len(reads[i][0]), strands[i], res[i]["status"], res[i]["n_sub"], len(cons[i]), o.status, o.n_sub, len(ocons[i])))
 st = np.bincount(res["status"], minlength=6)
 t = h.timing()
-print("reads %d  mismatches %d  statuses OK/NA/NOPEAK/NOCONS/SHORT/LIMIT = %s  band layers %d fallback %d (verify mode: layers whose band and full tracebacks differ %d) computed/full cells %.3f" % (
-    len(reads), bad, st.tolist(), t["n_band_layers"], t["n_band_fallback"], t["n_band_mismatch"], t["cells_polish_computed"] / max(t["cells_polish"], 1)))
+print("reads %d  mismatches %d  statuses OK/NA/NOPEAK/NOCONS/SHORT/LIMIT = %s  band layers %d fallback %d (verify mode: layers whose band and full tracebacks differ %d) computed/full cells %.3f  POA second pass %d reads (of them beyond 16-bit cells / far arena: %d)" % (
+    len(reads), bad, st.tolist(), t["n_band_layers"], t["n_band_fallback"], t["n_band_mismatch"], t["cells_polish_computed"] / max(t["cells_polish"], 1),
+    t["n_poa_redo"], t["n_poa_redo16"]))
 if t["n_band_mismatch"]:
     sys.exit(2)
 sys.exit(1 if bad else 0)
