@@ -17,7 +17,13 @@ def kname(raw):
     """kernel name without return type / arguments; k_window is a template (<false> = the launch that does the work, <true> =
     the full-size second launch for windows that overflowed the first launch's DP scratch)"""
     k = raw.split("(")[0].replace("void ", "")
-    return k.replace("k_window<false>", "k_window").replace("k_window<true>", "k_window_second_launch")
+    import re
+    k = k.replace("k_window<false>", "k_window").replace("k_window<true>", "k_window_second_launch")
+    # k_poa<W32, DEF, WIDE>: the first-pass instances are "k_poa", the 32-bit pass its own line
+    m = re.match(r"k_poa<(true|false), (true|false), (true|false)>", k)
+    if m:
+        k = "k_poa_32bit_pass" if m.group(1) == "true" else "k_poa"
+    return k
 
 
 def kernel_src_sha(root):
