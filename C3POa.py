@@ -175,7 +175,8 @@ if __name__ == "__main__":
     if not args.reads or not args.splint_file:
         print("Reads (--reads/-r) and splint (--splint_file/-s) are required", file=sys.stderr)
         sys.exit(1)
-    early_warm(args.numThreads)
+    if not os.environ.get("C3_NO_EARLY_WARM"):          # (A/B hook of tools/cli_throughput.py)
+        early_warm(args.numThreads)
     main(args, one_shot=True)
     for th_ in _WARMERS:                          # never leave while a thread is still inside HIP initialisation
         th_.join()

@@ -80,7 +80,7 @@ typedef struct {
   float ms_pack, ms_conk, ms_peaks, ms_poa, ms_prep, ms_window, ms_stitch, ms_total;
   int64_t n_reads, n_bases, n_windows;
   int64_t cells_conk, cells_poa, cells_polish;
-  int64_t n_poa_redo;      /* reads whose POA scratch (sized for the typical alignment) overflowed and were redone full-size */
+  int64_t n_poa_redo;      /* reads whose POA scratch (sized for the typical alignment) overflowed and were redone full-size, plus n_poa_redo16 */
   float ms_wall;           /* host wall time of the whole c3_batch_run call; ms_wall - ms_total = time the GPU waited for the host */
   float ms_host_worklist;  /* of which: building + uploading the POA work list on the host (timer starts AFTER the wait for k_conk / k_peaks) */
   float ms_alloc;          /* of which: growing device scratch buffers (only while batch shapes are still growing) */
@@ -90,7 +90,7 @@ typedef struct {
   int64_t n_band_layers, n_band_fallback;   /* window layers aligned in a band and accepted / redone unbanded after a failed certificate */
   int64_t n_band_mismatch;                  /* C3_DEBUG_BAND=verify only: accepted band layers whose traceback differs from the full matrix's (must be 0) */
   int64_t n_win_redo;                       /* windows with a layer beyond the first launch's DP scratch, redone by the full-size second launch of k_window */
-  int64_t n_poa_redo16;                     /* of n_poa_redo: reads handed to the 32-bit second POA pass because a score did not fit the 16-bit cells of the first (0 on the config shapes) */
+  int64_t n_poa_redo16;                     /* of n_poa_redo: reads redone by the 32-bit POA pass -- a score did not fit the 16-bit cells of the first passes, or the 32-bit cells of its wide / far rows did not fit the arena of the full-size pass (0 on the config shapes) */
 } c3_timing;
 
 typedef struct c3_handle c3_handle;
