@@ -68,6 +68,15 @@ def test_cfg4_2k_long_reads_wide_band():
     assert np.median(res["n_sub"][res["status"] == 0]) == 12
 
 
+def test_cfgL_long_inserts_one_batch():
+    """not a BASELINE config: 3 and 6 kb inserts, 3-5 repeats (reads of 10-32 kb) -- subreads beyond the LDS query copy and bands
+    of 145-250 columns, i.e. the WIDE kernel instance of k_poa: sharding invariance, counted cells, oracle
+    equality on a sample, and no read in the 32-bit pass"""
+    res = _whole_vs_shards_vs_oracle("cfgL", 1536, 16, 0.995, 0.95)
+    ns = res["n_sub"][res["status"] == 0]
+    assert ns.min() >= 2 and ns.max() <= 6
+
+
 # ---- cfg5: the streamed CLI -------------------------------------------------------------------------------------------
 
 def _write_inputs(tmp_path, recs, with_psl):
