@@ -12,6 +12,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <climits>
 #include <cmath>
@@ -65,8 +66,28 @@ struct BatchSet {
 
 }  // namespace
 
+// BGZF input (bgzip / htslib): a gzip file made of independent members of <= 64 KiB whose header carries the member's size
+// (extra subfield 'B','C'), so the members of a stretch of the file can be located WITHOUT inflating them and inflated by several
+// threads at once -- a plain gzip stream is one zlib state and inflates at ~275 MB/s whatever the machine (27 k reads/s:
+// profiles/r04_host_ceiling_gz.txt).  Plain gzip stays on gzread.
+struct BgzfStretch {
+  std::vector<unsigned char> comp;          // compressed members of the stretch, back to back
+  std::vector<size_t> coff, csz, doff;      // per member: offset / size in comp, offset of its data in dec
+  std::vector<char> dec;                    // inflated stretch
+  size_t dend = 0;
+};
+struct Bgzf {
+  FILE* fp = nullptr;
+  int threads = 1;
+  BgzfStretch st[2];                        // the stretch being parsed and the one being read + inflated beside it
+  int cur = 0;
+  size_t dpos = 0;                          // unread part of st[cur].dec starts here
+  std::thread pre; bool pre_on = false, pre_ok = false;
+  std::atomic<bool> eof{false}, bad{false};  // (written by the prefetch thread, read by the parser)
+};
+
 struct c3_reader {
-  FILE* fp = nullptr; gzFile gz = nullptr;
+  FILE* fp = nullptr; gzFile gz = nullptr; Bgzf* bz = nullptr;
   std::vector<char> buf; size_t beg = 0, end = 0; bool eof = false;
   std::vector<BatchSet> sets; int cur = -1;
   std::string err;
@@ -81,13 +102,120 @@ struct c3_reader {
 
 namespace {
 
+// header of a BGZF member at p (n bytes available): total member size, or 0 when it is not one
+size_t bgzf_member_size(const unsigned char* p, size_t n) {
+  if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+  const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8);
+  if (12 + xlen > n) return 0;
+  for (size_t q = 12; q + 4 <= 12 + xlen;) {
+    const size_t slen = (size_t)p[q + 2] | ((size_t)p[q + 3] << 8);
+    if (p[q] == 'B' && p[q + 1] == 'C' && slen == 2 && q + 6 <= 12 + xlen) return ((size_t)p[q + 4] | ((size_t)p[q + 5] << 8)) + 1;
+    q += 4 + slen;
+  }
+  return 0;
+}
+
+// inflate one member (raw deflate between the header and the 8-byte trailer), checking its CRC and size
+bool bgzf_inflate(const unsigned char* m, size_t msz, char* out, size_t osz) {
+  const size_t xlen = (size_t)m[10] | ((size_t)m[11] << 8);
+  const size_t hdr = 12 + xlen;
+  if (msz < hdr + 8) return false;
+  z_stream z; memset(&z, 0, sizeof(z));
+  if (inflateInit2(&z, -15) != Z_OK) return false;
+  z.next_in = const_cast<unsigned char*>(m + hdr); z.avail_in = (unsigned)(msz - hdr - 8);
+  z.next_out = (unsigned char*)out; z.avail_out = (unsigned)osz;
+  const int rc = inflate(&z, Z_FINISH);
+  const bool ok = rc == Z_STREAM_END && z.avail_out == 0;
+  inflateEnd(&z);
+  if (!ok) return false;
+  const unsigned char* t = m + msz - 8;
+  const unsigned long crc = (unsigned long)t[0] | ((unsigned long)t[1] << 8) | ((unsigned long)t[2] << 16) | ((unsigned long)t[3] << 24);
+  return crc32(crc32(0L, Z_NULL, 0), (const unsigned char*)out, (unsigned)osz) == crc;
+}
+
+// next stretch of the file: up to `max_members` members read, located by their headers, inflated by b->threads threads
+bool bgzf_next_stretch(Bgzf* bz, BgzfStretch* b, size_t max_members = 512) {
+  b->comp.clear(); b->coff.clear(); b->csz.clear(); b->doff.clear();
+  b->dend = 0;
+  size_t dtot = 0;
+  unsigned char hd[18];
+  while (b->coff.size() < max_members && !bz->eof) {
+    const size_t got = fread(hd, 1, 18, bz->fp);
+    if (got == 0) { bz->eof = true; break; }
+    if (got < 18) { bz->bad = true; return false; }
+    // the fixed part of the header holds the BC subfield when it comes first (every writer puts it there); otherwise read on
+    size_t msz = bgzf_member_size(hd, 18);
+    const size_t at = b->comp.size();
+    if (!msz) {
+      const size_t xlen = (size_t)hd[10] | ((size_t)hd[11] << 8);
+      if (hd[0] != 0x1f || hd[1] != 0x8b || !(hd[3] & 4) || xlen > 65535) { bz->bad = true; return false; }
+      b->comp.resize(at + 12 + xlen);
+      memcpy(b->comp.data() + at, hd, 18);
+      if (12 + xlen > 18 && fread(b->comp.data() + at + 18, 1, 12 + xlen - 18, bz->fp) != 12 + xlen - 18) { bz->bad = true; return false; }
+      msz = bgzf_member_size(b->comp.data() + at, 12 + xlen);
+      if (!msz || msz < 12 + xlen + 8) { bz->bad = true; return false; }
+      const size_t have = 12 + xlen;
+      b->comp.resize(at + msz);
+      if (fread(b->comp.data() + at + have, 1, msz - have, bz->fp) != msz - have) { bz->bad = true; return false; }
+    } else {
+      if (msz < 26) { bz->bad = true; return false; }
+      b->comp.resize(at + msz);
+      memcpy(b->comp.data() + at, hd, 18);
+      if (fread(b->comp.data() + at + 18, 1, msz - 18, bz->fp) != msz - 18) { bz->bad = true; return false; }
+    }
+    const unsigned char* t = b->comp.data() + at + msz - 4;
+    const size_t isz = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+    if (isz > (1u << 16)) { bz->bad = true; return false; }
+    if (isz == 0) continue;                                  // the empty end-of-file member (or an empty one in between)
+    b->coff.push_back(at); b->csz.push_back(msz); b->doff.push_back(dtot);
+    dtot += isz;
+  }
+  if (b->coff.empty()) return false;
+  b->dec.resize(dtot);
+  const size_t nm = b->coff.size();
+  auto work = [&](size_t t0, size_t step, bool* ok) {
+    for (size_t i = t0; i < nm; i += step) {
+      const size_t osz = (i + 1 < nm ? b->doff[i + 1] : dtot) - b->doff[i];
+      if (!bgzf_inflate(b->comp.data() + b->coff[i], b->csz[i], b->dec.data() + b->doff[i], osz)) { *ok = false; return; }
+    }
+  };
+  const size_t nt = std::min<size_t>((size_t)std::max(1, bz->threads), nm);
+  std::vector<char> oks(nt, 1);
+  std::vector<std::thread> th;
+  for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t, nt, (bool*)&oks[t]);
+  work(0, nt, (bool*)&oks[0]);
+  for (auto& x : th) x.join();
+  for (char o : oks) if (!o) { bz->bad = true; return false; }
+  b->dend = dtot;
+  return true;
+}
+
+// bytes of the inflated file, in order.  While the parser works through one stretch the next one is read and inflated on a
+// thread of its own (which fans out to b->threads inflaters): the reader thread only waits when inflating is the slower side
+long bgzf_read(Bgzf* b, char* dst, size_t room) {
+  if (b->dpos == b->st[b->cur].dend) {
+    if (b->pre_on) { b->pre.join(); b->pre_on = false; if (b->pre_ok) { b->cur ^= 1; b->dpos = 0; } else b->st[b->cur].dend = b->dpos = 0; }
+    else { if (b->bad || !bgzf_next_stretch(b, &b->st[b->cur])) return b->bad ? -1 : 0; b->dpos = 0; }
+    if (b->bad) return -1;
+    if (b->st[b->cur].dend == 0) return 0;
+    if (!b->eof) { BgzfStretch* nx = &b->st[b->cur ^ 1]; b->pre_on = true; b->pre = std::thread([b, nx]() { b->pre_ok = bgzf_next_stretch(b, nx); }); }
+  }
+  BgzfStretch& c = b->st[b->cur];
+  const size_t k = std::min(room, c.dend - b->dpos);
+  memcpy(dst, c.dec.data() + b->dpos, k);
+  b->dpos += k;
+  return (long)k;
+}
+
 bool refill(c3_reader* r) {
   if (r->eof) return false;
   if (r->beg > 0) { memmove(r->buf.data(), r->buf.data() + r->beg, r->end - r->beg); r->end -= r->beg; r->buf_off += (int64_t)r->beg; r->beg = 0; }
   if (r->end == r->buf.size()) r->buf.resize(r->buf.size() * 2);
   size_t room = r->buf.size() - r->end;
-  long got = r->gz ? (long)gzread(r->gz, r->buf.data() + r->end, (unsigned)std::min<size_t>(room, 1u << 30))
+  long got = r->bz ? bgzf_read(r->bz, r->buf.data() + r->end, room)
+           : r->gz ? (long)gzread(r->gz, r->buf.data() + r->end, (unsigned)std::min<size_t>(room, 1u << 30))
                    : (long)fread(r->buf.data() + r->end, 1, room, r->fp);
+  if (got < 0 && r->bz) r->err = "BGZF input: a member is damaged (size, inflate or CRC)";
   if (got <= 0) { r->eof = true; return false; }
   r->end += (size_t)got;
   return true;
@@ -149,9 +277,23 @@ extern "C" int c3_reader_open(const char* path, int n_sets, c3_reader** out) {
   if (!path || !out) return C3_E_ARG;
   c3_reader* r = new c3_reader();
   size_t n = strlen(path);
-  if (n > 3 && strcmp(path + n - 3, ".gz") == 0) { r->gz = gzopen(path, "rb"); if (r->gz) gzbuffer(r->gz, 1 << 20); }
+  if (n > 3 && strcmp(path + n - 3, ".gz") == 0) {
+    // BGZF (bgzip): members located by their headers and inflated in parallel; any other gzip file: one zlib stream
+    unsigned char hd[18]; size_t got = 0;
+    FILE* f = fopen(path, "rb");
+    if (f) { got = fread(hd, 1, 18, f); }
+    if (f && got == 18 && bgzf_member_size(hd, 18) && !getenv("C3_NO_BGZF")) {
+      rewind(f);
+      r->bz = new Bgzf(); r->bz->fp = f;
+      const char* e = getenv("C3_GZ_THREADS");
+      r->bz->threads = e ? std::max(1, atoi(e)) : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    } else {
+      if (f) fclose(f);
+      r->gz = gzopen(path, "rb"); if (r->gz) gzbuffer(r->gz, 1 << 20);
+    }
+  }
   else r->fp = fopen(path, "rb");
-  if (!r->gz && !r->fp) { delete r; return C3_E_ARG; }
+  if (!r->gz && !r->fp && !r->bz) { delete r; return C3_E_ARG; }
   { FILE* f = fopen(path, "rb"); if (f) { fseek(f, 0, SEEK_END); long z = ftell(f); r->file_bytes = z > 0 ? (size_t)z : 0; fclose(f); } }
   r->buf.resize((size_t)16 << 20);
   r->sets.resize((size_t)std::max(1, n_sets));
@@ -237,6 +379,7 @@ extern "C" void c3_reader_close(c3_reader* r) {
   if (!r) return;
   if (r->gz) gzclose(r->gz);
   if (r->fp) fclose(r->fp);
+  if (r->bz) { if (r->bz->pre_on) r->bz->pre.join(); if (r->bz->fp) fclose(r->bz->fp); delete r->bz; }
   delete r;
 }
 
@@ -327,11 +470,11 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
       // file / byte range (the other half are qualities), and only as many buffer sets as those bytes can fill are page-locked
       // now (a 100-read input used to pin ten buffers of max_reads reads each)
       size_t deliver = (size_t)-1;
-      if (!r->gz && r->file_bytes) {
+      if (!r->gz && !r->bz && r->file_bytes) {
         const int64_t stop = r->range_end >= 0 ? std::min<int64_t>(r->range_end + (int64_t)(4 * sl + 4096), (int64_t)r->file_bytes) : (int64_t)r->file_bytes;
         const int64_t here = r->buf_off + (int64_t)r->beg;
         deliver = (size_t)std::max<int64_t>(0, stop - here) / 2 + sb + sl + 4096;
-      } else if (r->gz && r->file_bytes) deliver = r->file_bytes * 16 + sb + sl + 4096;        // (compressed size: a generous bound)
+      } else if ((r->gz || r->bz) && r->file_bytes) deliver = r->file_bytes * 16 + sb + sl + 4096;        // (compressed size: a generous bound)
       want = std::min(want, std::max(deliver, sb + sl + 4096));
       if (!s.seqs.reserve(want, sb + sl) || !s.quals.reserve(want, sb + sl)) return C3_E_NOMEM;
       // ... and the other buffer sets of this reader right away: a page-lock issued later, while the GPU is busy, stalls the
@@ -347,6 +490,7 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
     nn += name_len; nb += sl; ++n;
     s.name_off.push_back((int64_t)nn); s.off.push_back((int64_t)nb);
   }
+  if (r->bz && r->bz->bad) return fail(r, "BGZF input: a member is damaged (header, size, inflate or CRC)");      // never a silently short file
   s.n_names = nn; s.n_bases = nb;
   r->hint_bases = std::max(r->hint_bases, nb);
   out->n = n; out->n_short = n_short;

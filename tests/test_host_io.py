@@ -388,3 +388,53 @@ def test_multi_line_fastq_ranges_are_reported_and_last_record_without_newline(tm
     open(pf, "w").write(">a\nACGT\n>b\nGGCC\n")
     rf = _lib.Reader(pf, n_sets=1)
     assert rf.next(10).n == 2 and rf.noqual() == 2
+
+
+def _bgzf_write(path, data, block=0xff00, extra_first=False):
+    """a BGZF file (bgzip / htslib layout): independent gzip members of <= 64 KiB, each with the 'BC' extra subfield holding the
+    member's size - 1, and the empty end-of-file member"""
+    import struct
+    import zlib
+    with open(path, "wb") as f:
+        for i in range(0, len(data), block):
+            chunk = data[i:i + block]
+            co = zlib.compressobj(6, zlib.DEFLATED, -15)
+            comp = co.compress(chunk) + co.flush()
+            xtra = (b"XY" + struct.pack("<H", 3) + b"abc") if extra_first else b""
+            xlen = 6 + len(xtra)
+            total = 12 + xlen + len(comp) + 8
+            f.write(struct.pack("<BBBBIBBH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, xlen) + xtra + b"BC" + struct.pack("<HH", 2, total - 1)
+                    + comp + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+
+
+def test_bgzf_input_is_inflated_in_parallel_and_equals_the_plain_file(tmp_path, monkeypatch):
+    """bgzip-compressed FASTQ (mm.fastx_read reads any gzip, C3POa.py:201,239): the native reader locates the members by their
+    headers and inflates them on several threads; records that straddle members, more members than one stretch holds (512),
+    a foreign extra subfield in front of 'BC', one thread or five -- always the records of the plain file; a damaged member is an
+    error, not a short file; ordinary gzip keeps the single-stream path"""
+    import gzip as _gz
+    recs = [(r[0], r[1], r[2]) for r in synth.generate("cfg1", n_reads=23)]
+    plain = str(tmp_path / "a.fastq")
+    _write_fastq(plain, recs)
+    data = open(plain, "rb").read()
+    for block, extra, threads in ((0xff00, False, "5"), (301, False, "5"), (301, False, "1"), (4096, True, "3")):
+        pz = str(tmp_path / ("b%d_%d.fastq.gz" % (block, extra)))
+        _bgzf_write(pz, data, block, extra)
+        assert _gz.open(pz, "rb").read() == data                         # (a valid multi-member gzip file for everybody else)
+        monkeypatch.setenv("C3_GZ_THREADS", threads)
+        assert _all(pz, 7)[0] == recs, (block, extra, threads)
+        assert len(data) // block + 1 > 512 or block != 301              # the small blocks really span several stretches
+    monkeypatch.setenv("C3_NO_BGZF", "1")                                # the same file through zlib's stream reader
+    assert _all(str(tmp_path / "b301_0.fastq.gz"), 7)[0] == recs
+    monkeypatch.delenv("C3_NO_BGZF")
+    # a flipped byte in the middle of a member: CRC / inflate error -> the reader fails loudly
+    bad = bytearray(open(str(tmp_path / "b65280_0.fastq.gz"), "rb").read())
+    bad[len(bad) // 2] ^= 0x55
+    pb = str(tmp_path / "bad.fastq.gz")
+    open(pb, "wb").write(bytes(bad))
+    with pytest.raises(ValueError):
+        _all(pb, 7)
+    # names-only pass and the length cut-off behave as on plain input
+    got, short, _z = _all(str(tmp_path / "b301_0.fastq.gz"), 6, min_len=sorted(len(r[1]) for r in recs)[5])
+    assert short == 5 and len(got) == 18

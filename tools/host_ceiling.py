@@ -77,6 +77,34 @@ class InstantHandle:
         pass
 
 
+def _bgzf_chunk(args):
+    import struct
+    import zlib
+    path, beg, end = args
+    out = []
+    with open(path, "rb") as f:
+        f.seek(beg)
+        data = f.read(end - beg)
+    for i in range(0, len(data), 0xff00):
+        chunk = data[i:i + 0xff00]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        comp = co.compress(chunk) + co.flush()
+        out.append(struct.pack("<BBBBIBBH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6) + b"BC" + struct.pack("<HH", 2, len(comp) + 25) + comp
+                   + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+    return b"".join(out)
+
+
+def bgzf_compress(src, dst, procs=16):
+    """bgzip layout (independent members of <= 64 KiB with the 'BC' size subfield + the empty end member), written with zlib"""
+    size = os.path.getsize(src)
+    step = 0xff00 * 256
+    jobs = [(src, b, min(b + step, size)) for b in range(0, size, step)]
+    with mp.Pool(procs) as pool, open(dst, "wb") as f:
+        for part in pool.imap(_bgzf_chunk, jobs):
+            f.write(part)
+        f.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+
+
 def _gen(job):
     s0, cnt, path = job
     st = []
@@ -93,6 +121,7 @@ def main():
     ap.add_argument("--dir", default="/dev/shm")
     ap.add_argument("--workers", default="1,2,4,8")
     ap.add_argument("--gz", action="store_true")
+    ap.add_argument("--bgzf", action="store_true", help="BGZF-compressed input (bgzip layout): members inflated in parallel by the native reader")
     ap.add_argument("--unique", type=int, default=100000, help="distinct reads generated; the file repeats them (names stay distinct)")
     a = ap.parse_args()
     d = tempfile.mkdtemp(prefix="c3host_", dir=a.dir)
@@ -114,6 +143,8 @@ def main():
         n_total = ((a.n + nu - 1) // nu) * nu
         if a.gz:
             os.system("gzip -1 %s" % fq); fq += ".gz"
+        elif a.bgzf:
+            bgzf_compress(fq, fq + ".gz"); os.remove(fq); fq += ".gz"
         size = os.path.getsize(fq)
         print("generated %d reads (%d distinct), %.2f GB in %.1f s" % (n_total, nu, size / 1e9, time.time() - t0), file=sys.stderr)
         sd = {"Splint1": [synth.SPLINT1, revcomp(synth.SPLINT1)]}
@@ -139,7 +170,7 @@ def main():
             assigner.close()
             osz = sum(os.path.getsize(out + "Splint1/" + f) for f in os.listdir(out + "Splint1"))
             print(json.dumps({"workers": w, "reads": n, "seconds": round(dt, 2), "reads_per_s": round(n / dt, 1), "input_GB": round(size / 1e9, 2),
-                              "output_GB": round(osz / 1e9, 2), "gz": a.gz, "ranges": st.get("ranges"), "psl_table_s": round(t_psl, 2),
+                              "output_GB": round(osz / 1e9, 2), "gz": "bgzf" if a.bgzf else a.gz, "gz_threads": os.environ.get("C3_GZ_THREADS"), "ranges": st.get("ranges"), "psl_table_s": round(t_psl, 2),
                               "stage_s": {k: round(st[k], 2) for k in ("parse", "assign", "upload", "fetch", "write", "wait_in", "wait_out") if k in st}}))
             shutil.rmtree(out, ignore_errors=True)
     finally:
