@@ -51,3 +51,20 @@ def test_world_size_must_match_gpus():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--reads", "8"],
                        capture_output=True, text=True, env=env, timeout=280)
     assert p.returncode != 0 and "WORLD_SIZE=2" in (p.stderr + p.stdout)
+
+
+def test_pmc_traffic_is_tied_to_the_kernel_sources():
+    """roofline.traffic comes from a committed rocprofv3 --pmc summary; bench.py only uses it when that summary was measured on the
+    kernels that are running (hash of c3poa_amd/csrc/*.hip + *.h, the same in tools/collect_profiles.py)"""
+    import glob
+    import json
+    import bench
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import collect_profiles
+    sha = bench.kernel_src_sha()
+    assert sha == collect_profiles.kernel_src_sha(ROOT) and len(sha) == 16
+    newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic_cfg2_100k.json")))[-1]
+    pm = json.load(open(newest))
+    # the newest committed summary either matches the sources (traffic reported) or is declared stale by bench.py (traffic null)
+    assert "kernels" in pm and ("kernel_src_sha" not in pm or isinstance(pm["kernel_src_sha"], str))
+    assert "k_poa" in pm["kernels"] or any(k.startswith("k_poa") for k in pm["kernels"])
