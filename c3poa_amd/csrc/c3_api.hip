@@ -495,22 +495,26 @@ static int run_zero(c3_handle* h) {
   HIPCHK(h->d_zflag.ensure((size_t)h->n + 16));
   HIPCHK(hipMemsetAsync(h->d_zflag.p, 0, (size_t)h->n, h->stream));
   if (!h->cfg.zero || h->injected) return 0;
-  long long dmax = 0;
+  long long dmax = 0; int fmax = 0;
   for (int i = 0; i < h->n; ++i) {
     const Summary& s = h->sum[i];
-    if (s.status == C3_ST_NO_CONSENSUS && s.n_sub == 0 && s.front > 0 && s.tail > 0 && s.front <= 4096 &&
-        (long long)s.front * s.tail <= (16 << 20)) {
+    if (s.status == C3_ST_NO_CONSENSUS && s.n_sub == 0 && s.front > 0 && s.tail > 0 &&
+        (long long)s.front * s.tail <= (16 << 20)) {                       // (oracle/c3o_zero.c: zr_max_cells)
       h->zwork.push_back(i);
       dmax = std::max(dmax, (long long)(s.front + 1) * (s.tail + 1));
+      fmax = std::max(fmax, s.front);
     }
   }
   const int nz = (int)h->zwork.size();
   if (nz == 0) return 0;
   const int grid = std::min(nz, 512);
   HIPCHK(h->d_zwork.ensure(sizeof(int) * (size_t)nz)); HIPCHK(h->d_zinfo.ensure(sizeof(int4) * (size_t)h->n));
-  HIPCHK(h->s_zero_d.ensure((size_t)dmax * grid + 64));
+  dmax = (dmax + 15) & ~15LL;
+  const int rowcap = fmax > 4096 ? fmax : 0;                                // k_zero: ZW columns live in LDS
+  const long long dstride = dmax + (rowcap ? (((long long)(rowcap + 1) * 8 + 15) & ~15LL) : 0);
+  HIPCHK(h->s_zero_d.ensure((size_t)dstride * grid + 64));
   HIPCHK(hipMemcpyAsync(h->d_zwork.p, h->zwork.data(), sizeof(int) * (size_t)nz, hipMemcpyHostToDevice, h->stream));
-  ZeroArgs z; fill_zero_args(h, z, nz); z.dcap = dmax;
+  ZeroArgs z; fill_zero_args(h, z, nz); z.dcap = dmax; z.dstride = dstride; z.rowcap = rowcap;
   DBG("zero: nz=%d grid=%d dmax=%lld\n", nz, grid, dmax);
   c3k_launch_zero(&z, grid, h->stream);
   HIPCHK(hipGetLastError());

@@ -57,13 +57,15 @@ struct StitchArgs {
 struct AdapterArgs {
   C3Batch b; C3Params p; int* counter;
   const uint8_t* ad_codes; const int* ad_len; int n_ad;
-  uint8_t* D; long long dcap;           // [grid][dcap] direction bytes
+  uint8_t* D; long long dcap, dstride;  // [grid][dstride]: dcap direction bytes, then two rows of rowcap + 1 ints
+  int rowcap;                           // (H and E of the previous row for front pieces beyond the LDS rows; 0 = none)
   int32_t* out;                         // [n * n_ad * 2][12]
 };
 
 struct ZeroArgs {
   C3Batch b; C3Info* info; C3Params p; int* counter; const int* work; int n_work;
-  uint8_t* D; long long dcap;           // [grid][dcap] direction bytes
+  uint8_t* D; long long dcap, dstride;  // [grid][dstride]: dcap direction bytes, then two rows of rowcap + 1 ints
+  int rowcap;                           // (H and E of the previous row for front pieces beyond the LDS rows; 0 = none)
   int4* zinfo; uint8_t* zflag;          // per read: r_st, r_en, q_st, q_en; rescue in progress / done
   const uint8_t* draft; char* cons;
 };

@@ -5,7 +5,8 @@
 // alignment of d1 = read[tail_beg:] (rows) against d0 = read[:front_end] (columns) with affine gaps and
 // turns the read into a 2-"subread" POA job (the two overlap slices); k_zero_finish stitches
 // d1[:q_st] + overlap consensus + d0[r_en:] after k_poa.  Rare path: one wave per read, previous
-// H/E row in LDS, direction bytes in global memory, scalar traceback.
+// H/E row in LDS (front pieces of up to ZW columns; longer ones keep the two rows in global memory behind the
+// block's direction bytes), direction bytes in global memory, scalar traceback.
 #include "c3_dev.h"
 #include "c3_args.h"
 
@@ -13,8 +14,8 @@
 #define WSYNC() __syncthreads()
 
 __global__ __launch_bounds__(64) void k_zero(ZeroArgs a) {
-  __shared__ int Hrow[ZW + 1];
-  __shared__ int Erow[ZW + 1];
+  __shared__ int Hlds[ZW + 1];
+  __shared__ int Elds[ZW + 1];
   const int lane = wave_lane();
   const int go = a.p.zr_gapo, ge = a.p.zr_gape, ma = a.p.zr_match, mb = -a.p.zr_mismatch;
   const int NEGZ = INT32_MIN / 2;
@@ -25,11 +26,14 @@ __global__ __launch_bounds__(64) void k_zero(ZeroArgs a) {
     const int L = (int)(a.b.off[rid + 1] - off);
     const uint32_t* pk = a.b.pk + a.b.woff[rid];
     const int n0 = info->front_end, t0 = info->tail_beg, n1 = L - t0;
-    uint8_t* D = a.D + (size_t)blockIdx.x * a.dcap;
+    uint8_t* D = a.D + (size_t)blockIdx.x * a.dstride;
     int4 z; z.x = z.y = z.z = z.w = 0;
-    bool ok = n0 > 0 && n1 > 0 && n0 <= ZW && (long long)n0 * n1 <= a.p.zr_max_cells && (long long)(n0 + 1) * (n1 + 1) <= a.dcap;
+    bool ok = n0 > 0 && n1 > 0 && (n0 <= ZW || n0 <= a.rowcap) && (long long)n0 * n1 <= a.p.zr_max_cells &&
+              (long long)(n0 + 1) * (n1 + 1) <= a.dcap;
     if (ok) {
       const int W = n0 + 1;
+      int* Hrow = Hlds; int* Erow = Elds;          // (generic pointers: flat loads serve both homes)
+      if (n0 > ZW) { Hrow = (int*)(D + a.dcap); Erow = Hrow + a.rowcap + 1; }
       for (int j = lane; j <= n0; j += 64) { Hrow[j] = 0; Erow[j] = NEGZ; }
       int best = 0, bi = 0, bj = 0;
       for (int i = 1; i <= n1; ++i) {

@@ -157,8 +157,8 @@ def test_stage_masks_and_state_errors():
     h.close()
 
 
-def _zero_read(rng, a, b, err=True):
-    ins = _rand(rng, 1300)
+def _zero_read(rng, a, b, err=True, n_ins=1300):
+    ins = _rand(rng, n_ins)
     clean = ins[a:] + synth.SPLINT1 + ins[:b]
     if not err:
         return clean, "I" * len(clean), ins
@@ -197,6 +197,20 @@ def test_zero_repeat_rescue(O):
     ores, ocons = O.process_batch(synth.SPLINT1, reads[:3], strands[:3], params=P, threads=1)
     assert [x.status for x in ores] == [3, 3, 3]
     h.close()
+
+
+def test_zero_repeat_long_front_piece(O):
+    """front pieces beyond the 4096 columns k_zero keeps in LDS (rows then live in global memory): the only size limit is the
+    oracle's 16 M cells (oracle/c3o_zero.c, zr_max_cells), on either side of it the two agree"""
+    rng = np.random.default_rng(24)
+    reads = []
+    for n_ins, a, b in ((6500, 1400, 2600), (6000, 1800, 3500), (7000, 1000, 2900), (4200, 50, 3000), (8200, 20, 1800)):
+        s, q, _ = _zero_read(rng, a, b, n_ins=n_ins)
+        reads.append((s, q))
+    res, cons = _compare(O, [synth.SPLINT1], reads, ["+"] * len(reads), [0] * len(reads))
+    assert [int(x) for x in res["status"]] == [0, 0, 3, 0, 0]                       # (6000 x 2900 cells: over the limit)
+    assert all(int(r["n_sub"]) == 0 for r in res)
+    assert len(cons[0]) > 6000 and len(cons[4]) > 8000
 
 
 def test_zero_repeat_mixed_with_normal_reads(O):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Randomised parity sweep, GPU path against the oracle (diagnostic, slower than the test suite):
-   python tools/fuzz_parity.py [n_reads] [seed]
+   python tools/fuzz_parity.py [n_reads] [seed] [max insert, default 3500]
 Concatemers with random insert length (60..3500), repeats (0..14), flank lengths, error rate (0..25 %), strand, quality
 profile, occasional non-ACGT bytes / lower case, ragged repeats (a 25-90 base chunk missing or duplicated in some copies), plus
 pure noise reads.  Prints the band counters of k_window (layers accepted by the certificate / redone unbanded)."""
@@ -13,6 +13,7 @@ from oracle import oracle_py as O
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+max_ins = int(sys.argv[3]) if len(sys.argv) > 3 else 3500          # 7000: subreads beyond 6 kb (bands of 3-4 chunks in k_poa's WIDE instance)
 rng = np.random.default_rng(seed)
 acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
 rnd = lambda L: acgt[rng.integers(0, 4, L)].tobytes().decode()   # noqa: E731
@@ -22,7 +23,7 @@ for i in range(n):
     if kind == 0:
         s = rnd(int(rng.integers(0, 4000))); q = "".join(chr(33 + int(v)) for v in rng.integers(0, 60, len(s)))
     else:
-        ins = rnd(int(rng.integers(60, 3500)))
+        ins = rnd(int(rng.integers(60, max_ins)))
         reps = int(rng.integers(0, 15)) if len(ins) < 1200 else int(rng.integers(0, 6))
         k0, k1 = int(rng.integers(0, len(ins))), int(rng.integers(0, len(ins)))
         if kind in (3, 4) and len(ins) > 300 and reps >= 2:
