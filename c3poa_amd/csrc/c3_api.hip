@@ -167,7 +167,7 @@ struct c3_handle {
   int n_poa_redo = 0;        // reads of the last run that needed the full-size second POA pass
   int n_poa_redo16 = 0;      // ... of them: because a score left the 16-bit cells
   DBuf s_eH, s_eD, s_lw, d_wrec, d_wlay, d_wbase, d_wout;       // prep / windows
-  DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc, s_win_h2, s_win_d2, d_wovf;
+  DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc, s_win_h2, s_win_d2, s_win_i2, s_win_nk2, s_win_b2, s_win_sc2, s_win_desc2, d_wovf;
   DBuf s_zero_d, d_zinfo, d_zflag, d_zwork; std::vector<int> zwork;  // window scratch
   std::vector<Summary> sum; std::vector<int> work;
   int res_prefix = 0;            // entries of peaks[] / sub_beg[] / sub_end[] that any read of the resident batch uses (0: unknown)
@@ -250,7 +250,7 @@ extern "C" void c3_destroy(c3_handle* h) {
   if (h->stream_dn) { (void)hipStreamSynchronize(h->stream_dn); (void)hipStreamDestroy(h->stream_dn); }
   if (h->ev_dn) (void)hipEventDestroy(h->ev_dn);
   if (h->h_tot) (void)hipHostFree(h->h_tot);
-  h->d_info_snap.release(); h->d_coff_part.release(); h->s_win_h2.release(); h->s_win_d2.release(); h->d_wovf.release();
+  h->d_info_snap.release(); h->d_coff_part.release(); h->s_win_h2.release(); h->s_win_d2.release(); h->s_win_i2.release(); h->s_win_nk2.release(); h->s_win_b2.release(); h->s_win_sc2.release(); h->s_win_desc2.release(); h->d_wovf.release();
   DBuf* all[] = {&h->d_sp_codes, &h->d_sp_len, &h->d_ascii, &h->d_pk, &h->d_woff, &h->d_qual, &h->d_off, &h->d_strand, &h->d_sid,
                  &h->d_info, &h->d_track, &h->d_draft, &h->d_tpos, &h->d_cons, &h->d_counter, &h->d_raw, &h->d_nraw, &h->d_sum,
                  &h->d_work, &h->d_bufA, &h->d_bufB, &h->d_cand, &h->d_cst, &h->d_msa, &h->d_msa_off, &h->d_msa_len,
@@ -731,15 +731,26 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     const int NI = 19;      // W_INTS of k_polish.hip
     const size_t per_slot = N * (NI * 4 + 8 + 2) + N * K * 16 + (size_t)hcap * 5;
     const int slots = auto_slots(h, h->cfg.slots_win, per_slot, n_win, 20);
-    const int slots2 = hcap < hcap_full ? std::min(slots, 256) : 0;
+    // the second launch holds ANY window: graph arrays for every base of every layer becoming a node, DP rows as wide as the longest
+    // layer (both maxima come back from k_prep with the window count); a handful of slots when that is large
+    const int Ncap2 = (int)std::min<long long>(65534, std::max<long long>(Ncap, (long long)cnt[10] + 8));
+    const long long rs2 = std::max<long long>(768, (((long long)cnt[11] + 1 + 63) / 64) * 64);
+    const long long hcap2 = std::max(hcap_full, (long long)(Ncap2 + 1) * rs2);
+    const size_t N2 = (size_t)Ncap2;
+    const size_t per_slot2 = N2 * (NI * 4 + 8 + 2) + N2 * K * 16 + sizeof(uint4) * (N2 + 1) + (size_t)hcap2 * 5;
+    const int slots2 = (int)std::max<long long>(1, std::min<long long>(std::min(slots, 128), (4LL << 30) / (long long)per_slot2));
     HIPCHK(h->s_win_i.ensure(sizeof(int) * N * NI * slots + 64)); HIPCHK(h->s_win_nk.ensure(sizeof(int) * N * K * 4 * slots));
     HIPCHK(h->s_win_h.ensure(sizeof(int32_t) * (size_t)hcap * slots)); HIPCHK(h->s_win_d.ensure((size_t)hcap * slots + 256));
     HIPCHK(h->s_win_b.ensure(N * 2 * slots)); HIPCHK(h->s_win_sc.ensure(sizeof(long long) * N * slots));
     HIPCHK(h->s_win_desc.ensure(sizeof(uint4) * (N + 1) * slots));
-    if (slots2) {
-      HIPCHK(h->s_win_h2.ensure(sizeof(int32_t) * (size_t)hcap_full * slots2)); HIPCHK(h->s_win_d2.ensure((size_t)hcap_full * slots2 + 256));
+    {
+      HIPCHK(h->s_win_h2.ensure(sizeof(int32_t) * (size_t)hcap2 * slots2)); HIPCHK(h->s_win_d2.ensure((size_t)hcap2 * slots2 + 256));
+      HIPCHK(h->s_win_i2.ensure(sizeof(int) * N2 * NI * slots2 + 64)); HIPCHK(h->s_win_nk2.ensure(sizeof(int) * N2 * K * 4 * slots2));
+      HIPCHK(h->s_win_b2.ensure(N2 * 2 * slots2)); HIPCHK(h->s_win_sc2.ensure(sizeof(long long) * N2 * slots2));
+      HIPCHK(h->s_win_desc2.ensure(sizeof(uint4) * (N2 + 1) * slots2));
       HIPCHK(h->d_wovf.ensure(sizeof(int) * (size_t)n_win));
     }
+    DBG("window: Ncap=%d hcap=%lld slots=%d | full-size launch: Ncap=%d hcap=%lld slots=%d (%.1f MB per slot)\n", Ncap, hcap, slots, Ncap2, hcap2, slots2, per_slot2 / 1048576.0);
     WinArgs a; memset(&a, 0, sizeof(a));
     a.b = dev_batch(h); a.p = dev_params(h->cfg); a.counter = h->d_counter.as<int>(); a.n_win = n_win;
     a.wrec_in = h->d_wrec.as<WinRec>(); a.wrec = h->d_wrec.as<WinRec>(); a.wlay = h->d_wlay.as<WLayer>(); a.NLcap = NLcap;
@@ -752,11 +763,13 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 256, h->stream));
     a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
     if (const char* e = getenv("C3_DEBUG_BAND")) a.band_mode = !strcmp(e, "off") ? 1 : !strcmp(e, "fail") ? 2 : !strcmp(e, "verify") ? 3 : 0;    // test hook (tests/test_gpu_band.py)
-    a.ovf_list = slots2 ? h->d_wovf.as<int>() : nullptr;
+    a.ovf_list = h->d_wovf.as<int>();
     c3k_launch_window(&a, slots, h->stream);
     HIPCHK(hipGetLastError());
-    if (slots2) {
-      a.H = h->s_win_h2.as<int32_t>(); a.D = h->s_win_d2.as<uint16_t>(); a.hcap = hcap_full;
+    {
+      a.ibase = h->s_win_i2.as<int>(); a.ebase = h->s_win_nk2.as<int>(); a.base = h->s_win_b2.as<uint8_t>(); a.score = h->s_win_sc2.as<long long>();
+      a.rdesc = h->s_win_desc2.as<uint4>(); a.Ncap = Ncap2; a.Lcap = std::min(a.Lcap, Ncap2);
+      a.H = h->s_win_h2.as<int32_t>(); a.D = h->s_win_d2.as<uint16_t>(); a.hcap = hcap2;
       a.wlist = h->d_wovf.as<int>(); a.n_win_dev = h->d_counter.as<int>() + W_CNT_OVF; a.ovf_list = nullptr;
       c3k_launch_window(&a, slots2, h->stream);
       HIPCHK(hipGetLastError());
@@ -777,6 +790,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   HIPCHK(hipStreamSynchronize(h->stream));
   memcpy(cnt, cnt_all, 64);
   if (n_win > 0) h->tm.n_win_redo = cnt_all[W_CNT_OVF];
+  if (n_win > 0) DBG("window: second launch %d; given up: backbone %d scratch %d nodes %d consensus %d\n", cnt_all[W_CNT_OVF], cnt_all[W_CNT_WHY], cnt_all[W_CNT_WHY + 1], cnt_all[W_CNT_WHY + 2], cnt_all[W_CNT_WHY + 3]);
   if (n_win > 0) { h->tm.cells_polish += *(long long*)(cnt + 2); h->tm.cells_polish_computed += *(long long*)(cnt + 4); h->tm.n_band_layers = cnt[6]; h->tm.n_band_fallback = cnt[7]; h->tm.n_band_mismatch = cnt[8]; if (cnt[8]) fprintf(stderr, "c3poa: band verify mismatch in window %d layer %d (R = %d): last differing base q = %d, band row %d, full row %d, row of q+1 = %d\n", cnt[9], cnt[10], cnt[11], cnt[12], cnt[13], cnt[14], cnt[15]); }
   HIPCHK(hipEventElapsedTime(ms_prep, h->ev[5], h->ev[6]));
   HIPCHK(hipEventElapsedTime(ms_win, h->ev[7], h->ev[8]));

@@ -49,6 +49,7 @@ struct WinArgs {
 };
 #define W_CNT_OVF 48                      /* d_counter ints: [0] queue of the first launch, [48] overflow count, [49] queue of the second */
 #define W_CNT_Q2 49
+#define W_CNT_WHY 50                      /* [50..53] windows given up: backbone longer than the output slot, DP scratch, graph nodes, consensus length */
 struct StitchArgs {
   C3Batch b; C3Info* info; const int* work; int n_work; const WinRec* wrec; const int* win_base; const uint8_t* wout; int wout_cap; char* cons;
   const uint8_t* zflag;

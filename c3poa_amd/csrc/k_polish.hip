@@ -330,9 +330,20 @@ __device__ __forceinline__ void prep_one(const PrepArgs& a, int wi, int lane, ui
       }
       WSYNC();
     }
+    // what k_window's full-size launch must be able to hold: the longest layer of any window (DP columns) and the most nodes a
+    // window graph can reach (every base of every layer a new node -- the bound the reference's containers grow to by themselves)
+    int mq = 0, mn = 0;
+    for (int w = lane; w < nwin; w += 64) {
+      const WinRec* r = &a.wrec[wbase + w];
+      int sum = r->blen;
+      for (int x = 0; x < r->n_layers; ++x) { const int len = a.wlay[(size_t)(wbase + w) * a.NLcap + x].len; sum += len; mq = max(mq, len); }
+      mn = max(mn, sum);
+    }
+    mq = wave_max(mq); mn = wave_max(mn);
     if (lane == 0) {
       info->n_win = nwin; a.win_base[rid] = wbase;
       atomicAdd((unsigned long long*)(a.counter + 2), (unsigned long long)cells);
+      atomicMax(a.counter + 10, mn); atomicMax(a.counter + 11, mq);
     }
     WSYNC();
 }
@@ -1108,7 +1119,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
     long long cells = 0, cells_done = 0;          // cells of the full matrices (what the oracle counts) / cells actually computed
     int olen = 0, polished = 0, fail = 0, n_band = 0, n_fallback = 0;
     if (nl + 1 < 3) {
-      if (blen > a.wout_cap) fail = 1;
+      if (blen > a.wout_cap) { fail = 1; if (lane == 0) atomicAdd(a.counter + W_CNT_WHY, 1); }
       else { for (int i = lane; i < blen; i += 64) out[i] = bb[i]; olen = blen; }
     } else {
       // ---- backbone chain (weight-0 edges, coverage 1)
@@ -1238,7 +1249,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         for (int attempt = 0; attempt < 4; ++attempt) {
           unsigned long long dbg_[6] = {0, 0, 0, 0, 0, 0};
           int nblocks = 0;
-          if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, d0bits, d1bits, ring_off, lds_ints, l.begin, l.end, blen, &cb, &nblocks) < 0) { fail = SECOND ? 1 : 2; break; }      // (2: the layer needs more DP scratch than this launch has -- the window goes to the full-size launch)
+          if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, d0bits, d1bits, ring_off, lds_ints, l.begin, l.end, blen, &cb, &nblocks) < 0) { fail = SECOND ? 1 : 2; if (SECOND && lane == 0) atomicAdd(a.counter + W_CNT_WHY + 1, 1); break; }      // (2: the layer needs more DP scratch than this launch has -- the window goes to the full-size launch)
 #ifdef C3_PHASE_PROF
           ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1];
 #endif
@@ -1445,7 +1456,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
           }
         }
         const int nn = n_old + carry_new;
-        if (nn > c.Ncap) { fail = 1; break; }
+        if (nn > c.Ncap) { fail = SECOND ? 1 : 2; if (SECOND && lane == 0) atomicAdd(a.counter + W_CNT_WHY + 2, 1); break; }      // (2: more nodes than the first launch's graph arrays hold -- the full-size launch has the worst case)
         WSYNC();
         const int K = c.K;
         // edges of the path, two 64-base chunks per turn.  Every base owns the out-list of its left neighbour's node and the in-list
@@ -1501,7 +1512,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         if (c.n <= a.Lcap) olen = win_consensus(c, s_score, s_pred, rec.tgs, nl, out, a.wout_cap, lane);
         else olen = win_consensus(c, (int*)c.H, (unsigned short*)(c.H + c.Ncap), rec.tgs, nl, out, a.wout_cap, lane);
         PH_MARK(8)
-        if (olen < 0) { fail = 1; olen = 0; } else polished = 1;
+        if (olen < 0) { fail = 1; olen = 0; if (lane == 0) atomicAdd(a.counter + W_CNT_WHY + 3, 1); } else polished = 1;
       }
     }
     if (fail == 2 && a.ovf_list) {

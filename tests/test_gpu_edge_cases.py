@@ -1,5 +1,6 @@
 """GPU edge cases against the oracle: ragged / degenerate reads, other splints (all conk templates),
 several splints per batch, extreme qualities, capacity limits, per-stage runs."""
+import os
 import numpy as np
 import pytest
 
@@ -211,6 +212,19 @@ def test_zero_repeat_long_front_piece(O):
     assert [int(x) for x in res["status"]] == [0, 0, 3, 0, 0]                       # (6000 x 2900 cells: over the limit)
     assert all(int(r["n_sub"]) == 0 for r in res)
     assert len(cons[0]) > 6000 and len(cons[4]) > 8000
+
+
+def test_window_beyond_the_first_launch_graph_and_scratch(O):
+    """a read of 200+ copies of a short insert whose peaks are only partly called: subreads of several units each, window layers
+    of 600+ bases that do not follow the draft -- one window graph grows past the first launch's node arrays and needs DP rows
+    wider than its scratch; the full-size launch is sized from the batch (longest layer, sum of the layers) and must hold it
+    (found by tools/fuzz_parity2.py seed 4, read 155: LIMIT on the GPU, a consensus in the oracle)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity2", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity2.py"))
+    fz = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz)
+    splint, mdist, reads, strands = fz.generate(200, 4)
+    res, cons = _compare(O, [splint], [reads[155]], [strands[155]], [0], mdistcutoff=mdist)
+    assert int(res[0]["status"]) == 0 and len(cons[0]) > 2000
 
 
 def test_zero_repeat_mixed_with_normal_reads(O):
