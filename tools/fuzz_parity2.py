@@ -84,6 +84,10 @@ def generate(n, seed):
             other = rnd(int(rng.integers(100, 2500)))
             for r in range(reps // 2, reps):
                 units[r] = splint + other
+            if seed >= 100:                                            # (seeds >= 100: up to five unrelated inserts, copies interleaved)
+                others = [ins, other] + [rnd(int(rng.integers(100, 2500))) for _ in range(int(rng.integers(1, 4)))]
+                for r in range(reps):
+                    units[r] = splint + others[int(rng.integers(0, len(others)))]
         if kind == 7 and reps >= 2:                                    # one splint copy lost most of itself
             r = int(rng.integers(0, reps))
             cut = int(rng.integers(len(splint) // 3, len(splint)))
