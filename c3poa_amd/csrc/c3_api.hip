@@ -433,7 +433,7 @@ static int run_conk(c3_handle* h) {
 static void savgol_coeffs(int window, double* c) {
   int m = (window - 1) / 2;
   double den = (double)(2 * m - 1) * (double)(2 * m + 1) * (double)(2 * m + 3);
-  for (int k = -m; k <= m; ++k) c[k + m] = 3.0 * (double)(3 * m * m + 3 * m - 1 - 5 * k * k) / den;
+  for (int k = -m; k <= 0; ++k) c[k + m] = 3.0 * (double)(3 * m * m + 3 * m - 1 - 5 * k * k) / den;      // (symmetric: k_peaks reads c[0 .. m]; PeaksArgs::coef holds 64 = the window limit of c3_create)
 }
 
 static int run_peaks(c3_handle* h) {
