@@ -122,9 +122,20 @@ if __name__ == "__main__":
         keep = [int(x) for x in os.environ["FUZZ_ONLY"].split(",")]
         reads = [reads[i] for i in keep]; strands = [strands[i] for i in keep]
     h = _lib.Handle(mdistcutoff=mdist); h.set_splints([splint])
-    h.upload([r[0] for r in reads], [r[1] for r in reads], strands)
-    h.run()
-    res, cons = h.results()
+    nb = int(os.environ.get("FUZZ_BATCHES", "1"))
+    if nb > 1:                                                         # ONE handle over several batches of very different sizes (buffers that grew, lists and flags of the batch before)
+        cuts = sorted(set([0, len(reads)] + [int(x) for x in np.random.default_rng(seed).integers(0, len(reads) + 1, nb - 1)]))
+        res_parts, cons = [], []
+        for b0, b1 in zip(cuts, cuts[1:]):
+            h.upload([r[0] for r in reads[b0:b1]], [r[1] for r in reads[b0:b1]], strands[b0:b1])
+            h.run()
+            r_, c_ = h.results()
+            res_parts.append(r_.copy()); cons += list(c_)
+        res = np.concatenate(res_parts)
+    else:
+        h.upload([r[0] for r in reads], [r[1] for r in reads], strands)
+        h.run()
+        res, cons = h.results()
     ores, ocons = O.process_batch(splint, reads, strands, params=O.default_params(mdistcutoff=mdist), threads=16)
     bad = 0
     for i in range(len(reads)):
