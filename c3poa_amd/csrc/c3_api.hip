@@ -682,7 +682,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     wcap += (2 * h->sum[i].max_sub + WL - 1) / WL + 1;
   }
   const int NLcap = max_ns + 2, NWcap = (2 * max_q + WL - 1) / WL + 1;
-  const int64_t ecap = (int64_t)(max_dang + 2) * 512;          // direction bytes: 512 per piece row
+  const int64_t ecap = ((int64_t)(max_dang + 2) / 3 + 2) * 256;    // 2-bit directions: one dword per lane and three piece rows
   const size_t per_slot_prep = (size_t)ecap + (size_t)NLcap * NWcap * 8;
   const int slots_p = auto_slots(h, h->cfg.slots_poa, per_slot_prep, nw, getenv("C3_DEBUG_PREP_WPC") ? atoi(getenv("C3_DEBUG_PREP_WPC")) : 20);
   HIPCHK(h->s_eD.ensure((size_t)ecap * slots_p));

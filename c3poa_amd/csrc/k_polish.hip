@@ -35,8 +35,10 @@
 // Lane owns EC consecutive band offsets (bb = lane*EC + cc; cell (i, j = i - W + bb)); the previous
 // row lives in registers (diagonal = same offset, up = offset+1), the left gap is an in-lane prefix
 // plus one DPP max-scan, cells are KEY = score*4 + tag (3 diag, 2 up, 1 left) so one v_max per
-// candidate keeps the oracle's tie order.  Only the direction bytes go to memory (8 per lane per row);
-// the draft sits in LDS and the piece bases arrive 64 rows at a time, so the row loop has no loads.
+// candidate keeps the oracle's tie order.  Only the directions go to memory, as a 2-BIT STREAM: a lane's five cells of a row are
+// 10 bits, three rows share one dword (word (i-1)/3 of the lane, bits 10*((i-1)%3) + 2*cc; tag 3 diag, 2 up, 1 left, 0 none) that
+// is stored once per three rows (round 4; it was 8 bytes per lane and row: 512 bytes per row against 85).
+// The draft sits in LDS and the piece bases arrive 64 rows at a time, so the row loop has no loads.
 #ifndef C3_PREP_WAVES
 #define C3_PREP_WAVES 5
 #endif
@@ -53,7 +55,9 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
   const int db = dir_ > 0 ? 0 : C - 1;
   const int NEGK = -(1 << 28);
   for (int k = lane; k < n; k += 64) tpos[pb + dir_ * k] = -1;
-  if (bw > 64 * EC || (long long)(n + 1) * 512 > a.ecap) return -1;
+  if (bw > 64 * EC || ((long long)(n + 2) / 3 + 1) * 256 > a.ecap) return -1;
+  unsigned* const DW = (unsigned*)D;
+  unsigned dacc = 0;
   int hprev[EC];
 #pragma unroll
   for (int cc = 0; cc < EC; ++cc) {           // row 0: H[0][j] = j*g for 0 <= j <= min(C, W)
@@ -79,6 +83,7 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
 #pragma unroll
     for (int cc = 0; cc < EC; ++cc) dcp |= code_at(1 - W + bb0 + cc - 1) << (4 * cc);
     long long cells_s = 0;
+    int ph3 = 0;                                                           // (i - 1) % 3
     for (int ib = 1; ib <= n; ib += 64) {
       int pcs = 0;
       if (ib + lane <= n) pcs = c3_code_at(pk, pb + dir_ * (ib + lane - 1));
@@ -108,7 +113,7 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
         }
         const int s = wave_scan_max(run);
         int ex = wave_shr1(s, NEGK);
-        unsigned d0 = 0, d1 = 0;
+        unsigned d0 = 0;
 #pragma unroll
         for (int cc = 0; cc < EC; ++cc) {
           // (no test for the row's first column: everything to its left is NEGK, so the left candidate loses by itself;
@@ -119,13 +124,17 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
           const int hh = k2 & ~3;
           hprev[cc] = hh;
           const unsigned tag = (unsigned)k2 & 3u;                           // 3 diag, 2 up, 1 left, 0 invalid
-          if (cc < 4) d0 |= tag << (8 * cc); else d1 |= tag;
+          d0 |= tag << (2 * cc);
           const bool up_ = hh > bestc[cc];                                 // (column 0 and invalid cells are <= 0: never)
           bestc[cc] = max(bestc[cc], hh);
           bic[cc] = up_ ? i : bic[cc];
         }
-        unsigned* drow = (unsigned*)(D + (size_t)i * 512) + lane * 2;
-        drow[0] = 0x03030303u - d0; drow[1] = 3u - d1;                     // bytes: 0 diag, 1 up, 2 left, 3 none
+        dacc = (dacc >> 10) | (d0 << 20);                                  // three rows per dword: the oldest row ends up in bits 0-9
+        if (ph3 == 2 || i == n) {                                          // (uniform: a scalar branch)
+          DW[(unsigned)(i - 1) / 3u * 64u + lane] = dacc >> (10 * (2 - ph3));
+          dacc = 0;
+        }
+        ph3 = ph3 == 2 ? 0 : ph3 + 1;
         dcp = (dcp >> 4) | (nxt_code << (4 * (EC - 1)));
       }
     }
@@ -170,7 +179,7 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
       }
       const int s = wave_scan_max(run);
       int ex = wave_shr1(s, NEGK);
-      unsigned d0 = 0, d1 = 0;
+      unsigned d0 = 0;
 #pragma unroll
       for (int cc = 0; cc < EC; ++cc) {
         const int bb = lane * EC + cc, j = i - W + bb;
@@ -180,12 +189,13 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
         ex = max(ex, y[cc]);
         const int hh = k2 & ~3;
         hprev[cc] = val ? hh : NEGK;
-        const unsigned dir = val ? (unsigned)(3 - (k2 & 3)) : 3u;      // 0 diag, 1 up, 2 left
-        if (cc < 4) d0 |= dir << (8 * cc); else d1 |= dir;
+        const unsigned tag = val ? (unsigned)(k2 & 3) : 0u;            // 3 diag, 2 up, 1 left, 0 none
+        d0 |= tag << (2 * cc);
         if (val) { ++cells; if (j > 0 && hh > best) { best = hh; bi = i; bj = j; } }
       }
-      unsigned* drow = (unsigned*)(D + (size_t)i * 512) + lane * 2;
-      drow[0] = d0; drow[1] = d1;
+      const int ph = (i - 1) % 3;
+      dacc = (dacc >> 10) | (d0 << 20);
+      if (ph == 2 || i == n) { DW[(unsigned)(i - 1) / 3u * 64u + lane] = dacc >> (10 * (2 - ph)); dacc = 0; }
     }
   }
   WSYNC();
@@ -200,8 +210,8 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
       if (i == 0) break;                                   // row 0: only left moves, nothing to record
       const int bb = j - i + W;
       const int ik = i - lane;
-      int d = 3;
-      if (ik >= 1) d = D[(size_t)ik * 512 + (bb / EC) * 8 + bb % EC];
+      int d = 3;                                                   // 0 diag, 1 up, 2 left, 3 none
+      if (ik >= 1) d = 3 - (int)((DW[(unsigned)(ik - 1) / 3u * 64u + bb / EC] >> (10 * ((ik - 1) % 3) + 2 * (bb % EC))) & 3u);
       const unsigned long long bal = __ballot(ik >= 1 && d == 0 && j - lane >= 1);
       const int m = (~bal) ? __builtin_ctzll(~bal) : 64;
       if (lane < m) tpos[pb + dir_ * (ik - 1)] = db + dir_ * (j - lane - 1);
