@@ -10,9 +10,17 @@
 #include <stddef.h>
 #include <stdlib.h>
 #include <string.h>
-
 typedef struct { char* base; size_t cap, off; int depth; } c3o_arena;
 extern __thread c3o_arena c3o_tls_arena;
+#ifdef C3O_NO_ARENA
+/* sanitizer builds (`make asan`): every allocation is the heap's own, so AddressSanitizer sees each buffer's real bounds */
+static inline void c3o_enter(void) {}
+static inline void c3o_leave(void) {}
+static inline void* c3o_alloc(size_t n) { return malloc(n); }
+static inline void* c3o_zalloc(size_t n, size_t sz) { return calloc(n, sz); }
+static inline void* c3o_regrow(void* p, size_t n) { return realloc(p, n); }
+static inline void c3o_release(void* p) { free(p); }
+#else
 
 static inline void c3o_enter(void) {
   c3o_arena* a = &c3o_tls_arena;
@@ -52,4 +60,5 @@ static inline void* c3o_regrow(void* p, size_t n) {
 #define calloc(n, s) c3o_zalloc(n, s)
 #define realloc(p, n) c3o_regrow(p, n)
 #define free(p) c3o_release(p)
+#endif /* C3O_NO_ARENA */
 #endif

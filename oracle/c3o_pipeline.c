@@ -11,8 +11,8 @@
 #include <malloc.h>
 #ifdef _OPENMP
 #include <omp.h>
-#include "c3o_mem.h"
 #endif
+#include "c3o_mem.h"
 
 #define C3O_MAX_SUB 250
 
