@@ -167,7 +167,8 @@ struct c3_handle {
   int n_poa_redo = 0;        // reads of the last run that needed the full-size second POA pass
   int n_poa_redo16 = 0;      // ... of them: because a score left the 16-bit cells
   DBuf s_eH, s_eD, s_lw, d_wrec, d_wlay, d_wbase, d_wout;       // prep / windows
-  DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc, s_win_h2, s_win_d2, s_win_i2, s_win_nk2, s_win_b2, s_win_sc2, s_win_desc2, d_wovf;
+  DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc, s_win_h2, s_win_d2, s_win_i2, s_win_nk2, s_win_b2, s_win_sc2, s_win_desc2, d_wout2, d_wovf;
+  int win_out2_cap = 0;
   DBuf s_zero_d, d_zinfo, d_zflag, d_zwork; std::vector<int> zwork;  // window scratch
   std::vector<Summary> sum; std::vector<int> work;
   int res_prefix = 0;            // entries of peaks[] / sub_beg[] / sub_end[] that any read of the resident batch uses (0: unknown)
@@ -250,7 +251,7 @@ extern "C" void c3_destroy(c3_handle* h) {
   if (h->stream_dn) { (void)hipStreamSynchronize(h->stream_dn); (void)hipStreamDestroy(h->stream_dn); }
   if (h->ev_dn) (void)hipEventDestroy(h->ev_dn);
   if (h->h_tot) (void)hipHostFree(h->h_tot);
-  h->d_info_snap.release(); h->d_coff_part.release(); h->s_win_h2.release(); h->s_win_d2.release(); h->s_win_i2.release(); h->s_win_nk2.release(); h->s_win_b2.release(); h->s_win_sc2.release(); h->s_win_desc2.release(); h->d_wovf.release();
+  h->d_info_snap.release(); h->d_coff_part.release(); h->s_win_h2.release(); h->s_win_d2.release(); h->s_win_i2.release(); h->s_win_nk2.release(); h->s_win_b2.release(); h->s_win_sc2.release(); h->s_win_desc2.release(); h->d_wout2.release(); h->d_wovf.release();
   DBuf* all[] = {&h->d_sp_codes, &h->d_sp_len, &h->d_ascii, &h->d_pk, &h->d_woff, &h->d_qual, &h->d_off, &h->d_strand, &h->d_sid,
                  &h->d_info, &h->d_track, &h->d_draft, &h->d_tpos, &h->d_cons, &h->d_counter, &h->d_raw, &h->d_nraw, &h->d_sum,
                  &h->d_work, &h->d_bufA, &h->d_bufB, &h->d_cand, &h->d_cst, &h->d_msa, &h->d_msa_off, &h->d_msa_len,
@@ -616,6 +617,13 @@ static int run_poa(c3_handle* h) {
   long long cells_full = (long long)(2 * max_q + 2) * (2 * w + 1 + max_q / 5);
   if (max_ns < 2) cells_full = 64;
   if (cells_full > 0x7fffff00LL) cells_full = 0x7fffff00LL;
+  // the LAST pass must hold any alignment the reference would finish: every node a row (a graph never has more nodes than
+  // bases went into it), every row as wide as the subread -- per read, not from the batch maxima.  (With match << mismatch an
+  // alignment prefers gaps to mismatches and nearly every base becomes a node of its own: tools/fuzz_parity3.py seeds 55, 93, 111
+  // ended such reads as LIMIT while the oracle finished them.)
+  long long cells_worst = cells_full;
+  for (int i : h->work) if (h->sum[i].n_sub >= 2) cells_worst = std::max(cells_worst, (long long)(h->sum[i].sum_sub + 8) * (h->sum[i].max_sub + 2));
+  if (cells_worst > 0x7fffff00LL) cells_worst = 0x7fffff00LL;
   // typical need: every further subread adds ~12 % nodes (mismatch siblings + insertions) to a graph of max_q nodes; a row
   // holds 2w+1 cells plus the drift between the row's nominal column and the argmax of its predecessors
   const double nodes_typ = (double)max_q * (1.0 + 0.15 * std::max(0, max_ns - 1));
@@ -658,7 +666,7 @@ static int run_poa(c3_handle* h) {
     if (cnt[5] > 0) {
       h->n_poa_redo += cnt[5]; h->n_poa_redo16 = cnt[5];
       HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
-      if ((rc = launch_poa(h, ovB, cnt[5], Ncap_full, K, Pcap, cells_full, nullptr, nullptr, 24, 0))) return rc;
+      if ((rc = launch_poa(h, ovB, cnt[5], Ncap_full, K, Pcap, cells_worst, nullptr, nullptr, 24, 0))) return rc;
     }
   }
   if (!h->zwork.empty()) {             // zero-repeat rescue, second half: stitch left + overlap consensus + right
@@ -750,6 +758,10 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
       HIPCHK(h->s_win_desc2.ensure(sizeof(uint4) * (N2 + 1) * slots2));
       HIPCHK(h->d_wovf.ensure(sizeof(int) * (size_t)n_win));
     }
+    // output slots of the second launch: a consensus is a path of the graph, at most Ncap2 bases; up to 1 GB of them
+    const int wout2_cap = (Ncap2 + 63) & ~63;
+    const int wout2_n = (int)std::max<long long>(std::min<long long>(n_win, 16), std::min<long long>(n_win, (1LL << 30) / wout2_cap));
+    HIPCHK(h->d_wout2.ensure((size_t)wout2_cap * wout2_n + 64)); h->win_out2_cap = wout2_cap;
     DBG("window: Ncap=%d hcap=%lld slots=%d | full-size launch: Ncap=%d hcap=%lld slots=%d (%.1f MB per slot)\n", Ncap, hcap, slots, Ncap2, hcap2, slots2, per_slot2 / 1048576.0);
     WinArgs a; memset(&a, 0, sizeof(a));
     a.b = dev_batch(h); a.p = dev_params(h->cfg); a.counter = h->d_counter.as<int>(); a.n_win = n_win;
@@ -759,7 +771,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     a.base = h->s_win_b.as<uint8_t>(); a.score = h->s_win_sc.as<long long>();
     a.H = h->s_win_h.as<int32_t>(); a.D = h->s_win_d.as<uint16_t>(); a.rdesc = h->s_win_desc.as<uint4>(); a.Ncap = Ncap; a.K = K; a.hcap = hcap; a.Lcap = std::min(std::min(Ncap, 2 * WL + 30 * NLcap), ((getenv("C3_DEBUG_WIN_LDS") ? atoi(getenv("C3_DEBUG_WIN_LDS")) : 6656) - 16) / 6);       // (LDS per wave capped at 6.5 KB: at cfg4 the uncapped sweep arrays took 8.5 KB and k_window ran 7 % slower; larger graphs use the global-scratch sweep)
     if (const char* e = getenv("C3_DEBUG_WIN_LCAP")) a.Lcap = std::max(64, std::min(Ncap, atoi(e)));   // test hook: forces the global-scratch consensus path
-    a.wout = h->d_wout.as<uint8_t>(); a.wout_cap = wout_cap;
+    a.wout = h->d_wout.as<uint8_t>(); a.wout_cap = wout_cap; a.wout2 = h->d_wout2.as<uint8_t>(); a.wout2_cap = wout2_cap; a.wout2_n = wout2_n;
     HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 256, h->stream));
     a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
     if (const char* e = getenv("C3_DEBUG_BAND")) a.band_mode = !strcmp(e, "off") ? 1 : !strcmp(e, "fail") ? 2 : !strcmp(e, "verify") ? 3 : 0;    // test hook (tests/test_gpu_band.py)
@@ -780,7 +792,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   StitchArgs s; memset(&s, 0, sizeof(s));
   s.b = dev_batch(h); s.info = h->d_info.as<C3Info>(); s.work = h->d_work.as<int>(); s.n_work = nw;
   s.wrec = h->d_wrec.as<WinRec>(); s.win_base = h->d_wbase.as<int>(); s.wout = h->d_wout.as<uint8_t>(); s.wout_cap = wout_cap;
-  s.cons = h->d_cons.as<char>(); s.zflag = h->d_zflag.as<uint8_t>();
+  s.cons = h->d_cons.as<char>(); s.zflag = h->d_zflag.as<uint8_t>(); s.wout2 = h->d_wout2.as<uint8_t>(); s.wout2_cap = h->win_out2_cap;
   DBG("stitch\n");
   c3k_launch_stitch(&s, std::min(nw, h->n_cus * 16), h->stream);
   HIPCHK(hipGetLastError());

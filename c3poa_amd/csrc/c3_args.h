@@ -46,6 +46,9 @@ struct WinArgs {
   // takes its windows from `wlist`, their number from device memory (`n_win_dev`) and its queue from counter[W_CNT_Q2]
   // (k_window<true>: the first launch's code carries none of this)
   const int* wlist; const int* n_win_dev; int* ovf_list;
+  // output of the second launch: entry q of its queue writes wout2 + q * wout2_cap (a window consensus can be as long as the graph has
+  // nodes; the first launch's slots hold 3 windows + 64 and hand longer ones over); WinRec::pad_ = q + 1 tells k_stitch where to look
+  uint8_t* wout2; int wout2_cap, wout2_n;
 };
 #define W_CNT_OVF 48                      /* d_counter ints: [0] queue of the first launch, [48] overflow count, [49] queue of the second */
 #define W_CNT_Q2 49
@@ -53,6 +56,7 @@ struct WinArgs {
 struct StitchArgs {
   C3Batch b; C3Info* info; const int* work; int n_work; const WinRec* wrec; const int* win_base; const uint8_t* wout; int wout_cap; char* cons;
   const uint8_t* zflag;
+  const uint8_t* wout2; int wout2_cap;
 };
 // adapter finder (k_adapter): every read x every entry of the splint table x both strands
 struct AdapterArgs {

@@ -1105,17 +1105,17 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
   PH_DECL
 
   for (;;) {
-    int wi = 0;
+    int wi = 0, qi = 0;
     if (lane == 0) {
       if (SECOND) {                                 // the windows the first launch could not hold: list and count in device memory
-        wi = atomicAdd(a.counter + W_CNT_Q2, 1);
+        qi = wi = atomicAdd(a.counter + W_CNT_Q2, 1);
         wi = wi < *(const volatile int*)a.n_win_dev ? a.wlist[wi] : -1;
       } else {
         wi = atomicAdd(a.counter, 1);
         if (wi >= a.n_win) wi = -1;
       }
     }
-    wi = wave_first(wi);
+    wi = wave_first(wi); qi = wave_first(qi);
     if (wi < 0) break;
     PH_MARK(9)
     const WinRec rec = a.wrec_in[wi];
@@ -1124,12 +1124,14 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
     const uint32_t* pk = a.b.pk + a.b.woff[rid];
     const uint8_t* qual = a.b.qual + off;
     const uint8_t* bb = a.draft + off + (size_t)rec.w * P.pol_window;
-    uint8_t* out = a.wout + (size_t)wi * a.wout_cap;
+    // (second launch: its own output slots, as long as a graph can have nodes)
+    const int ocap = SECOND ? (qi < a.wout2_n ? a.wout2_cap : 0) : a.wout_cap;
+    uint8_t* out = SECOND ? a.wout2 + (size_t)min(qi, max(a.wout2_n - 1, 0)) * a.wout2_cap : a.wout + (size_t)wi * a.wout_cap;
     const WLayer* lay = a.wlay + (size_t)wi * a.NLcap;
     long long cells = 0, cells_done = 0;          // cells of the full matrices (what the oracle counts) / cells actually computed
     int olen = 0, polished = 0, fail = 0, n_band = 0, n_fallback = 0;
     if (nl + 1 < 3) {
-      if (blen > a.wout_cap) { fail = 1; if (lane == 0) atomicAdd(a.counter + W_CNT_WHY, 1); }
+      if (blen > ocap) { fail = SECOND ? 1 : 2; if (SECOND && lane == 0) atomicAdd(a.counter + W_CNT_WHY, 1); }
       else { for (int i = lane; i < blen; i += 64) out[i] = bb[i]; olen = blen; }
     } else {
       // ---- backbone chain (weight-0 edges, coverage 1)
@@ -1519,17 +1521,17 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
       }
       if (!fail) {
         // ---- consensus: LDS-resident sweep; graphs larger than the LDS arrays use the slot's DP scratch instead
-        if (c.n <= a.Lcap) olen = win_consensus(c, s_score, s_pred, rec.tgs, nl, out, a.wout_cap, lane);
-        else olen = win_consensus(c, (int*)c.H, (unsigned short*)(c.H + c.Ncap), rec.tgs, nl, out, a.wout_cap, lane);
+        if (c.n <= a.Lcap) olen = win_consensus(c, s_score, s_pred, rec.tgs, nl, out, ocap, lane);
+        else olen = win_consensus(c, (int*)c.H, (unsigned short*)(c.H + c.Ncap), rec.tgs, nl, out, ocap, lane);
         PH_MARK(8)
-        if (olen < 0) { fail = 1; olen = 0; if (lane == 0) atomicAdd(a.counter + W_CNT_WHY + 3, 1); } else polished = 1;
+        if (olen < 0) { fail = SECOND ? 1 : 2; olen = 0; if (SECOND && lane == 0) atomicAdd(a.counter + W_CNT_WHY + 3, 1); } else polished = 1;      // (2: a consensus longer than the first launch's output slot)
       }
     }
     if (fail == 2 && a.ovf_list) {
       if (lane == 0) a.ovf_list[atomicAdd(a.counter + W_CNT_OVF, 1)] = wi;          // nothing of this window has been published
     } else if (lane == 0) {
       WinRec* r = &a.wrec[wi];
-      r->out_len = fail ? -1 : olen; r->polished = polished;        // (fail == 2 with no second launch to take it: the window is over the limits)
+      r->out_len = fail ? -1 : olen; r->polished = polished; r->pad_ = SECOND ? qi + 1 : 0;        // (fail == 2 with no second launch to take it: the window is over the limits)
       atomicAdd((unsigned long long*)(a.counter + 2), (unsigned long long)cells);
       atomicAdd((unsigned long long*)(a.counter + 4), (unsigned long long)cells_done);
       if (n_band) atomicAdd(a.counter + 6, n_band);
@@ -1557,13 +1559,14 @@ __global__ __launch_bounds__(64) void k_stitch(StitchArgs a) {
     for (int w = 0; w < nwin; ++w) {
       const WinRec r = a.wrec[wb + w];
       if (r.out_len < 0) { bad = 1; break; }
-      if (olen + r.out_len > L) { bad = 1; break; }
-      const uint8_t* src = a.wout + (size_t)(wb + w) * a.wout_cap;
+      if (olen + r.out_len > L) { bad = 2; break; }          // longer than the read: the caller's buffer ends there (the oracle: no consensus)
+      const uint8_t* src = r.pad_ ? a.wout2 + (size_t)(r.pad_ - 1) * a.wout2_cap : a.wout + (size_t)(wb + w) * a.wout_cap;
       for (int i = lane; i < r.out_len; i += 64) cons[olen + i] = "ACGT"[src[i] & 3];
       olen += r.out_len; any |= r.polished;
     }
     if (lane == 0) {
-      if (bad) { info->status = C3_ST_LIMIT; info->cons_len = 0; }
+      if (bad == 1) { info->status = C3_ST_LIMIT; info->cons_len = 0; }
+      else if (bad == 2) { info->status = C3_ST_NO_CONSENSUS; info->cons_len = 0; }
       else if (!any || olen == 0) { info->status = C3_ST_NO_CONSENSUS; info->cons_len = 0; }   // racon drops unpolished targets
       else info->cons_len = olen;
     }

@@ -227,6 +227,31 @@ def test_window_beyond_the_first_launch_graph_and_scratch(O):
     assert int(res[0]["status"]) == 0 and len(cons[0]) > 2000
 
 
+@pytest.mark.parametrize("seed,idx", [(55, [52, 83]), (93, [24, 44, 52, 70, 72]), (111, [2, 45, 48, 52, 53])])
+def test_non_default_configurations_found_by_the_fuzzer(O, seed, idx):
+    """tools/fuzz_parity3.py, seeds 55 / 93 / 111 (a random non-default c3_config each): with abPOA match 1-2 against mismatch 8 an
+    alignment prefers gaps and nearly every base becomes a node -- the last k_poa pass needs cells for `nodes x subread length`,
+    not for the batch's typical band; with polishing windows of 100 bases a window consensus can be longer than 3 windows + 64 --
+    the full-size k_window launch has output slots as long as its graph has nodes.  Both ended as LIMIT, the oracle finishes them."""
+    import importlib.util
+    from c3poa_amd import _lib
+    spec = importlib.util.spec_from_file_location("fuzz_parity3", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity3.py"))
+    fz3 = importlib.util.module_from_spec(spec); spec.loader.exec_module(fz3)
+    cfg = fz3.random_config(np.random.default_rng(10_000 + seed))
+    splint, _md, reads, strands = fz3.fz.generate(100, 50_000 + seed)
+    keep = [i for i, r in enumerate(reads) if len(r[0]) < 40_000]
+    reads = [reads[keep[i]] for i in idx]; strands = [strands[keep[i]] for i in idx]
+    h = _lib.Handle(**cfg)
+    h.set_splints([splint])
+    h.upload([r[0] for r in reads], [r[1] for r in reads], strands)
+    h.run()
+    res, cons = h.results()
+    ores, ocons = O.process_batch(splint, reads, strands, params=O.default_params(**cfg), threads=8)
+    assert [int(x) for x in res["status"]] == [o.status for o in ores] and list(cons) == list(ocons)
+    assert sum(1 for o in ores if o.status == 0) >= len(idx) - 2
+    h.close()
+
+
 def test_zero_repeat_mixed_with_normal_reads(O):
     rng = np.random.default_rng(22)
     recs = list(synth.generate("cfg1", n_reads=6))
