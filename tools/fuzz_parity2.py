@@ -120,23 +120,29 @@ if __name__ == "__main__":
     import os
     if os.environ.get("FUZZ_ONLY"):                                    # replay single reads of this seed (comma separated indices)
         keep = [int(x) for x in os.environ["FUZZ_ONLY"].split(",")]
-        reads = [reads[i] for i in keep]; strands = [strands[i] for i in keep]
-    h = _lib.Handle(mdistcutoff=mdist); h.set_splints([splint])
+        reads = [reads[i] for i in keep]; strands = [strands[i] for i in keep]; sids = [sids[i] for i in keep]
+    h = _lib.Handle(mdistcutoff=mdist); h.set_splints(splints)
+    sid_arr = np.array(sids, dtype=np.int16)
     nb = int(os.environ.get("FUZZ_BATCHES", "1"))
     if nb > 1:                                                         # ONE handle over several batches of very different sizes (buffers that grew, lists and flags of the batch before)
         cuts = sorted(set([0, len(reads)] + [int(x) for x in np.random.default_rng(seed).integers(0, len(reads) + 1, nb - 1)]))
         res_parts, cons = [], []
         for b0, b1 in zip(cuts, cuts[1:]):
-            h.upload([r[0] for r in reads[b0:b1]], [r[1] for r in reads[b0:b1]], strands[b0:b1])
+            h.upload([r[0] for r in reads[b0:b1]], [r[1] for r in reads[b0:b1]], strands[b0:b1], sid_arr[b0:b1])
             h.run()
             r_, c_ = h.results()
             res_parts.append(r_.copy()); cons += list(c_)
         res = np.concatenate(res_parts)
     else:
-        h.upload([r[0] for r in reads], [r[1] for r in reads], strands)
+        h.upload([r[0] for r in reads], [r[1] for r in reads], strands, sid_arr)
         h.run()
         res, cons = h.results()
-    ores, ocons = O.process_batch(splint, reads, strands, params=O.default_params(mdistcutoff=mdist), threads=16)
+    ores, ocons = [None] * len(reads), [None] * len(reads)
+    for k, sp_k in enumerate(splints):                                 # (the oracle takes one splint per call)
+        ix = [i for i in range(len(reads)) if sids[i] == k]
+        o_, c_ = O.process_batch(sp_k, [reads[i] for i in ix], [strands[i] for i in ix], params=O.default_params(mdistcutoff=mdist), threads=16)
+        for j, i in enumerate(ix):
+            ores[i], ocons[i] = o_[j], c_[j]
     bad = 0
     for i in range(len(reads)):
         o = ores[i]
@@ -149,8 +155,8 @@ if __name__ == "__main__":
                     i, len(reads[i][0]), strands[i], res[i]["status"], res[i]["n_sub"], res[i]["n_peaks"], len(cons[i]), o.status, o.n_sub, o.n_peaks, len(ocons[i])))
     st = np.bincount(res["status"], minlength=6)
     t = h.timing()
-    print("seed %d splint %d nt mdist %d: reads %d (longest %d, most subreads %d)  mismatches %d  statuses OK/NA/NOPEAK/NOCONS/SHORT/LIMIT = %s  band layers %d fallback %d  POA second pass %d reads (beyond 16-bit cells / far arena: %d)" % (
-        seed, len(splint), mdist, len(reads), max(len(r[0]) for r in reads), int(res["n_sub"].max()), bad, st.tolist(), t["n_band_layers"], t["n_band_fallback"],
+    print("seed %d splint %s nt mdist %d: reads %d (longest %d, most subreads %d)  mismatches %d  statuses OK/NA/NOPEAK/NOCONS/SHORT/LIMIT = %s  band layers %d fallback %d  POA second pass %d reads (beyond 16-bit cells / far arena: %d)" % (
+        seed, "/".join(str(len(x)) for x in splints), mdist, len(reads), max(len(r[0]) for r in reads), int(res["n_sub"].max()), bad, st.tolist(), t["n_band_layers"], t["n_band_fallback"],
         t["n_poa_redo"], t["n_poa_redo16"]))
     sys.exit(1 if bad else 0)
 
