@@ -116,8 +116,15 @@ if __name__ == "__main__":
     from oracle import oracle_py as O
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 400
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    splint, mdist, reads, strands = generate(n, seed)
     import os
+    splint, mdist, reads, strands = generate(n, seed)
+    splints, sids = [splint], [0] * len(reads)
+    for k in range(1, int(os.environ.get("FUZZ_SPLINTS", "1"))):       # several splints of different lengths in ONE batch (reads interleaved)
+        sp_k, _m, r_k, s_k = generate(max(8, n // 2), 1000 * k + seed)
+        splints.append(sp_k); reads += r_k; strands += s_k; sids += [k] * len(r_k)
+    if len(splints) > 1:
+        perm = np.random.default_rng(seed).permutation(len(reads))
+        reads = [reads[i] for i in perm]; strands = [strands[i] for i in perm]; sids = [sids[i] for i in perm]
     if os.environ.get("FUZZ_ONLY"):                                    # replay single reads of this seed (comma separated indices)
         keep = [int(x) for x in os.environ["FUZZ_ONLY"].split(",")]
         reads = [reads[i] for i in keep]; strands = [strands[i] for i in keep]; sids = [sids[i] for i in keep]
