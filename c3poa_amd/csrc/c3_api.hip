@@ -104,6 +104,16 @@ __global__ void k_init_info(C3Info* info, int n) {
   if (i < n) { C3Info* p = &info[i]; p->status = C3_ST_OK; p->n_peaks = 0; p->n_sub = 0; p->has_front = p->has_tail = 0;
                p->front_end = p->tail_beg = 0; p->cons_len = 0; p->draft_len = 0; p->n_win = 0; }
 }
+// after k_poa: the longest draft and the polishing windows of all drafts of the work list -> out[0], out[1] (what k_prep's window tables
+// must hold; kept out of k_poa, whose register allocation a two-atomic epilogue cost 1.5-2 %)
+__global__ void k_draft_stats(const C3Info* info, const int* work, int nw, int WL, int* out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  int c = 0;
+  if (k < nw) { const C3Info* p = &info[work[k]]; c = p->status == C3_ST_OK ? p->draft_len : 0; }
+  int mx = c, nwin = c > 0 ? (c + WL - 1) / WL + 1 : 0;
+  for (int o = 32; o > 0; o >>= 1) { mx = max(mx, __shfl_xor(mx, o)); nwin += __shfl_xor(nwin, o); }
+  if ((threadIdx.x & 63) == 0 && nwin > 0) { atomicMax(out, mx); atomicAdd(out + 1, nwin); }
+}
 struct Summary { int status, n_sub, max_sub, sum_sub, max_dang, front, tail, n_peaks; };
 __global__ void k_summary(const C3Info* info, const int64_t* off, int n, Summary* out) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -169,6 +179,7 @@ struct c3_handle {
   DBuf s_eH, s_eD, s_lw, d_wrec, d_wlay, d_wbase, d_wout;       // prep / windows
   DBuf s_win_i, s_win_nk, s_win_h, s_win_d, s_win_b, s_win_sc, s_win_desc, s_win_h2, s_win_d2, s_win_i2, s_win_nk2, s_win_b2, s_win_sc2, s_win_desc2, d_wout2, d_wovf;
   int win_out2_cap = 0;
+  int poa_max_draft = -1, poa_sum_win = -1;       // from k_poa of THIS batch (-1: the drafts did not come from it)
   DBuf s_zero_d, d_zinfo, d_zflag, d_zwork; std::vector<int> zwork;  // window scratch
   std::vector<Summary> sum; std::vector<int> work;
   int res_prefix = 0;            // entries of peaks[] / sub_beg[] / sub_end[] that any read of the resident batch uses (0: unknown)
@@ -376,7 +387,7 @@ extern "C" int c3_batch_commit(c3_handle* h) {
   HIPCHK(hipGetLastError());
   float ms = 0; HIPCHK(hipEventElapsedTime(&ms, h->ev_up[0], h->ev_up[1]));
   memset(&h->tm, 0, sizeof(h->tm)); h->tm.ms_pack = ms; h->tm.n_reads = n; h->tm.n_bases = h->total;
-  h->stages_done = 0; h->injected = false; h->n_windows = 0; h->res_prefix = 0;
+  h->stages_done = 0; h->injected = false; h->n_windows = 0; h->res_prefix = 0; h->poa_max_draft = h->poa_sum_win = -1;
   return C3_E_OK;
 }
 
@@ -397,7 +408,7 @@ extern "C" int c3_batch_assign(c3_handle* h, const int16_t* splint_id, const cha
   hipLaunchKernelGGL(k_init_info, dim3((h->n + 255) / 256), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), h->n);
   HIPCHK(hipStreamSynchronize(h->stream));
   HIPCHK(hipGetLastError());
-  h->stages_done = 0;
+  h->stages_done = 0; h->poa_max_draft = h->poa_sum_win = -1;
   return C3_E_OK;
 }
 
@@ -675,6 +686,8 @@ static int run_poa(c3_handle* h) {
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipMemcpyAsync(h->phase_poa, h->d_counter.as<char>() + 64, 128, hipMemcpyDeviceToHost, h->stream));
+  hipLaunchKernelGGL(k_draft_stats, dim3((nw + 255) / 256), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), h->d_work.as<int>(), nw, h->cfg.pol_window, h->d_counter.as<int>() + 6);
+  HIPCHK(hipGetLastError());
   return 0;
 }
 
@@ -689,7 +702,11 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     max_ns = std::max(max_ns, h->sum[i].n_sub); max_q = std::max(max_q, h->sum[i].max_sub); max_dang = std::max(max_dang, h->sum[i].max_dang);
     wcap += (2 * h->sum[i].max_sub + WL - 1) / WL + 1;
   }
-  const int NLcap = max_ns + 2, NWcap = (2 * max_q + WL - 1) / WL + 1;
+  int NLcap = max_ns + 2, NWcap = (2 * max_q + WL - 1) / WL + 1;
+  if (h->poa_max_draft >= 0) {       // the drafts exist: the window tables are sized for them, not for a bound (a draft is a path of the graph and can be longer than twice the longest subread)
+    NWcap = (h->poa_max_draft + WL - 1) / WL + 1;
+    wcap = (long long)h->poa_sum_win + 8;
+  }
   const int64_t ecap = ((int64_t)(max_dang + 2) / 3 + 2) * 256;    // 2-bit directions: one dword per lane and three piece rows
   const size_t per_slot_prep = (size_t)ecap + (size_t)NLcap * NWcap * 8;
   const int slots_p = auto_slots(h, h->cfg.slots_poa, per_slot_prep, nw, getenv("C3_DEBUG_PREP_WPC") ? atoi(getenv("C3_DEBUG_PREP_WPC")) : 20);
@@ -845,6 +862,7 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
       HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 64, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       if (!h->work.empty()) h->tm.cells_poa = *(long long*)(cnt + 2);
+      h->poa_max_draft = h->work.empty() ? 0 : cnt[6]; h->poa_sum_win = h->work.empty() ? 0 : cnt[7];
       h->tm.n_poa_redo = h->n_poa_redo; h->tm.n_poa_redo16 = h->n_poa_redo16;
       DBG("run: poa done\n");
       HIPCHK(hipEventElapsedTime(&ms, t3, t4)); h->tm.ms_poa = ms;
@@ -1088,7 +1106,7 @@ static int inject(c3_handle* h, int n, const char* const* subs, const char* cons
   int rc = c3_batch_upload(h, 1, seq.data(), ql.data(), off, &sid, &st);
   if (rc) return rc;
   HIPCHK(hipMemcpy(h->d_info.p, &r, sizeof(r), hipMemcpyHostToDevice));
-  h->injected = true;
+  h->injected = true; h->poa_max_draft = h->poa_sum_win = -1;
   return 0;
 }
 

@@ -41,7 +41,7 @@ typedef enum {
   C3_ST_NO_PEAKS = 2,      /* C3POa.py:125,131 */
   C3_ST_NO_CONSENSUS = 3,  /* repeats == 0, or polish emitted nothing (determine_consensus.py:44-47,97-99) */
   C3_ST_TOO_SHORT = 4,     /* shorter than the smoothing half-window */
-  C3_ST_LIMIT = 5          /* capacity limit: more than 250 kept subreads (peaks beyond C3_MAX_PEAKS), a polishing window graph of more than 65 534 nodes, a draft longer than twice the longest subread;
+  C3_ST_LIMIT = 5          /* capacity limit: more than 250 kept subreads (peaks beyond C3_MAX_PEAKS), a polishing window graph of more than 65 534 nodes;
                               every other scratch of the path is sized from the batch and redone at worst-case size when it overflows */
 } c3_status;
 
