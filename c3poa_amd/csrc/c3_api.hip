@@ -795,6 +795,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     a.ovf_list = h->d_wovf.as<int>();
     c3k_launch_window(&a, slots, h->stream);
     HIPCHK(hipGetLastError());
+    if (getenv("C3_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(h->stream)); DBG("window: first launch done\n"); }
     {
       a.ibase = h->s_win_i2.as<int>(); a.ebase = h->s_win_nk2.as<int>(); a.base = h->s_win_b2.as<uint8_t>(); a.score = h->s_win_sc2.as<long long>();
       a.rdesc = h->s_win_desc2.as<uint4>(); a.Ncap = Ncap2; a.Lcap = std::min(a.Lcap, Ncap2);
@@ -802,6 +803,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
       a.wlist = h->d_wovf.as<int>(); a.n_win_dev = h->d_counter.as<int>() + W_CNT_OVF; a.ovf_list = nullptr;
       c3k_launch_window(&a, slots2, h->stream);
       HIPCHK(hipGetLastError());
+      if (getenv("C3_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(h->stream)); DBG("window: full-size launch done\n"); }
     }
     HIPCHK(hipMemcpyAsync(h->phase_win, h->d_counter.as<char>() + 64, 128, hipMemcpyDeviceToHost, h->stream));
   }

@@ -1164,6 +1164,9 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         }
         const WLayer l = lay[li];
         const int Q = l.len;
+        // (layers beyond W_QCAP bases keep rq / tq in the slot's opq / opn arrays, 2 * Ncap ints each: a longer layer -- a 1 200-base
+        // insertion against a 100-base window -- does not fit the first launch's arrays; the full-size launch has Ncap >= every layer)
+        if (Q > 2 * c.Ncap) { fail = SECOND ? 1 : 2; if (SECOND && lane == 0) atomicAdd(a.counter + W_CNT_WHY + 1, 1); break; }
         const bool full = l.begin < offset && l.end > blen - offset;
         // ---- rows of this alignment (masked sub-graph or everything)
         if (!full) {
