@@ -50,9 +50,42 @@ if __name__ == "__main__":
     tmp = tempfile.mkdtemp(prefix="fuzzcli_", dir=os.environ.get("FUZZ_TMP", "/tmp"))
     try:
         fq, fa, out = tmp + "/reads.fastq", tmp + "/splint.fasta", tmp + "/out"
-        with open(fq, "w") as fh:
-            for nm, (s, q) in zip(names, reads):
-                fh.write("@%s some comment\n%s\n+\n%s\n" % (nm, s, q))
+        # the FASTQ text: sometimes multi-line records, CRLF line ends, no final newline (kseq.h semantics, as mm.fastx_read)
+        style = int(rng.integers(0, 4))
+        parts = []
+        for nm, (s, q) in zip(names, reads):
+            if style == 1 and len(s) > 200:
+                w = int(rng.integers(60, 5000))
+                s_txt = "\n".join(s[i:i + w] for i in range(0, len(s), w)); q_txt = "\n".join(q[i:i + w] for i in range(0, len(q), w))
+            else:
+                s_txt, q_txt = s, q
+            parts.append("@%s some comment\n%s\n+%s\n%s\n" % (nm, s_txt, nm if style == 1 else "", q_txt))
+        text = "".join(parts)
+        if style == 2:
+            text = text.replace("\n", "\r\n")
+        if style == 3:
+            text = text[:-1]
+        data = text.encode()
+        comp = int(rng.integers(0, 3))                              # plain / gzip (one stream) / BGZF (parallel inflate)
+        if comp == 1:
+            import gzip
+            fq += ".gz"
+            with gzip.open(fq, "wb", compresslevel=1) as fh:
+                fh.write(data)
+        elif comp == 2:
+            import struct, zlib
+            fq += ".gz"
+            block = int(rng.choice([0xff00, 4096, 20000]))
+            with open(fq, "wb") as fh:
+                for i in range(0, len(data), block):
+                    chunk = data[i:i + block]
+                    co = zlib.compressobj(1, zlib.DEFLATED, -15)
+                    c_ = co.compress(chunk) + co.flush()
+                    fh.write(struct.pack("<BBBBIBBH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(c_) + 8 - 1)
+                             + c_ + struct.pack("<II", zlib.crc32(chunk), len(chunk)))
+                fh.write(bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"))
+        else:
+            open(fq, "wb").write(data)
         open(fa, "w").write(">Sp1\n%s\n" % splint)
         os.makedirs(out + "/tmp")
         if mode == "psl":
@@ -109,8 +142,8 @@ if __name__ == "__main__":
         if log[1] != "Total reads: %d" % len(reads) or (mode == "psl" and log[3].split(" (")[0] != "Under len cutoff: %d" % n_short):
             bad += 1
             print("DIFFERENT log:", log[1:4], "expected total", len(reads), "short", n_short)
-        print("seed %d mode %s: %d reads (%d processed), splint %d nt, -l %d -d %d -g %d%s, batch %s readers %s: %d consensus + %d subread records, differences %d" % (
-            seed, mode, len(reads), len(keep), len(splint), lencut, mdist, group, "" if zero else " -z", os.environ["C3_GPU_BATCH_READS"], os.environ["C3_READERS_PER_GPU"],
+        print("seed %d mode %s input %s/%s: %d reads (%d processed), splint %d nt, -l %d -d %d -g %d%s, batch %s readers %s: %d consensus + %d subread records, differences %d" % (
+            seed, mode, ("one-line", "multi-line", "CRLF", "no final newline")[style], ("plain", "gzip", "BGZF")[comp], len(reads), len(keep), len(splint), lencut, mdist, group, "" if zero else " -z", os.environ["C3_GPU_BATCH_READS"], os.environ["C3_READERS_PER_GPU"],
             len(got_c), len(got_s), bad))
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
