@@ -42,7 +42,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 # per-GPU reads per step: BASELINE.json configs (cfg3: 1M reads over 8 GPUs)
-DEFAULT_READS = {"cfg1": 1000, "cfg2": 100000, "cfg3": 125000, "cfg4": 100000, "cfg5": 131072, "cfgL": 20000}
+DEFAULT_READS = {"cfg1": 1000, "cfg2": 100000, "cfg3": 125000, "cfg4": 100000, "cfg5": 131072, "cfgL": 50000}
 WORKLOAD_TEXT = {
     "cfg1": "5 kb, 3x1.5 kb repeats (plumbing case)",
     "cfg2": "5 kb, 3x1.5 kb repeats, Splint1, 10% error",

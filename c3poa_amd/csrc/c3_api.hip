@@ -20,6 +20,7 @@ extern "C" void c3k_launch_poa(const PoaArgs*, int, int, int, hipStream_t);
 extern "C" void c3k_launch_prep(const PrepArgs*, int, hipStream_t);
 extern "C" void c3k_launch_window(const WinArgs*, int, hipStream_t);
 extern "C" void c3k_launch_stitch(const StitchArgs*, int, hipStream_t);
+extern "C" void c3k_launch_poa_mw(const PoaArgs*, int slots, hipStream_t);      // the last pass: a workgroup of eight waves per read (k_poa_mw.hip)
 extern "C" void c3k_launch_zero(const ZeroArgs*, int, hipStream_t);
 extern "C" void c3k_launch_zero_finish(const ZeroArgs*, int, hipStream_t);
 
@@ -586,7 +587,11 @@ static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, 
   const bool w32 = d_overflow16 == nullptr || getenv("C3_DEBUG_POA32");      // the pass that takes the reads beyond 16 bits (test hook: every pass)
   const long long far = w32 ? cells : cells >> 2;
   const size_t per_slot = N * (NI * 4 + 8 + 5 + 32 + 4 * C3_JUMP_LEVELS) + N * K * 12 + (size_t)cells * 2 + (size_t)far * 16 + (size_t)Pcap * 4;
-  const int slots = auto_slots(h, h->cfg.slots_poa, per_slot, nw, waves_per_cu);
+  // the pass nothing may outgrow runs as a workgroup of eight waves per read (the reads that reach it are the ones with bands as wide
+  // as the subread: hundreds of ms on one wave); C3_DEBUG_POA_MW=0: the single-wave 32-bit instance instead, C3_DEBUG_POA32=2: every pass (test hooks)
+  const char* e32 = getenv("C3_DEBUG_POA32"); const char* emw = getenv("C3_DEBUG_POA_MW");
+  const bool mw = w32 && ((d_overflow == nullptr && d_overflow16 == nullptr && !(emw && atoi(emw) == 0)) || (e32 && atoi(e32) == 2));
+  const int slots = auto_slots(h, h->cfg.slots_poa, per_slot, nw, mw ? std::max(1, waves_per_cu / 8) : waves_per_cu);
   HIPCHK(h->s_poa_i.ensure(sizeof(int) * N * NI * slots)); HIPCHK(h->s_poa_nk.ensure(sizeof(int) * N * K * 3 * slots));
   HIPCHK(h->s_poa_cells.ensure(((size_t)cells * 2 + (size_t)far * 16) * slots + 256)); HIPCHK(h->s_poa_b.ensure(N * 5 * slots)); HIPCHK(h->s_poa_sc.ensure(sizeof(long long) * N * slots));
   HIPCHK(h->s_poa_desc.ensure(sizeof(uint4) * 2 * N * slots));
@@ -604,9 +609,10 @@ static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, 
   a.msa_dbg = nullptr; a.msa_off = nullptr; a.msa_len = nullptr;
   if (h->debug_msa) { a.msa_dbg = h->d_msa.as<uint8_t>(); a.msa_off = h->d_msa_off.as<int64_t>(); a.msa_len = h->d_msa_len.as<int>(); }
   a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
-  DBG("poa: nw=%d Ncap=%d K=%d cells=%lld slots=%d (%.1f MB per slot)%s\n", nw, Ncap, K, cells, slots, per_slot / 1048576.0, d_overflow ? "" : (d_overflow16 ? " [full-size pass]" : " [32-bit pass]"));
+  DBG("poa: nw=%d Ncap=%d K=%d cells=%lld slots=%d (%.1f MB per slot)%s\n", nw, Ncap, K, cells, slots, per_slot / 1048576.0, d_overflow ? "" : (d_overflow16 ? " [full-size pass]" : (mw ? " [32-bit pass, eight waves per read]" : " [32-bit pass]")));
   // the pass with an overflow list runs the 16-bit rows; the final pass (no list) the 32-bit rows only (C3_DEBUG_POA32: test hook, first pass too)
-  c3k_launch_poa(&a, slots, w32 ? 1 : 0, wide_ring, h->stream);
+  if (mw) c3k_launch_poa_mw(&a, slots, h->stream);
+  else c3k_launch_poa(&a, slots, w32 ? 1 : 0, wide_ring, h->stream);
   HIPCHK(hipGetLastError());
   return 0;
 }

@@ -15,7 +15,17 @@
 #include "c3_args.h"
 #include <type_traits>
 
+#ifdef C3_POA_MW
+// k_poa_mw.hip compiles this file a second time for the LAST pass: a workgroup of C3_POA_MW waves per read.  Wave 0 runs every
+// phase exactly as the single-wave kernel does (its WSYNC is a wave-local fence there, not a barrier); the wide general rows
+// are computed by all waves together (mw_chunks), two phases between three real barriers.
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+// the barrier between the phases of a wide row: cells written by one wave are read by another -- all on one CU, through one
+// vector L1: workgroup scope is enough (an agent-scope release writes the L2 back, microseconds per row)
+#define MW_BARRIER() __syncthreads()
+#else
 #define WSYNC() __syncthreads()
+#endif
 // adjacency slot k of node v.  Slot-major (all first edges, then all second edges, ...): nearly every node has one or two
 // edges, so the arrays a wave actually touches are contiguous runs of Ncap ints instead of one 64-byte line per node
 #define EI(v, k) ((size_t)(k) * (size_t)c.Ncap + (size_t)(v))
@@ -35,6 +45,9 @@ struct Ctx {
   const uint32_t* pk;        // packed read
 #ifdef C3_DEBUG_PUNT
   unsigned long long* dbg;
+#endif
+#ifdef C3_MW_CHECK
+  unsigned long long* chk;
 #endif
 #define CTX_I(name, k) __device__ __forceinline__ int* name() const { return I + (size_t)(k) * Ncap; }
   CTX_I(n_in, 0) CTX_I(n_out, 1) CTX_I(grp, 2) CTX_I(index, 5) CTX_I(gfirst, 6) CTX_I(glast, 7)
@@ -193,6 +206,107 @@ static_assert(3 * RING_CELLS_N * 2 + PQW_N * 4 <= sizeof(L.ring), "the NARROW qu
 #define S9(x) ((x) * 512)
 #define NEGS (-(1 << 29))
 #define NEG2S (-(1 << 30))
+#ifdef C3_POA_MW
+// ---- the wide general rows of the last pass, by all waves of the workgroup.  A read whose band has blown up to the width of the
+// subread (a missed or an extra peak: one subread twice as long as the others) has tens of thousands of rows of up to Q columns;
+// one wave takes 300-600 ms for it.  The row's 64-column chunks are dealt round-robin to the waves.  Phase A: the vertical /
+// diagonal states of the chunk (Ht, E1, E2, their tags) from the predecessor rows -- no dependence between chunks -- and the
+// chunk's scan aggregates into LDS; phase B: the horizontal states from the aggregates of the chunks to the left (what the
+// single-wave loop carries from chunk to chunk), the final H and direction cells.  Bit for bit the arithmetic of the loop below.
+#define MW_CH 512          /* chunks of a row (rows of more columns take the single-wave loop) */
+#define MW_NP 16           /* predecessors of a row handed to the other waves */
+struct MwTask {
+  int cmd, beg, end, nin, vb, fo, ro, ty, qb, pad_;
+  unsigned long long pk;
+  int pb[MW_NP], pe[MW_NP], po[MW_NP];
+  int agg1[MW_CH], agg2[MW_CH], lastht[MW_CH], cmx[MW_CH], fpos[MW_CH], lpos[MW_CH];
+};
+__shared__ MwTask MWT;
+struct MwConst { int mt9_, mm9_, e1_9_, e2_9_, o1_9_, o2_9_; };
+template <int PHASE>
+__device__ void mw_chunks(const Ctx& c, const MwConst& kc, int wave, int lane) {
+  const int beg = MWT.beg, end = MWT.end, nin = MWT.nin, vb = MWT.vb, fo = MWT.fo, ro = MWT.ro, ty = MWT.ty, qb = MWT.qb;
+  const uint32_t* pk = (const uint32_t*)MWT.pk;
+  const int wd = end - beg + 1, nch = (wd + 63) >> 6;
+  const int oe1 = kc.o1_9_ + kc.e1_9_, oe2 = kc.o2_9_ + kc.e2_9_;
+#ifdef C3_MW_MASTER_ONLY
+  for (int ci = wave == 0 ? 0 : nch; ci < nch; ci += 1) {
+#else
+  for (int ci = wave; ci < nch; ci += C3_POA_MW) {
+#endif
+    const int c0 = 64 * ci;
+    const int j = beg + c0 + lane;
+    const bool act = j <= end;
+    const int cix = c0 + lane;
+    const int cl1 = kc.e1_9_ * (lane + c0), cl2 = kc.e2_9_ * (lane + c0);             // e * (column - beg)
+    if (PHASE == 0) {
+      int kM = INT32_MIN, kE1 = INT32_MIN, kE2 = INT32_MIN;
+      for (int k = 0; k < nin; ++k) {
+        const int b = MWT.pb[k], e = MWT.pe[k], po = MWT.po[k];
+        const bool vd = j > 0 && j - 1 >= b && j - 1 <= e, vp = j >= b && j <= e;
+        int hd = NEGS, hp = NEGS, e1p = NEGS, e2p = NEGS;
+        if (vd) hd = c.H()[po + (j - 1 - b)];
+        if (vp) { hp = c.H()[po + (j - b)]; e1p = c.E1()[po + (j - b)]; e2p = c.E2()[po + (j - b)]; }
+        kM = max(kM, hd + (511 - k));
+        kE1 = max(kE1, max(hp - oe1 + (511 - 2 * k), e1p - kc.e1_9_ + (510 - 2 * k)));
+        kE2 = max(kE2, max(hp - oe2 + (511 - 2 * k), e2p - kc.e2_9_ + (510 - 2 * k)));
+      }
+      int qc = 7;
+      if (act && j > 0) qc = c3_code_at(pk, qb + j - 1);
+      const int M9 = (j > 0) ? (kM & ~511) + ((vb == qc) ? kc.mt9_ : kc.mm9_) : NEGS;
+      const int E1v = kE1 & ~511, E2v = kE2 & ~511;
+      const int k2 = max(max(M9 + 2, E1v + 1), E2v);
+      const int ht9 = k2 & ~511;
+      const unsigned mp = 511u - ((unsigned)kM & 511u), c1 = 511u - ((unsigned)kE1 & 511u), c2 = 511u - ((unsigned)kE2 & 511u);
+      const unsigned d = ((~c1) & 1u) | (((~c2) & 1u) << 1) | (((unsigned)k2 & 3u) << 2);
+      const unsigned pby = mp | ((c1 >> 1) << 2) | ((c2 >> 1) << 4);
+      const unsigned dw = mp | (c1 << 8) | (c2 << 17) | ((unsigned)(2 - (k2 & 3)) << 26);
+      const int htm = act ? ht9 : NEG2S;
+      int s1 = htm + cl1, s2 = htm + cl2, s3 = htm;
+      wave_scan_max3(s1, s2, s3);
+      // (read out of the scans HERE, by every lane: taken inside the one-lane branch below, the scans' DPP steps were sunk into it
+      // with it and ran with one lane enabled)
+      const int cm = wave_bcast(s3, 63), g1 = wave_bcast(s1, 63), g2 = wave_bcast(s2, 63), lh = wave_bcast(htm, 63);
+      const unsigned long long mm = __ballot(htm == cm);
+      if (lane == 0) {
+        MWT.agg1[ci] = g1; MWT.agg2[ci] = g2; MWT.lastht[ci] = lh; MWT.cmx[ci] = cm;
+        MWT.fpos[ci] = beg + c0 + __builtin_ctzll(mm); MWT.lpos[ci] = beg + c0 + 63 - __builtin_clzll(mm);
+      }
+      if (act) {
+        if (ty == 2) c.D()[fo + cix] = dw;
+        else { c.D8()[(unsigned)(ro + cix)] = (uint8_t)d; if (ty == 1) c.P8()[(unsigned)(ro + cix)] = (uint8_t)pby; }
+        c.H()[fo + cix] = ht9; c.E1()[fo + cix] = E1v; c.E2()[fo + cix] = E2v;          // (H: Ht until phase B)
+
+      }
+    } else {
+      // what the chunks to the left hand over: the maxima of their two scans, the last Ht
+      int a1 = NEG2S, a2 = NEG2S;
+      for (int x = lane; x < ci; x += 64) { a1 = max(a1, MWT.agg1[x]); a2 = max(a2, MWT.agg2[x]); }
+      const int carry1 = wave_max(a1), carry2 = wave_max(a2);
+      const int prev_ht = ci > 0 ? MWT.lastht[ci - 1] : NEGS;
+      const int ht9 = act ? c.H()[fo + cix] : 0;
+      const int htm = act ? ht9 : NEG2S;
+      int s1 = htm + cl1, s2 = htm + cl2, s3 = htm;
+      wave_scan_max3(s1, s2, s3);
+      const int px1 = max(wave_shr1(s1, NEG2S), carry1), px2 = max(wave_shr1(s2, NEG2S), carry2);
+      const int htl = wave_shr1(htm, prev_ht);
+      int f1, f2; unsigned f1x = 0, f2x = 0;
+      if (j == beg) { f1 = f2 = NEG2S; }
+      else {
+        f1 = px1 - kc.o1_9_ - cl1; f2 = px2 - kc.o2_9_ - cl2;
+        f1x = f1 != htl - oe1; f2x = f2 != htl - oe2;
+      }
+      const int k3 = max(max(ht9 + 2, f1 + 1), f2);
+      const int h9 = k3 & ~511;
+      if (act) {
+        if (ty == 2) c.D()[fo + cix] |= ((unsigned)(2 - (k3 & 3)) << 28) | (f1x << 30) | (f2x << 31);
+        else c.D8()[(unsigned)(ro + cix)] |= (uint8_t)((((unsigned)k3 & 3u) << 4) | (f1x << 6) | (f2x << 7));
+        c.H()[fo + cix] = h9;
+      }
+    }
+  }
+}
+#endif
 // fast / near rows and the ring: biased unsigned 16-bit keys, (score - row base) * 8 + BIAS16 (+ 3 tag bits while candidates compete)
 #define S3(x) ((x) * 8)
 #define BIAS16 32768
@@ -300,6 +414,9 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
 #define o2_9 (o2_8 << 6)
 #define oe1_9 (oe1_8 << 6)
 #define oe2_9 (oe2_8 << 6)
+#ifdef C3_POA_MW
+  const MwConst mwk = {mt9, mm9, e1_9, e2_9, o1_9, o2_9};
+#endif
   const int w = wave_first(P.band_b + (int)(P.band_f * (double)Q));
   const int le1_8 = e1_8 * lane, le2_8 = e2_8 * lane;               // the F scans run in lane coordinates: e*(j-beg) = e*lane
 #define le1 (le1_8 << 6)
@@ -668,7 +785,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
 #ifdef C3_DEBUG_PUNT
     if ((toglobal || ovf) && fo + wd > c.far_cap() && lane == 0) { atomicAdd(c.dbg + 13, 1ull); atomicMax(c.dbg + 11, ((unsigned long long)(unsigned)fo << 32) | (unsigned)c.far_cap()); }
 #endif
-    if (toglobal || ovf) { if (fo + wd > c.far_cap()) return -4; u_nfar = fo + wd; }
+    if (toglobal || ovf) { if (fo + wd > c.far_cap()) return (!W32 && WIDE) ? -6 : -4; u_nfar = fo + wd; }      // (-6: the far arena of a 16-bit pass over LONG subreads -- a band that blew up to thousands of columns; such a read goes straight to the last pass, whose wide rows eight waves share)
     const int ro = ncell;
     const int ty = ovf ? 2 : (nin >= 2 ? 1 : 0);                   // cell format: byte / byte + predecessor byte / 32-bit word
     ncell += wd;
@@ -678,6 +795,46 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     int gH = NEG16, gE1 = NEG16, gE2 = NEG16;    // the row's 16-bit cells (first chunk) for a fast successor
     int Wg = 0;                                  // the base its ring cells are kept against: the maximum of its first chunk
     int bad = 0;
+#ifdef C3_POA_MW
+    const int nch_ = (wd + 63) >> 6;
+    #ifndef C3_MW_COND
+#define C3_MW_COND 1
+#endif
+    #ifndef MW_MINCH
+#define MW_MINCH 3
+#endif
+    const bool mw_row = W32 && v != SRC && nch_ >= MW_MINCH && nch_ <= MW_CH && nin <= MW_NP && (C3_MW_COND);
+    if (mw_row) {
+      if (lane == 0) {
+        MWT.cmd = 1; MWT.beg = beg; MWT.end = end; MWT.nin = nin; MWT.vb = vb; MWT.fo = fo; MWT.ro = ro; MWT.ty = ty; MWT.qb = qb;
+        MWT.pk = (unsigned long long)c.pk;
+      }
+      if (lane < nin) {                           // lane k fetches predecessor k: one round trip for all of them
+        const int pi = lane == 0 ? p0 : lane == 1 ? p1 : lane == 2 ? p2 : lane == 3 ? p3 : c.index()[c.in_from()[EI(v, lane)]];
+        MWT.pb[lane] = c.rowm()[3 * pi]; MWT.pe[lane] = c.rowm()[3 * pi + 1] & 0x0fffffff; MWT.po[lane] = c.foff()[pi];
+      }
+      MW_BARRIER();
+      mw_chunks<0>(c, mwk, 0, lane);
+      MW_BARRIER();
+      mw_chunks<1>(c, mwk, 0, lane);
+      MW_BARRIER();
+      // the row's maximum and its leftmost / rightmost column: first chunk that reaches it, last chunk that equals it
+      int bx = INT32_MIN;
+      for (int x = lane; x < nch_; x += 64) bx = max(bx, MWT.cmx[x]);
+      bx = wave_max(bx);
+      int fx = INT32_MAX, lx = -1;
+      for (int x = lane; x < nch_; x += 64) if (MWT.cmx[x] == bx) { fx = min(fx, x); lx = max(lx, x); }
+      fx = wave_min(fx); lx = wave_max(lx);
+      best = bx; bl = MWT.fpos[fx]; br = MWT.lpos[lx];
+      Wg = u_b8;
+    }
+#ifdef C3_MW_CHECK
+    const int mw_best = best, mw_bl = bl, mw_br = br;
+    if (mw_row) { best = INT32_MIN; bl = br = 0; }
+#else
+    else
+#endif
+#endif
     for (int c0 = 0; c0 < wd; c0 += 64) {
       const int j = beg + c0 + lane;
       const bool act = j <= end;
@@ -758,6 +915,13 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
         f1 = px1 - o1_9 - cl1; f2 = px2 - o2_9 - cl2;
         f1x = f1 != htl - oe1_9; f2x = f2 != htl - oe2_9;
       }
+#if defined(C3_POA_MW) && defined(C3_MW_CHECK)
+      if (mw_row && lane == 0) {              // the chunk aggregates of phase A against this loop's
+        if (wave_bcast(s1, 63) != MWT.agg1[c0 >> 6]) atomicAdd(c.chk + 8, 1ull);
+        if (wave_bcast(s2, 63) != MWT.agg2[c0 >> 6]) atomicAdd(c.chk + 9, 1ull);
+        if (wave_bcast(htm, 63) != MWT.lastht[c0 >> 6]) atomicAdd(c.chk + 10, 1ull);
+      }
+#endif
       carry1 = max(carry1, wave_bcast(s1, 63)); carry2 = max(carry2, wave_bcast(s2, 63));
       prev_ht = wave_bcast(htm, 63);
       const int k3 = max(max(ht9 + 2, f1 + 1), f2);
@@ -770,6 +934,14 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       // that share a base must not start a new one, or every row next to it sees predecessors on different bases and turns
       // general too; only when its own maximum does not fit that base does it take the maximum (as the other rows do)
       if (c0 == 0) { Wg = u_b8; const int r_ = (cmx >> 6) - Wg + BIAS16; if (cmx > NEGS / 2 && (unsigned)(r_ - RB_LO16) > (unsigned)c.rb_span) Wg = cmx >> 6; }
+#if defined(C3_POA_MW) && defined(C3_MW_CHECK)
+      if (act && mw_row) {
+        const int ci = c0 + lane;
+#define MWCHK(mem, val, kind) if ((mem) != (val)) { atomicAdd(c.chk + (kind), 1ull); }
+        if (ty == 2) { MWCHK(c.D()[fo + ci], dw, 0) } else { MWCHK(c.D8()[(unsigned)(ro + ci)], (uint8_t)d, 1) if (ty == 1) { MWCHK(c.P8()[(unsigned)(ro + ci)], (uint8_t)pby, 2) } }
+        MWCHK(c.H()[fo + ci], h9, 3) MWCHK(c.E1()[fo + ci], E1v, 4) MWCHK(c.E2()[fo + ci], E2v, 5)
+      }
+#endif
       if (act) {
         const int ci = c0 + lane;
         if (ty == 2) c.D()[fo + ci] = dw;
@@ -787,6 +959,9 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
       if (cmx > best) { best = cmx; const unsigned long long mm = __ballot(htm == cmx); bl = beg + c0 + __builtin_ctzll(mm); br = beg + c0 + 63 - __builtin_clzll(mm); }
       else if (cmx == best) { const unsigned long long mm = __ballot(htm == cmx); if (mm) br = beg + c0 + 63 - __builtin_clzll(mm); }
     }
+#if defined(C3_POA_MW) && defined(C3_MW_CHECK)
+    if (mw_row && lane == 0) { if (mw_best != best) atomicAdd(c.chk + 6, 1ull); if (mw_bl != bl || mw_br != br) { atomicAdd(c.chk + 7, 1ull); } }
+#endif
     if (!W32 && __builtin_amdgcn_ballot_w64(bad != 0) != 0) punt |= 2;
     // leftmost / rightmost argmax -> band hints read by the successors
     const int left = wd > 0 ? bl : 0, right = wd > 0 ? br : 0;
@@ -1052,6 +1227,7 @@ __device__ int pairwise_merge(const uint8_t* rowA, const uint8_t* rowB, int ncol
 
 // stand-alone stage probe: pairwise_consensus(msa_rows, subreads, quals) (bin/consensus.py:76-81) for one pair.
 // rows: 2 x ncol codes; scratch: 2 x ncol bytes; out: ncol bytes of codes, out_len[0] = their number.
+#ifndef C3_POA_MW
 __global__ void k_pairwise(const uint8_t* rows, int ncol, const uint8_t* qualA, int lenA, const uint8_t* qualB, int lenB,
                            uint8_t* scratch, uint8_t* out, int* out_len) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -1063,6 +1239,7 @@ extern "C" void c3k_launch_pairwise(const uint8_t* rows, int ncol, const uint8_t
                                     uint8_t* scratch, uint8_t* out, int* out_len, hipStream_t s) {
   hipLaunchKernelGGL(k_pairwise, dim3(1), dim3(64), 0, s, rows, ncol, qa, la, qb, lb, scratch, out, out_len);
 }
+#endif
 
 // 6 waves/SIMD (80 VGPRs, 26 spilled outside the row loop) with a 4-row LDS ring (6.7 KB per wave, 24 waves per CU):
 // 59.4 ms per 32768 cfg2 reads against 67.8 ms at 4 waves/SIMD with the 8-row ring -- the row loop is a dependent
@@ -1073,7 +1250,11 @@ extern "C" void c3k_launch_pairwise(const uint8_t* rows, int ncol, const uint8_t
 #define C3_POA_WAVES 6
 #endif
 template <bool W32, bool DEF, bool WIDE>
+#ifdef C3_POA_MW
+__global__ __launch_bounds__(64 * C3_POA_MW) void k_poa(PoaArgs a) {
+#else
 __global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
+#endif
   const int lane = wave_lane();
   const int slot = blockIdx.x;
   Ctx c;
@@ -1085,6 +1266,24 @@ __global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
   c.K = a.K; c.Ncap = a.Ncap; c.cells_cap = a.cells_cap; c.osel = 0; c.rb_span = a.rb_span > 0 ? a.rb_span : RB_HI16 - RB_LO16;
 #ifdef C3_DEBUG_PUNT
   c.dbg = a.phases;
+#endif
+#ifdef C3_MW_CHECK
+  c.chk = a.phases;
+#endif
+#ifdef C3_POA_MW
+  if (threadIdx.x >= 64) {                      // the other waves: wide rows on request, nothing else
+    const int wave = (int)(threadIdx.x >> 6);
+    const int m8 = S3(a.p.poa_match), x8 = S3(-a.p.poa_mismatch);
+    const MwConst kc = {m8 << 6, x8 * 64, S3(a.p.e1) << 6, S3(a.p.e2) << 6, S3(a.p.o1) << 6, S3(a.p.o2) << 6};
+    for (;;) {
+      MW_BARRIER();
+      if (MWT.cmd == 2) return;
+      mw_chunks<0>(c, kc, wave, lane);
+      MW_BARRIER();
+      mw_chunks<1>(c, kc, wave, lane);
+      MW_BARRIER();
+    }
+  }
 #endif
   PH_DECL
 
@@ -1119,7 +1318,7 @@ __global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
       int poff = 0;
       for (int s = 0; s < ns && !fail; ++s) {
         const int qb = wave_first(info->sub_beg[s]), Q = wave_first(info->sub_end[s]) - qb;
-        if (s > 0) { const int rc = poa_align<W32, DEF, WIDE>(c, a.p, qb, Q, lane, &cells PHP); if (rc < 0) { fail = (rc == -4 || rc == -5) ? 2 : 1; punted = rc == -5; break; } }
+        if (s > 0) { const int rc = poa_align<W32, DEF, WIDE>(c, a.p, qb, Q, lane, &cells PHP); if (rc < 0) { fail = (rc == -4 || rc == -5 || rc == -6) ? 2 : 1; punted = rc == -5 || rc == -6; break; } }
         if (poa_fuse(c, s == 0, qb, Q, c.path() + poff, lane PHP) < 0) { fail = 2; break; }                 // node capacity
         poff += Q;
       }
@@ -1303,8 +1502,17 @@ __global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
     WSYNC();
   }
   PH_FLUSH(a.phases)
+#ifdef C3_POA_MW
+  if (lane == 0) MWT.cmd = 2;
+  MW_BARRIER();
+#endif
 }
 
+#ifdef C3_POA_MW
+extern "C" void c3k_launch_poa_mw(const PoaArgs* a, int slots, hipStream_t stream) {
+  hipLaunchKernelGGL((k_poa<true, false, false>), dim3(slots), dim3(64 * C3_POA_MW), 0, stream, *a);
+}
+#else
 extern "C" void c3k_launch_poa(const PoaArgs* a, int slots, int wide32, int wide_ring, hipStream_t stream) {
   const C3Params& p = a->p;
   const bool def = p.poa_match == 5 && p.poa_mismatch == 4 && p.o1 == 4 && p.e1 == 2 && p.o2 == 24 && p.e2 == 1;
@@ -1314,3 +1522,4 @@ extern "C" void c3k_launch_poa(const PoaArgs* a, int slots, int wide32, int wide
   else { if (def) C3_POA_LAUNCH(false, true, false); else C3_POA_LAUNCH(false, false, false); }
 #undef C3_POA_LAUNCH
 }
+#endif

@@ -63,7 +63,8 @@ def test_sixteen_bit_cells_equal_the_oracle_and_hand_nothing_over(cfg, n):
     ores, ocons = O.process_batch(synth.SPLINT1, [(r[1], r[2]) for r in recs], [r[3] for r in recs],
                                   params=O.default_params(mdistcutoff=md), threads=8)
     cells = sum(int(r.cells_poa) for r in ores)
-    for env in ({}, {"C3_DEBUG_POA_RBSPAN": "3300"}, {"C3_DEBUG_POA_RBSPAN": "4000"}, {"C3_DEBUG_POA32": "1"}):
+    # (C3_DEBUG_POA32 = 1: everything through the single-wave 32-bit instance, 2: through the eight-wave workgroup of the last pass)
+    for env in ({}, {"C3_DEBUG_POA_RBSPAN": "3300"}, {"C3_DEBUG_POA_RBSPAN": "4000"}, {"C3_DEBUG_POA32": "1"}, {"C3_DEBUG_POA32": "2"}):
         res, cons, t = _run(recs, md, env)
         for i in range(n):
             assert res[i]["status"] == ores[i].status and cons[i] == ocons[i], (cfg, env, i)
@@ -93,7 +94,7 @@ def test_msa_rows_survive_a_moving_base():
 
 
 @pytest.mark.parametrize("cfg,n,envs", [
-    ("cfgL", 10, ({}, {"C3_DEBUG_POA_WIDE": "0"}, {"C3_DEBUG_POA_RBSPAN": "3300"})),       # 3 kb / 6 kb inserts: WIDE ring by default
+    ("cfgL", 10, ({}, {"C3_DEBUG_POA_WIDE": "0"}, {"C3_DEBUG_POA_RBSPAN": "3300"}, {"C3_DEBUG_POA32": "2"})),       # 3 kb / 6 kb inserts: WIDE ring by default; the last pass's workgroup kernel (rows of 3+ chunks by eight waves)
     ("cfg2", 64, ({"C3_DEBUG_POA_WIDE": "1"},)),                                            # the WIDE instance on ordinary reads
     ("cfg4", 12, ({"C3_DEBUG_POA_WIDE": "1"},)),
 ])
@@ -112,4 +113,4 @@ def test_long_subreads_and_the_wide_ring(cfg, n, envs):
         res, cons, t = _run(recs, md, env)
         for i in range(n):
             assert res[i]["status"] == ores[i].status and cons[i] == ocons[i], (cfg, env, i)
-        assert t["cells_poa"] == cells and t["n_poa_redo16"] == 0, (cfg, env, t["n_poa_redo16"])
+        assert t["cells_poa"] == cells and (t["n_poa_redo16"] == 0 or "C3_DEBUG_POA32" in env), (cfg, env, t["n_poa_redo16"])

@@ -7,7 +7,7 @@ make -s -j8 >/dev/null
 HIPCC=/opt/rocm/bin/hipcc
 $HIPCC -O1 -g -fPIC -std=c++17 -fsanitize=address -fno-gpu-sanitize -shared-libsan -c c3_io.cpp -o build/c3_io_asan.o
 $HIPCC --offload-arch=gfx950 -shared -fPIC -fsanitize=address -fno-gpu-sanitize -shared-libsan -o ../lib/libc3poa_hip_hostasan.so \
-  build/k_conk.o build/k_peaks.o build/k_poa.o build/k_polish.o build/k_zero.o build/k_adapter.o build/c3_api.o build/c3_io_asan.o -lz
+  build/k_conk.o build/k_peaks.o build/k_poa.o build/k_poa_mw.o build/k_polish.o build/k_zero.o build/k_adapter.o build/c3_api.o build/c3_io_asan.o -lz
 cd ../..
 RT=$(find /opt/rocm/lib/llvm -name "libclang_rt.asan-x86_64.so" | head -1)
 LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0 C3POA_LIB=c3poa_amd/lib/libc3poa_hip_hostasan.so \
