@@ -91,7 +91,7 @@ typedef struct {
   int64_t n_band_layers, n_band_fallback;   /* window layers aligned in a band and accepted / redone unbanded after a failed certificate */
   int64_t n_band_mismatch;                  /* C3_DEBUG_BAND=verify only: accepted band layers whose traceback differs from the full matrix's (must be 0) */
   int64_t n_win_redo;                       /* windows with a layer beyond the first launch's DP scratch, redone by the full-size second launch of k_window */
-  int64_t n_poa_redo16;                     /* of n_poa_redo: reads redone by the 32-bit POA pass -- a score did not fit the 16-bit cells of the first passes, or the 32-bit cells of its wide / far rows did not fit the arena of the full-size pass (0 on the config shapes) */
+  int64_t n_poa_redo16;                     /* of n_poa_redo: reads redone by the LAST POA pass (32-bit cells, a workgroup of eight waves per read) -- a score did not fit the 16-bit cells of the first passes, or the far arena of a pass overflowed (long subreads: a band that blew up goes straight there) */
 } c3_timing;
 
 typedef struct c3_handle c3_handle;
