@@ -214,6 +214,7 @@ static_assert(3 * RING_CELLS_N * 2 + PQW_N * 4 <= sizeof(L.ring), "the NARROW qu
 // chunk's scan aggregates into LDS; phase B: the horizontal states from the aggregates of the chunks to the left (what the
 // single-wave loop carries from chunk to chunk), the final H and direction cells.  Bit for bit the arithmetic of the loop below.
 #define MW_CH 512          /* chunks of a row (rows of more columns take the single-wave loop) */
+#define MW_MINCH 3         /* ... and rows of fewer chunks than this as well: three barriers cost more than two chunks */
 #define MW_NP 16           /* predecessors of a row handed to the other waves */
 struct MwTask {
   int cmd, beg, end, nin, vb, fo, ro, ty, qb, pad_;
@@ -229,11 +230,7 @@ __device__ void mw_chunks(const Ctx& c, const MwConst& kc, int wave, int lane) {
   const uint32_t* pk = (const uint32_t*)MWT.pk;
   const int wd = end - beg + 1, nch = (wd + 63) >> 6;
   const int oe1 = kc.o1_9_ + kc.e1_9_, oe2 = kc.o2_9_ + kc.e2_9_;
-#ifdef C3_MW_MASTER_ONLY
-  for (int ci = wave == 0 ? 0 : nch; ci < nch; ci += 1) {
-#else
   for (int ci = wave; ci < nch; ci += C3_POA_MW) {
-#endif
     const int c0 = 64 * ci;
     const int j = beg + c0 + lane;
     const bool act = j <= end;
@@ -797,13 +794,7 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
     int bad = 0;
 #ifdef C3_POA_MW
     const int nch_ = (wd + 63) >> 6;
-    #ifndef C3_MW_COND
-#define C3_MW_COND 1
-#endif
-    #ifndef MW_MINCH
-#define MW_MINCH 3
-#endif
-    const bool mw_row = W32 && v != SRC && nch_ >= MW_MINCH && nch_ <= MW_CH && nin <= MW_NP && (C3_MW_COND);
+    const bool mw_row = W32 && v != SRC && nch_ >= MW_MINCH && nch_ <= MW_CH && nin <= MW_NP;      // (narrower rows: wave 0 alone, no barrier)
     if (mw_row) {
       if (lane == 0) {
         MWT.cmd = 1; MWT.beg = beg; MWT.end = end; MWT.nin = nin; MWT.vb = vb; MWT.fo = fo; MWT.ro = ro; MWT.ty = ty; MWT.qb = qb;
