@@ -177,9 +177,13 @@ if __name__ == "__main__":
         sys.exit(1)
     if not os.environ.get("C3_NO_EARLY_WARM"):          # (A/B hook of tools/cli_throughput.py)
         early_warm(args.numThreads)
-    main(args, one_shot=True)
-    for th_ in _WARMERS:                          # never leave while a thread is still inside HIP initialisation
-        th_.join()
+    try:
+        main(args, one_shot=True)
+    finally:
+        # never leave -- normally, by sys.exit or by an exception (a refused FASTA input, a bad path) -- while a thread is still inside
+        # HIP initialisation: the interpreter's and the runtime's teardown beside it can hang or crash a run that should end with rc 1
+        for th_ in _WARMERS:
+            th_.join()
     # every output file has been written and closed; skip the interpreter's and the HIP runtime's teardown (unpinning the reader
     # buffers, freeing the device scratch: ~1.5 s that produce nothing)
     sys.stdout.flush(); sys.stderr.flush()

@@ -64,7 +64,52 @@ def kernel_src_sha():
     return hsh.hexdigest()[:16]
 
 
-def parity_sample(recs, n_unique, res, cbuf, coff, mdist, k=64, seed=1234):
+PROFILE_TAGS = ("r05", "r04", "r03", "r02", "r01")
+SIMDS = 1024              # 256 CUs x 4 SIMDs
+
+
+def pmc_traffic_lookup(profiles_dir, cfg, reads, dom, sha):
+    """HBM bytes per launch of kernel `dom` from the newest committed rocprofv3 PMC summary of this workload -- ONLY when that summary
+    was measured on the kernel sources running here (same hash); otherwise traffic is None and the source says what exists.
+    PMC counters cannot be collected from inside this process (tools/profile_round.sh + tools/collect_profiles.py make the file)."""
+    for tag in PROFILE_TAGS:
+        name = "%s_pmc_traffic_%s_%dk.json" % (tag, cfg, reads // 1000)
+        try:
+            pm = json.load(open(os.path.join(profiles_dir, name)))
+            t_ = pm["kernels"][dom.replace("ms_", "k_")]["hbm_bytes_per_launch"]
+        except Exception:
+            continue
+        if pm.get("kernel_src_sha") == sha:
+            return t_, "profiles/%s (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024; kernel sources %s = this build)" % (name, sha)
+        # measured on other kernels than the ones running here: not this run's traffic
+        return None, "none for this build (kernel sources %s; profiles/%s was measured on %s: %.4g bytes per launch)" % (
+            sha, name, pm.get("kernel_src_sha", "an earlier round's kernels"), t_)
+    return None, None
+
+
+def valu_lookup(profiles_dir, cfg, dom, sha):
+    """what actually binds the DP kernels -- vector instruction issue -- from the newest committed SQ-counter summary of this config
+    (tools/pmc_sq.sh -> profiles/rNN_sq_counters_<cfg>.json), under the same kernel-source-hash rule as the traffic"""
+    for tag in PROFILE_TAGS:
+        name = "%s_sq_counters_%s.json" % (tag, cfg)
+        try:
+            sq = json.load(open(os.path.join(profiles_dir, name)))
+            k = sq["kernels"][dom.replace("ms_", "k_")]
+        except Exception:
+            continue
+        if sq.get("kernel_src_sha") != sha:
+            return {"insts_per_cell": None, "busy_frac": None,
+                    "source": "none for this build (kernel sources %s; profiles/%s was measured on %s: %.3f vector wave-instructions per cell)" % (
+                        sha, name, sq.get("kernel_src_sha", "an earlier round's kernels"), k.get("insts_per_cell") or 0.0)}
+        return {"insts_per_cell": k.get("insts_per_cell"), "busy_frac": k.get("busy_frac"),
+                "insts_per_simd_cycle": k.get("insts_per_simd_cycle"), "cycles_per_inst_assumed": sq.get("cycles_per_inst_assumed"),
+                "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU / SQ_BUSY_CYCLES on tools/phase_prof.py %s %s; busy_frac = vector wave-instructions x "
+                          "%.2f issue cycles (mean of the two instruction classes of tools/ubench/valu_cost.hip) / SIMD cycles of the kernel; kernel sources %s = this build)" % (
+                              name, sq.get("reads"), cfg, sq.get("cycles_per_inst_assumed") or 0.0, sha)}
+    return {"insts_per_cell": None, "busy_frac": None, "source": None}
+
+
+def parity_sample(recs, n_unique, res, cbuf, coff, mdist, k=1024, seed=1234):
     """CHECKER (outside every timed region): the oracle on k random reads of the batch the last step processed; counts reads
     whose status or consensus bytes differ from what the GPU delivered for them"""
     from c3poa_amd import synth
@@ -154,6 +199,7 @@ def parse_args(argv=None):
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic reads generated per rank (0 = all)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--parity-reads", type=int, default=1024, help="random reads of the last batch (of every config run) checked against the oracle after the timed region")
     ap.add_argument("--other-configs", default="auto",
                     help="comma list of further configs run for 3 steps after the headline (rank 0, N=1): 'auto' = cfg3,cfg4,cfgL "
                          "when the headline is cfg2 at full size, 'none' = skip")
@@ -276,8 +322,12 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     fetcher.close()
+    per_rank_ms = [round(dt / a.steps * 1e3, 3)]
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+        # every rank's own step time (the line's ms_per_step is their MAX): an imbalance between GPUs shows in the driver's SCALE line
+        per_rank_ms = [None] * world
+        dist.all_gather_object(per_rank_ms, round(dt / a.steps * 1e3, 3))
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     tm = h.last_timing
@@ -309,25 +359,13 @@ def main():
                            for i in range(n_id)])
         # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the number
         # comes from the committed rocprofv3 passes of THIS command when the workload matches
-        traffic, tsrc = None, None
         sha = kernel_src_sha()
-        for tag in ("r04", "r03", "r02", "r01"):
-            try:
-                name = "%s_pmc_traffic_%s_%dk.json" % (tag, a.cfg, a.reads // 1000)
-                pm = json.load(open(os.path.join(ROOT, "profiles", name)))
-                t_ = pm["kernels"][dom.replace("ms_", "k_")]["hbm_bytes_per_launch"]
-            except Exception:
-                continue
-            if pm.get("kernel_src_sha") == sha:
-                traffic = t_
-                tsrc = "profiles/%s (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024; kernel sources %s = this build)" % (name, sha)
-            else:               # measured on other kernels than the ones running here: not this run's traffic
-                tsrc = "none for this build (kernel sources %s; profiles/%s was measured on %s: %.4g bytes per launch)" % (
-                    sha, name, pm.get("kernel_src_sha", "an earlier round's kernels"), t_)
-            break
+        traffic, tsrc = pmc_traffic_lookup(os.path.join(ROOT, "profiles"), a.cfg, a.reads, dom, sha)
+        valu = valu_lookup(os.path.join(ROOT, "profiles"), a.cfg, dom, sha)
         out = {
             "metric": "R2C2 reads->consensus/sec", "value": round(value, 1), "unit": "reads/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "per_rank_ms_per_step": per_rank_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32",
             "data": "synthetic (c3poa_amd.synth %s: %d distinct reads%s)" % (
                 a.cfg, n_unique, "" if reps == 1 else ", tiled x%d" % reps),
@@ -351,15 +389,22 @@ def main():
                          "windows": int(tm["n_windows"]), "windows_second_launch": int(tm["n_win_redo"]),
                          "cells_poa": int(tm["cells_poa"]), "poa_gcells_per_s": round(tm["cells_poa"] / (avg["ms_poa"] * 1e-3) / 1e9, 1),
                          "poa_second_pass_reads": int(tm["n_poa_redo"]), "poa_reads_beyond_16bit": int(tm["n_poa_redo16"]),
-                         "gcups": round(cells / (sum(avg.values()) * 1e-3) / 1e9, 2)},
+                         # cell updates per second of kernel time.  gcups_computed counts the cells the kernels COMPUTE (conk + POA + the banded
+                         # polish rows); gcups_full_matrices counts what the oracle's full polish matrices hold (the figure printed as "gcups"
+                         # until round 4) -- the band's certificate makes the two results identical, not the two amounts of work
+                         "gcups_computed": round((tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish_computed"]) / (sum(avg.values()) * 1e-3) / 1e9, 2),
+                         "gcups_full_matrices": round(cells / (sum(avg.values()) * 1e-3) / 1e9, 2),
+                         # what binds the dominant kernel is vector instruction issue, not HBM: instructions per counted cell and the
+                         # share of the SIMDs' issue cycles they fill, from the committed SQ-counter pass of this build (None otherwise)
+                         "valu": valu},
             "gen_s": round(t_gen, 1),
         }
     h.close()
     host.close()
     if rank == 0 and not a.no_cpu:
-        out["parity_sample"] = parity_sample(recs, n_unique, res, cbuf, coff, md)
+        out["parity_sample"] = parity_sample(recs, n_unique, res, cbuf, coff, md, k=a.parity_reads)
     if rank == 0 and world == 1 and other_recs:
-        out["other_configs"] = {c: run_other_config(c, local_rank, *other_recs[c], check=not a.no_cpu) for c in other_recs}
+        out["other_configs"] = {c: run_other_config(c, local_rank, *other_recs[c], check=not a.no_cpu, parity_reads=a.parity_reads) for c in other_recs}
     if rank == 0 and world == 1 and not a.no_cpu:
         out["cpu_baseline"] = cpu_baseline(recs, md, a.cpu_seconds)
     if dist is not None:
@@ -369,9 +414,9 @@ def main():
         print(json.dumps(out))
 
 
-def run_other_config(cfg, device, recs, gen_s, steps=3, check=True):
+def run_other_config(cfg, device, recs, gen_s, steps=3, check=True, parity_reads=1024):
     """the same pipelined step (stage || run -> results snapshot -> commit, fetch beside the next run) on another BASELINE config at its per-GPU size, every
-    read distinct (unless --other-unique tiles them): driver-clocked rates for cfg3 / cfg4 next to the cfg2 headline, each with an oracle check of 64
+    read distinct (unless --other-unique tiles them): driver-clocked rates for cfg3 / cfg4 next to the cfg2 headline, each with an oracle check of --parity-reads (1 024)
     random reads of the batch after its timed region (full parity of these shapes: tests/test_gpu_configs.py)"""
     import torch
     from c3poa_amd import _lib, synth
@@ -414,6 +459,7 @@ def run_other_config(cfg, device, recs, gen_s, steps=3, check=True):
     o = {"value": round(n * steps / dt, 1), "unit": "reads/s", "reads_per_step": n, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2),
          "kernel_ms": {k: round(float(np.mean(v)), 2) for k, v in kms.items()},
          "cells": int(tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish"]), "cells_polish_computed": int(tm["cells_polish_computed"]),
+         "gcups_computed": round((tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish_computed"]) / (sum(float(np.mean(v)) for v in kms.values()) * 1e-3) / 1e9, 2),
          "band_fallback_layers": int(tm["n_band_fallback"]), "band_layers": int(tm["n_band_layers"]), "windows_second_launch": int(tm["n_win_redo"]),
          "cells_poa": int(tm["cells_poa"]), "poa_gcells_per_s": round(tm["cells_poa"] / (float(np.mean(kms["ms_poa"])) * 1e-3) / 1e9, 1),
          "poa_second_pass_reads": int(tm["n_poa_redo"]), "poa_reads_beyond_16bit": int(tm["n_poa_redo16"]),
@@ -421,7 +467,7 @@ def run_other_config(cfg, device, recs, gen_s, steps=3, check=True):
          "data": "synthetic %s, %d distinct reads%s" % (cfg, nu, "" if reps == 1 else " tiled x%d" % reps), "gen_s": round(gen_s, 1)}
     h.close(); host.close()
     if check:
-        o["parity_sample"] = parity_sample(recs, nu, res, cbuf, coff, synth.CONFIGS[cfg]["mdist"])
+        o["parity_sample"] = parity_sample(recs, nu, res, cbuf, coff, synth.CONFIGS[cfg]["mdist"], k=parity_reads)
     return o
 
 

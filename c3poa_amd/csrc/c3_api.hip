@@ -633,14 +633,21 @@ static int run_poa(c3_handle* h) {
   const int w = h->cfg.poa_band_b + (int)(h->cfg.poa_band_f * max_q);
   long long cells_full = (long long)(2 * max_q + 2) * (2 * w + 1 + max_q / 5);
   if (max_ns < 2) cells_full = 64;
-  if (cells_full > 0x7fffff00LL) cells_full = 0x7fffff00LL;
+  if (cells_full > 0x7ffff000LL) cells_full = 0x7ffff000LL;
   // the LAST pass must hold any alignment the reference would finish: every node a row (a graph never has more nodes than
   // bases went into it), every row as wide as the subread -- per read, not from the batch maxima.  (With match << mismatch an
   // alignment prefers gaps to mismatches and nearly every base becomes a node of its own: tools/fuzz_parity3.py seeds 55, 93, 111
   // ended such reads as LIMIT while the oracle finished them.)
   long long cells_worst = cells_full;
   for (int i : h->work) if (h->sum[i].n_sub >= 2) cells_worst = std::max(cells_worst, (long long)(h->sum[i].sum_sub + 8) * (h->sum[i].max_sub + 2));
-  if (cells_worst > 0x7fffff00LL) cells_worst = 0x7fffff00LL;
+  // ... clamped to what ONE slot of the last pass may allocate (18 bytes per cell of the memory budget auto_slots() works with; the row
+  // loops add up to 256 cells of head room to an int: stay clear of INT_MAX).  A read beyond it -- a 150 kb read with a missed peak --
+  // ends as C3_ST_LIMIT by the kernel's own capacity check; it must not turn into an allocation failure for the whole batch
+  {
+    const long long budget = (long long)((h->mem_total ? h->mem_total / 3 : ((size_t)64 << 30)) / 18) - (long long)(Ncap_full + Pcap) * 16;
+    cells_worst = std::min(cells_worst, std::max(budget, cells_full));
+    if (cells_worst > 0x7ffff000LL) cells_worst = 0x7ffff000LL;
+  }
   // typical need: every further subread adds ~12 % nodes (mismatch siblings + insertions) to a graph of max_q nodes; a row
   // holds 2w+1 cells plus the drift between the row's nominal column and the argmax of its predecessors
   const double nodes_typ = (double)max_q * (1.0 + 0.15 * std::max(0, max_ns - 1));
@@ -673,6 +680,7 @@ static int run_poa(c3_handle* h) {
     int cnt[8];
     HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 32, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
+    const int beyond_p1 = cnt[5];                   // reads pass 1 handed straight to the last pass (cnt[5] keeps counting through pass 2)
     if (cnt[4] > 0) {
       h->n_poa_redo = cnt[4];
       HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
@@ -681,7 +689,7 @@ static int run_poa(c3_handle* h) {
       HIPCHK(hipStreamSynchronize(h->stream));
     }
     if (cnt[5] > 0) {
-      h->n_poa_redo += cnt[5]; h->n_poa_redo16 = cnt[5];
+      h->n_poa_redo += beyond_p1; h->n_poa_redo16 = cnt[5];      // distinct reads redone: a read pass 2 sent on is in cnt[4] already
       HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
       if ((rc = launch_poa(h, ovB, cnt[5], Ncap_full, K, Pcap, cells_worst, nullptr, nullptr, 24, 0))) return rc;
     }

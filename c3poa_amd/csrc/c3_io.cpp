@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <sys/stat.h>
@@ -89,7 +90,7 @@ struct Bgzf {
 
 struct c3_reader {
   FILE* fp = nullptr; gzFile gz = nullptr; Bgzf* bz = nullptr;
-  std::vector<char> buf; size_t beg = 0, end = 0; bool eof = false;
+  std::vector<char> buf; size_t beg = 0, end = 0; bool eof = false; bool gz_bad = false;
   std::vector<BatchSet> sets; int cur = -1;
   std::string err;
   bool have_line = false; const char* lp = nullptr; size_t ll = 0;   // one line of look-ahead
@@ -167,26 +168,34 @@ bool bgzf_next_stretch(Bgzf* bz, BgzfStretch* b, size_t max_members = 512) {
     const unsigned char* t = b->comp.data() + at + msz - 4;
     const size_t isz = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
     if (isz > (1u << 16)) { bz->bad = true; return false; }
-    if (isz == 0) continue;                                  // the empty end-of-file member (or an empty one in between)
+    if (isz == 0) {
+      // the empty end-of-file member (or an empty one in between).  It is checked like any other member -- an empty deflate stream and
+      // the CRC of no bytes -- so a damaged member whose ISIZE field reads zero is an error, not a silently dropped block
+      char none;
+      if (!bgzf_inflate(b->comp.data() + at, msz, &none, 0)) { bz->bad = true; return false; }
+      b->comp.resize(at);
+      continue;
+    }
     b->coff.push_back(at); b->csz.push_back(msz); b->doff.push_back(dtot);
     dtot += isz;
   }
   if (b->coff.empty()) return false;
   b->dec.resize(dtot);
   const size_t nm = b->coff.size();
-  auto work = [&](size_t t0, size_t step, bool* ok) {
+  auto work = [&](size_t t0, size_t step, std::atomic<bool>* ok) {
     for (size_t i = t0; i < nm; i += step) {
       const size_t osz = (i + 1 < nm ? b->doff[i + 1] : dtot) - b->doff[i];
       if (!bgzf_inflate(b->comp.data() + b->coff[i], b->csz[i], b->dec.data() + b->doff[i], osz)) { *ok = false; return; }
     }
   };
   const size_t nt = std::min<size_t>((size_t)std::max(1, bz->threads), nm);
-  std::vector<char> oks(nt, 1);
+  std::unique_ptr<std::atomic<bool>[]> oks(new std::atomic<bool>[nt]);
+  for (size_t t = 0; t < nt; ++t) oks[t] = true;
   std::vector<std::thread> th;
-  for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t, nt, (bool*)&oks[t]);
-  work(0, nt, (bool*)&oks[0]);
+  for (size_t t = 1; t < nt; ++t) th.emplace_back(work, t, nt, &oks[t]);
+  work(0, nt, &oks[0]);
   for (auto& x : th) x.join();
-  for (char o : oks) if (!o) { bz->bad = true; return false; }
+  for (size_t t = 0; t < nt; ++t) if (!oks[t]) { bz->bad = true; return false; }
   b->dend = dtot;
   return true;
 }
@@ -217,6 +226,7 @@ bool refill(c3_reader* r) {
            : r->gz ? (long)gzread(r->gz, r->buf.data() + r->end, (unsigned)std::min<size_t>(room, 1u << 30))
                    : (long)fread(r->buf.data() + r->end, 1, room, r->fp);
   if (got < 0 && r->bz) r->err = "BGZF input: a member is damaged (size, inflate or CRC)";
+  if (got < 0 && !r->bz && r->gz) r->gz_bad = true;                  // (reported by c3_reader_next: never a silently shorter file)
   if (got <= 0) { r->eof = true; return false; }
   r->end += (size_t)got;
   return true;
@@ -492,6 +502,7 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
     s.name_off.push_back((int64_t)nn); s.off.push_back((int64_t)nb);
   }
   if (r->bz && r->bz->bad) return fail(r, "BGZF input: a member is damaged (header, size, inflate or CRC)");      // never a silently short file
+  if (r->gz_bad) return fail(r, "gzip input: the stream is damaged (inflate, CRC or length check)");
   s.n_names = nn; s.n_bases = nb;
   r->hint_bases = std::max(r->hint_bases, nb);
   out->n = n; out->n_short = n_short;

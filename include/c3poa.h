@@ -81,7 +81,7 @@ typedef struct {
   float ms_pack, ms_conk, ms_peaks, ms_poa, ms_prep, ms_window, ms_stitch, ms_total;
   int64_t n_reads, n_bases, n_windows;
   int64_t cells_conk, cells_poa, cells_polish;
-  int64_t n_poa_redo;      /* reads whose POA scratch (sized for the typical alignment) overflowed and were redone full-size, plus n_poa_redo16 */
+  int64_t n_poa_redo;      /* DISTINCT reads redone by a later POA pass: scratch (sized for the typical alignment) overflowed -> full-size pass, or handed to the last pass (n_poa_redo16 counts the visits of that pass; a read that took both is counted once here) */
   float ms_wall;           /* host wall time of the whole c3_batch_run call; ms_wall - ms_total = time the GPU waited for the host */
   float ms_host_worklist;  /* of which: building + uploading the POA work list on the host (timer starts AFTER the wait for k_conk / k_peaks) */
   float ms_alloc;          /* of which: growing device scratch buffers (only while batch shapes are still growing) */

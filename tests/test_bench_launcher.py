@@ -68,3 +68,31 @@ def test_pmc_traffic_is_tied_to_the_kernel_sources():
     # the newest committed summary either matches the sources (traffic reported) or is declared stale by bench.py (traffic null)
     assert "kernels" in pm and ("kernel_src_sha" not in pm or isinstance(pm["kernel_src_sha"], str))
     assert "k_poa" in pm["kernels"] or any(k.startswith("k_poa") for k in pm["kernels"])
+
+
+def test_traffic_and_valu_lookups_take_only_this_builds_counters(tmp_path):
+    """both branches of the lookup behind roofline.traffic / roofline.valu: a committed summary measured on THESE kernel sources is
+    reported, one measured on other sources (or without a hash) is named but never reported as this build's, none at all is None"""
+    import json
+    sha = "0123456789abcdef"
+    pm = {"kernel_src_sha": sha, "kernels": {"k_poa": {"hbm_bytes_per_launch": 123.0}, "k_window": {"hbm_bytes_per_launch": 7.0}}}
+    json.dump(pm, open(tmp_path / "r05_pmc_traffic_cfg2_100k.json", "w"))
+    t, src = bench.pmc_traffic_lookup(str(tmp_path), "cfg2", 100000, "ms_poa", sha)
+    assert t == 123.0 and "r05_pmc_traffic_cfg2_100k.json" in src and "this build" in src
+    t, src = bench.pmc_traffic_lookup(str(tmp_path), "cfg2", 100000, "ms_poa", "f" * 16)
+    assert t is None and src.startswith("none for this build") and sha in src
+    pm.pop("kernel_src_sha")                                                   # a summary from before the hash existed
+    json.dump(pm, open(tmp_path / "r05_pmc_traffic_cfg2_100k.json", "w"))
+    t, src = bench.pmc_traffic_lookup(str(tmp_path), "cfg2", 100000, "ms_poa", sha)
+    assert t is None and src.startswith("none for this build")
+    assert bench.pmc_traffic_lookup(str(tmp_path), "cfg4", 100000, "ms_poa", sha) == (None, None)      # no file for the workload
+    # the newest tag wins: an r04 file of this build is not consulted when an r05 file (stale) exists
+    json.dump({"kernel_src_sha": sha, "kernels": {"k_poa": {"hbm_bytes_per_launch": 5.0}}}, open(tmp_path / "r04_pmc_traffic_cfg2_100k.json", "w"))
+    assert bench.pmc_traffic_lookup(str(tmp_path), "cfg2", 100000, "ms_poa", sha)[0] is None
+    sq = {"kernel_src_sha": sha, "cycles_per_inst_assumed": 2.9, "reads": 32768, "kernels": {"k_poa": {"insts_per_cell": 3.5, "busy_frac": 0.65, "insts_per_simd_cycle": 0.22}}}
+    json.dump(sq, open(tmp_path / "r05_sq_counters_cfg2.json", "w"))
+    v = bench.valu_lookup(str(tmp_path), "cfg2", "ms_poa", sha)
+    assert v["insts_per_cell"] == 3.5 and v["busy_frac"] == 0.65 and "this build" in v["source"]
+    v = bench.valu_lookup(str(tmp_path), "cfg2", "ms_poa", "e" * 16)
+    assert v["insts_per_cell"] is None and v["busy_frac"] is None and v["source"].startswith("none for this build")
+    assert bench.valu_lookup(str(tmp_path), "cfg3", "ms_poa", sha) == {"insts_per_cell": None, "busy_frac": None, "source": None}

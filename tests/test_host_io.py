@@ -435,6 +435,21 @@ def test_bgzf_input_is_inflated_in_parallel_and_equals_the_plain_file(tmp_path, 
     open(pb, "wb").write(bytes(bad))
     with pytest.raises(ValueError):
         _all(pb, 7)
+    # a member whose ISIZE field was zeroed (its data would vanish without a trace if "size 0" meant "skip"): an error as well
+    raw = open(str(tmp_path / "b65280_0.fastq.gz"), "rb").read()
+    import struct
+    first = struct.unpack("<H", raw[raw.index(b"BC\x02\x00") + 4:][:2])[0] + 1            # size of the first member
+    pz0 = str(tmp_path / "isize0.fastq.gz")
+    open(pz0, "wb").write(raw[:first - 4] + b"\0\0\0\0" + raw[first:])
+    with pytest.raises(ValueError):
+        _all(pz0, 7)
+    # ... and so is a damaged ordinary gzip stream (zlib's reader reports it; it used to end the input as if the file were shorter)
+    pg = str(tmp_path / "plain_bad.fastq.gz")
+    zb = bytearray(_gz.compress(data))
+    zb[len(zb) // 2] ^= 0x55
+    open(pg, "wb").write(bytes(zb))
+    with pytest.raises(ValueError):
+        _all(pg, 7)
     # names-only pass and the length cut-off behave as on plain input
     got, short, _z = _all(str(tmp_path / "b301_0.fastq.gz"), 6, min_len=sorted(len(r[1]) for r in recs)[5])
     assert short == 5 and len(got) == 18

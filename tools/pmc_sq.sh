@@ -21,6 +21,15 @@ except Exception:
     pass
 print("# tools/pmc_sq.sh $N $CFG: rocprofv3 --kernel-trace --pmc (two passes of 8 SQ counters) on python3 tools/phase_prof.py $N $CFG (shipped build)")
 print("# counted DP cells of the batch: poa %s, polish full matrices %s, polish computed %s" % (tm.get("cells_poa"), tm.get("cells_polish"), tm.get("cells_polish_computed")))
+import hashlib, os
+hsh = hashlib.sha1()
+for f_ in sorted(glob.glob("c3poa_amd/csrc/*.hip") + glob.glob("c3poa_amd/csrc/*.h")):
+    hsh.update(os.path.basename(f_).encode() + b"\0" + open(f_, "rb").read())
+# mean issue cost of a vector wave-instruction: the two classes of tools/ubench/valu_cost.hip (2.3 cycles: add / sub / logic / 16-bit min-max;
+# 4.2 cycles: DPP, 32-bit min-max, compares, selects, lane reads), about two thirds / one third in the DP rows' ISA
+CPI = 2.9
+js = {"note": "tools/pmc_sq.sh $N $CFG: rocprofv3 --kernel-trace --pmc, SQ counters of the shipped build on tools/phase_prof.py", "cfg": "$CFG", "reads": $N,
+      "kernel_src_sha": hsh.hexdigest()[:16], "cycles_per_inst_assumed": CPI, "kernels": {}}
 val = defaultdict(dict); dur = {}
 for f in glob.glob("$R/p*/*results.db"):
     db = sqlite3.connect(f)
@@ -36,4 +45,15 @@ for n, d in sorted(val.items(), key=lambda t: -dur.get(t[0], 0)):
     if cells and "SQ_INSTS_VALU" in d:
         print("           per counted cell: %.3f vector wave-instructions (= %.0f lane operations), %.3f scalar instructions" % (
             d["SQ_INSTS_VALU"] / cells, 64 * d["SQ_INSTS_VALU"] / cells, d.get("SQ_INSTS_SALU", 0) / cells))
+    # vector issue: SQ_BUSY_CYCLES is summed over the 32 shader engines -> / 32 = cycles of the kernel; 1 024 SIMDs
+    cyc = d.get("SQ_BUSY_CYCLES", 0.0) / 32.0
+    kn = n.split("<")[0]
+    if cyc and "SQ_INSTS_VALU" in d and kn not in js["kernels"]:
+        ipc = d["SQ_INSTS_VALU"] / 1024.0 / cyc
+        js["kernels"][kn] = {"instance": n, "ms": dur[n] / 1e6, "insts_valu": d["SQ_INSTS_VALU"], "insts_salu": d.get("SQ_INSTS_SALU"), "kernel_cycles": cyc,
+                             "cells": cells, "insts_per_cell": (d["SQ_INSTS_VALU"] / cells) if cells else None,
+                             "insts_per_simd_cycle": ipc, "busy_frac": ipc * CPI}
+        print("           vector issue: %.3f wave-instructions per SIMD cycle (%.2f GHz); x %.2f cycles per instruction = %.0f %% of the issue cycles" % (ipc, cyc / dur[n], CPI, 100 * ipc * CPI))
+import json
+json.dump(js, open("$R/summary.json", "w"), indent=1)
 PY
