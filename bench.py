@@ -440,7 +440,7 @@ def run_other_config(cfg, device, recs, gen_s, steps=3, check=True, parity_reads
         h.stage_pinned(host); h.run(); fetcher.after_run(); h.commit()
         if timed:
             for k, v in h.last_timing.items():
-                if k.startswith("ms_") and k not in ("ms_pack", "ms_total", "ms_wall", "ms_alloc", "ms_host_worklist", "ms_host_gap"):
+                if k.startswith("ms_") and k not in ("ms_pack", "ms_total", "ms_wall", "ms_alloc", "ms_host_worklist", "ms_host_gap", "ms_poa_tail"):
                     kms.setdefault(k, []).append(v)
     step(False)
     torch.cuda.synchronize()
@@ -463,6 +463,7 @@ def run_other_config(cfg, device, recs, gen_s, steps=3, check=True, parity_reads
          "band_fallback_layers": int(tm["n_band_fallback"]), "band_layers": int(tm["n_band_layers"]), "windows_second_launch": int(tm["n_win_redo"]),
          "cells_poa": int(tm["cells_poa"]), "poa_gcells_per_s": round(tm["cells_poa"] / (float(np.mean(kms["ms_poa"])) * 1e-3) / 1e9, 1),
          "poa_second_pass_reads": int(tm["n_poa_redo"]), "poa_reads_beyond_16bit": int(tm["n_poa_redo16"]),
+         "ms_poa_last_pass_beside_polish": round(float(tm.get("ms_poa_tail", 0.0)), 2),       # (its own stream, overlapped: not in kernel_ms)
          "consensus_ok": int((res["status"] == 0).sum()), "identity_vs_truth_mean": round(float(np.mean(idents)), 5),
          "data": "synthetic %s, %d distinct reads%s" % (cfg, nu, "" if reps == 1 else " tiled x%d" % reps), "gen_s": round(gen_s, 1)}
     h.close(); host.close()

@@ -53,7 +53,8 @@ class Timing(C.Structure):
                                          "ms_stitch", "ms_total")] + \
                [(n, C.c_int64) for n in ("n_reads", "n_bases", "n_windows", "cells_conk", "cells_poa", "cells_polish", "n_poa_redo")] + \
                [(n, C.c_float) for n in ("ms_wall", "ms_host_worklist", "ms_alloc", "ms_host_gap")] + \
-               [(n, C.c_int64) for n in ("cells_polish_computed", "n_band_layers", "n_band_fallback", "n_band_mismatch", "n_win_redo", "n_poa_redo16")]
+               [(n, C.c_int64) for n in ("cells_polish_computed", "n_band_layers", "n_band_fallback", "n_band_mismatch", "n_win_redo", "n_poa_redo16")] + \
+               [(n, C.c_float) for n in ("ms_poa_tail", "pad_")]
 
 
 class HostBatchStruct(C.Structure):

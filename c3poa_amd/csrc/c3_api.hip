@@ -175,6 +175,10 @@ struct c3_handle {
   DBuf d_ascii, d_pk, d_woff, d_qual, d_off, d_strand, d_sid, d_info, d_track, d_draft, d_tpos, d_cons, d_counter, d_gather, d_gather_off;
   DBuf d_raw, d_nraw, d_sum, d_work, d_bufA, d_bufB, d_cand, d_cst, d_msa, d_msa_off, d_msa_len;
   DBuf s_poa_i, s_poa_nk, s_poa_cells, s_poa_b, s_poa_sc, s_poa_desc, s_poa_jump, s_poa_path, d_overflow;      // POA scratch
+  // the LAST POA pass (a handful of reads whose bands blew up: a workgroup of eight waves each, >100 ms on four CUs) runs on a stream of
+  // its own beside k_prep / k_window of every other read; the stragglers are polished by a small tail afterwards (run_tail)
+  hipStream_t stream_mw = nullptr; hipEvent_t ev_mw[2] = {nullptr, nullptr}; DBuf d_counter_mw, d_work_main;
+  std::vector<int> strag, work_main; bool tail_pending = false;
   int n_poa_redo = 0;        // reads of the last run that needed the full-size second POA pass
   int n_poa_redo16 = 0;      // ... of them: because a score left the 16-bit cells
   DBuf s_eH, s_eD, s_lw, d_wrec, d_wlay, d_wbase, d_wout;       // prep / windows
@@ -247,6 +251,8 @@ extern "C" int c3_create(const c3_config* cfg, c3_handle** out) {
   if ((e = hipStreamCreate(&h->stream)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   if ((e = hipStreamCreate(&h->stream_up)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   if ((e = hipStreamCreate(&h->stream_dn)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  if ((e = hipStreamCreate(&h->stream_mw)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  for (int i = 0; i < 2; ++i) if ((e = hipEventCreate(&h->ev_mw[i])) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   if ((e = hipEventCreateWithFlags(&h->ev_dn, hipEventDisableTiming)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   if ((e = hipHostMalloc((void**)&h->h_tot, 64, hipHostMallocDefault)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   for (int i = 0; i < 2; ++i) if ((e = hipEventCreate(&h->ev_up[i])) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
@@ -261,6 +267,9 @@ extern "C" void c3_destroy(c3_handle* h) {
   (void)hipSetDevice(h->cfg.device);
   (void)hipStreamSynchronize(h->stream);
   if (h->stream_dn) { (void)hipStreamSynchronize(h->stream_dn); (void)hipStreamDestroy(h->stream_dn); }
+  if (h->stream_mw) { (void)hipStreamSynchronize(h->stream_mw); (void)hipStreamDestroy(h->stream_mw); }
+  for (int i = 0; i < 2; ++i) if (h->ev_mw[i]) (void)hipEventDestroy(h->ev_mw[i]);
+  h->d_counter_mw.release(); h->d_work_main.release();
   if (h->ev_dn) (void)hipEventDestroy(h->ev_dn);
   if (h->h_tot) (void)hipHostFree(h->h_tot);
   h->d_info_snap.release(); h->d_coff_part.release(); h->s_win_h2.release(); h->s_win_d2.release(); h->s_win_i2.release(); h->s_win_nk2.release(); h->s_win_b2.release(); h->s_win_sc2.release(); h->s_win_desc2.release(); h->d_wout2.release(); h->d_wovf.release();
@@ -577,7 +586,10 @@ static int fetch_summary(c3_handle* h) {
 }
 
 // one launch of k_poa over `nw` reads of `d_work` with the given capacities
-static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, int Pcap, long long cells, int* d_overflow, int* d_overflow16, int waves_per_cu, int wide_ring) {
+static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, int Pcap, long long cells, int* d_overflow, int* d_overflow16, int waves_per_cu, int wide_ring,
+                      DBuf* cnt_buf = nullptr, hipStream_t st = nullptr) {
+  if (!cnt_buf) cnt_buf = &h->d_counter;          // (the overlapped last pass counts in a buffer of its own: k_prep / k_window use d_counter meanwhile)
+  if (!st) st = h->stream;
   const size_t N = (size_t)Ncap;
   const int NI = 19;      // int arrays of N (c3_args.h)
   cells = (cells + 15) & ~15LL;                   // every per-slot arena starts 16-byte aligned
@@ -599,7 +611,7 @@ static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, 
   HIPCHK(h->s_poa_path.ensure(sizeof(int) * (size_t)Pcap * slots));
   PoaArgs a; memset(&a, 0, sizeof(a));
   a.b = dev_batch(h); a.info = h->d_info.as<C3Info>(); a.p = dev_params(h->cfg);
-  a.counter = h->d_counter.as<int>(); a.work = d_work; a.n_work = nw;
+  a.counter = cnt_buf->as<int>(); a.work = d_work; a.n_work = nw;
   a.ibase = h->s_poa_i.as<int>(); a.ebase = h->s_poa_nk.as<int>(); a.cellsb = h->s_poa_cells.as<char>();
   a.bbase = h->s_poa_b.as<uint8_t>(); a.score = h->s_poa_sc.as<long long>();
   a.Ncap = Ncap; a.K = K; a.Pcap = Pcap; a.cells_cap = (int)cells; a.desc = h->s_poa_desc.as<uint4>(); a.jump = h->s_poa_jump.as<int>();
@@ -608,11 +620,11 @@ static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, 
   a.draft = h->d_draft.as<uint8_t>(); a.tpos = h->d_tpos.as<int32_t>();
   a.msa_dbg = nullptr; a.msa_off = nullptr; a.msa_len = nullptr;
   if (h->debug_msa) { a.msa_dbg = h->d_msa.as<uint8_t>(); a.msa_off = h->d_msa_off.as<int64_t>(); a.msa_len = h->d_msa_len.as<int>(); }
-  a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
+  a.phases = (unsigned long long*)(cnt_buf->as<char>() + 64);
   DBG("poa: nw=%d Ncap=%d K=%d cells=%lld slots=%d (%.1f MB per slot)%s\n", nw, Ncap, K, cells, slots, per_slot / 1048576.0, d_overflow ? "" : (d_overflow16 ? " [full-size pass]" : (mw ? " [32-bit pass, eight waves per read]" : " [32-bit pass]")));
   // the pass with an overflow list runs the 16-bit rows; the final pass (no list) the 32-bit rows only (C3_DEBUG_POA32: test hook, first pass too)
-  if (mw) c3k_launch_poa_mw(&a, slots, h->stream);
-  else c3k_launch_poa(&a, slots, w32 ? 1 : 0, wide_ring, h->stream);
+  if (mw) c3k_launch_poa_mw(&a, slots, st);
+  else c3k_launch_poa(&a, slots, w32 ? 1 : 0, wide_ring, st);
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -621,7 +633,8 @@ static int launch_poa(c3_handle* h, const int* d_work, int nw, int Ncap, int K, 
 // small slots mean more resident waves, and the DP kernels live on resident waves -- and the few reads that overflow it
 // (ragged subread lengths widen the adaptive band; long insertions add nodes) are queued by the kernel and redone by a
 // second launch with worst-case scratch, so no read is ever lost to the smaller first-pass capacity.
-static int run_poa(c3_handle* h) {
+static int run_poa(c3_handle* h, bool polish_follows) {
+  h->tail_pending = false; h->strag.clear();
   const int nw = (int)h->work.size();
   HIPCHK(h->d_draft.ensure((size_t)h->total + 64)); HIPCHK(h->d_tpos.ensure(sizeof(int32_t) * (size_t)h->total + 64));
   HIPCHK(h->d_cons.ensure((size_t)h->total + 64));
@@ -633,7 +646,10 @@ static int run_poa(c3_handle* h) {
   const int w = h->cfg.poa_band_b + (int)(h->cfg.poa_band_f * max_q);
   long long cells_full = (long long)(2 * max_q + 2) * (2 * w + 1 + max_q / 5);
   if (max_ns < 2) cells_full = 64;
-  if (cells_full > 0x7ffff000LL) cells_full = 0x7ffff000LL;
+  // (every cell capacity stays max_q + 512 below INT_MAX: the kernel's `used + width > capacity` tests add a row -- at most a subread
+  // wide -- or up to 256 cells of head room to a 32-bit count that never exceeds the capacity, and must not wrap)
+  const long long cells_max = 0x7fffffffLL - (long long)max_q - 512;
+  if (cells_full > cells_max) cells_full = cells_max;
   // the LAST pass must hold any alignment the reference would finish: every node a row (a graph never has more nodes than
   // bases went into it), every row as wide as the subread -- per read, not from the batch maxima.  (With match << mismatch an
   // alignment prefers gaps to mismatches and nearly every base becomes a node of its own: tools/fuzz_parity3.py seeds 55, 93, 111
@@ -646,7 +662,7 @@ static int run_poa(c3_handle* h) {
   {
     const long long budget = (long long)((h->mem_total ? h->mem_total / 3 : ((size_t)64 << 30)) / 18) - (long long)(Ncap_full + Pcap) * 16;
     cells_worst = std::min(cells_worst, std::max(budget, cells_full));
-    if (cells_worst > 0x7ffff000LL) cells_worst = 0x7ffff000LL;
+    if (cells_worst > cells_max) cells_worst = cells_max;
   }
   // typical need: every further subread adds ~12 % nodes (mismatch siblings + insertions) to a graph of max_q nodes; a row
   // holds 2w+1 cells plus the drift between the row's nominal column and the argmax of its predecessors
@@ -688,10 +704,45 @@ static int run_poa(c3_handle* h) {
       HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 32, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
     }
+    if (const char* e = getenv("C3_DEBUG_POA_PUNT_MOD")) {
+      // test hook (host only -- nothing in the kernels' row loops pays for it): every read with rid % k == 0 and two or more subreads joins
+      // the last pass's list as if one of its scores had left the 16-bit cells; the last pass recomputes and overwrites its draft
+      const int k_ = std::max(1, atoi(e));
+      std::vector<int> lst(cnt[5] > 0 ? cnt[5] : 0);
+      if (cnt[5] > 0) { HIPCHK(hipMemcpyAsync(lst.data(), ovB, sizeof(int) * (size_t)cnt[5], hipMemcpyDeviceToHost, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); }
+      std::vector<char> in(h->n, 0);
+      for (int r : lst) in[r] = 1;
+      for (int r : h->work) if (r % k_ == 0 && h->sum[r].n_sub >= 2 && !in[r]) lst.push_back(r);
+      if (!lst.empty()) { HIPCHK(hipMemcpyAsync(ovB, lst.data(), sizeof(int) * lst.size(), hipMemcpyHostToDevice, h->stream)); HIPCHK(hipStreamSynchronize(h->stream)); }
+      cnt[5] = (int)lst.size();
+    }
     if (cnt[5] > 0) {
       h->n_poa_redo += beyond_p1; h->n_poa_redo16 = cnt[5];      // distinct reads redone: a read pass 2 sent on is in cnt[4] already
-      HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
-      if ((rc = launch_poa(h, ovB, cnt[5], Ncap_full, K, Pcap, cells_worst, nullptr, nullptr, 24, 0))) return rc;
+      // The last pass: a handful of reads on a handful of CUs for 100+ ms (cfgL: four reads, 132 ms of a 1.1 s batch).  When the polish
+      // follows in this call it runs on a stream of its own BESIDE k_prep / k_window / k_stitch of all the other reads; the stragglers are
+      // polished by a small tail (run_tail).  Not when a straggler is a zero-repeat rescue (k_zero_finish needs its draft first), and
+      // C3_NO_TAIL_OVERLAP=1 keeps everything in series (A/B and test hook).
+      h->strag.resize(cnt[5]);
+      HIPCHK(hipMemcpyAsync(h->strag.data(), ovB, sizeof(int) * (size_t)cnt[5], hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      bool overlap = polish_follows && !getenv("C3_NO_TAIL_OVERLAP") && cnt[5] < nw;
+      if (overlap && !h->zwork.empty()) {
+        std::vector<char> isz(h->n, 0);
+        for (int z : h->zwork) isz[z] = 1;
+        for (int r : h->strag) if (isz[r]) { overlap = false; break; }
+      }
+      if (overlap) {
+        HIPCHK(h->d_counter_mw.ensure(512));
+        HIPCHK(hipMemsetAsync(h->d_counter_mw.p, 0, 512, h->stream_mw));       // (the main stream is idle: its passes were waited for above)
+        HIPCHK(hipEventRecord(h->ev_mw[0], h->stream_mw));
+        if ((rc = launch_poa(h, ovB, cnt[5], Ncap_full, K, Pcap, cells_worst, nullptr, nullptr, 24, 0, &h->d_counter_mw, h->stream_mw))) return rc;
+        HIPCHK(hipEventRecord(h->ev_mw[1], h->stream_mw));
+        h->tail_pending = true;
+      } else {
+        h->strag.clear();
+        HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
+        if ((rc = launch_poa(h, ovB, cnt[5], Ncap_full, K, Pcap, cells_worst, nullptr, nullptr, 24, 0))) return rc;
+      }
     }
   }
   if (!h->zwork.empty()) {             // zero-repeat rescue, second half: stitch left + overlap consensus + right
@@ -705,14 +756,16 @@ static int run_poa(c3_handle* h) {
   return 0;
 }
 
-static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st) {
-  const int nw = (int)h->work.size();
+// k_prep -> k_window (two launches) -> k_stitch over one work list (the whole batch, or -- when the last POA pass runs beside it -- the
+// batch without the stragglers and then the stragglers alone); times and counters ADD to h->tm (c3_batch_run zeroes them)
+static int run_polish(c3_handle* h, const std::vector<int>& work, const int* d_work, float* ms_prep, float* ms_win, float* ms_st) {
+  const int nw = (int)work.size();
   DBG("polish: nw=%d\n", nw);
   HIPCHK(h->d_cons.ensure((size_t)h->total + 64));
   if (nw == 0) return 0;
   const int WL = h->cfg.pol_window;
   int max_ns = 0, max_q = 0, max_dang = 0; long long wcap = 0;
-  for (int i : h->work) {
+  for (int i : work) {
     max_ns = std::max(max_ns, h->sum[i].n_sub); max_q = std::max(max_q, h->sum[i].max_sub); max_dang = std::max(max_dang, h->sum[i].max_dang);
     wcap += (2 * h->sum[i].max_sub + WL - 1) / WL + 1;
   }
@@ -730,7 +783,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   HIPCHK(h->d_wbase.ensure(sizeof(int) * (size_t)h->n));
   PrepArgs p; memset(&p, 0, sizeof(p));
   p.b = dev_batch(h); p.info = h->d_info.as<C3Info>(); p.p = dev_params(h->cfg);
-  p.counter = h->d_counter.as<int>(); p.work = h->d_work.as<int>(); p.n_work = nw;
+  p.counter = h->d_counter.as<int>(); p.work = d_work; p.n_work = nw;
   p.draft = h->d_draft.as<uint8_t>(); p.tpos = h->d_tpos.as<int32_t>();
   p.eH = h->s_eH.as<int32_t>(); p.eD = h->s_eD.as<uint8_t>(); p.ecap = ecap;
   p.lw_first = h->s_lw.as<int>(); p.lw_last = p.lw_first + (size_t)NLcap * NWcap * slots_p; p.NLcap = NLcap; p.NWcap = NWcap;
@@ -749,7 +802,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   // k_prep reserves windows with an atomicAdd BEFORE its capacity check: after an overflow the counter exceeds wcap, and
   // the records past wcap were never written (the reads that overflowed carry C3_ST_LIMIT and n_win = 0)
   const int n_win = (int)std::min<long long>(cnt[8], std::min<long long>(wcap, 0x7fffffff));
-  h->n_windows = n_win;
+  h->n_windows += n_win;
   DBG("prep done: n_win=%d\n", n_win);
   const int wout_cap = 3 * WL + 64;
   HIPCHK(hipEventRecord(h->ev[7], h->stream));
@@ -769,7 +822,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     const size_t N = (size_t)Ncap;
     const int NI = 19;      // W_INTS of k_polish.hip
     const size_t per_slot = N * (NI * 4 + 8 + 2) + N * K * 16 + (size_t)hcap * 5;
-    const int slots = auto_slots(h, h->cfg.slots_win, per_slot, n_win, 20);
+    const int slots = auto_slots(h, h->cfg.slots_win, per_slot, n_win, 24);       // six waves per SIMD (80 VGPRs, five LDS granules of 1 280 bytes)
     // the second launch holds ANY window: graph arrays for every base of every layer becoming a node, DP rows as wide as the longest
     // layer (both maxima come back from k_prep with the window count); a handful of slots when that is large
     const int Ncap2 = (int)std::min<long long>(65534, std::max<long long>(Ncap, (long long)cnt[10] + 8));
@@ -777,7 +830,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     const long long hcap2 = std::max(hcap_full, (long long)(Ncap2 + 1) * rs2);
     const size_t N2 = (size_t)Ncap2;
     const size_t per_slot2 = N2 * (NI * 4 + 8 + 2) + N2 * K * 16 + sizeof(uint4) * (N2 + 1) + (size_t)hcap2 * 5;
-    const int slots2 = (int)std::max<long long>(1, std::min<long long>(std::min(slots, 128), (4LL << 30) / (long long)per_slot2));
+    const int slots2 = (int)std::max<long long>(1, std::min<long long>(std::min(slots, 1024), (4LL << 30) / (long long)per_slot2));      // (up to four waves per CU: since round 5 the second launch also takes the layers that need wide unbanded rows -- noisy reads can send a few per cent of the windows there)
     HIPCHK(h->s_win_i.ensure(sizeof(int) * N * NI * slots + 64)); HIPCHK(h->s_win_nk.ensure(sizeof(int) * N * K * 4 * slots));
     HIPCHK(h->s_win_h.ensure(sizeof(int32_t) * (size_t)hcap * slots)); HIPCHK(h->s_win_d.ensure((size_t)hcap * slots + 256));
     HIPCHK(h->s_win_b.ensure(N * 2 * slots)); HIPCHK(h->s_win_sc.ensure(sizeof(long long) * N * slots));
@@ -800,7 +853,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
     a.draft = h->d_draft.as<uint8_t>();
     a.ibase = h->s_win_i.as<int>(); a.ebase = h->s_win_nk.as<int>();
     a.base = h->s_win_b.as<uint8_t>(); a.score = h->s_win_sc.as<long long>();
-    a.H = h->s_win_h.as<int32_t>(); a.D = h->s_win_d.as<uint16_t>(); a.rdesc = h->s_win_desc.as<uint4>(); a.Ncap = Ncap; a.K = K; a.hcap = hcap; a.Lcap = std::min(std::min(Ncap, 2 * WL + 30 * NLcap), ((getenv("C3_DEBUG_WIN_LDS") ? atoi(getenv("C3_DEBUG_WIN_LDS")) : 6656) - 16) / 6);       // (LDS per wave capped at 6.5 KB: at cfg4 the uncapped sweep arrays took 8.5 KB and k_window ran 7 % slower; larger graphs use the global-scratch sweep)
+    a.H = h->s_win_h.as<int32_t>(); a.D = h->s_win_d.as<uint16_t>(); a.rdesc = h->s_win_desc.as<uint4>(); a.Ncap = Ncap; a.K = K; a.hcap = hcap; a.Lcap = std::min(std::min(Ncap, 2 * WL + 30 * NLcap), ((getenv("C3_DEBUG_WIN_LDS") ? atoi(getenv("C3_DEBUG_WIN_LDS")) : 6400) - 16) / 6);       // (LDS per wave capped at FIVE allocation granules of 1 280 bytes, 24 waves per CU: at cfg4 the uncapped sweep arrays took 8.5 KB and k_window ran 7 % slower; larger graphs use the global-scratch sweep)
     if (const char* e = getenv("C3_DEBUG_WIN_LCAP")) a.Lcap = std::max(64, std::min(Ncap, atoi(e)));   // test hook: forces the global-scratch consensus path
     a.wout = h->d_wout.as<uint8_t>(); a.wout_cap = wout_cap; a.wout2 = h->d_wout2.as<uint8_t>(); a.wout2_cap = wout2_cap; a.wout2_n = wout2_n;
     HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 256, h->stream));
@@ -823,7 +876,7 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   }
   HIPCHK(hipEventRecord(h->ev[8], h->stream));
   StitchArgs s; memset(&s, 0, sizeof(s));
-  s.b = dev_batch(h); s.info = h->d_info.as<C3Info>(); s.work = h->d_work.as<int>(); s.n_work = nw;
+  s.b = dev_batch(h); s.info = h->d_info.as<C3Info>(); s.work = d_work; s.n_work = nw;
   s.wrec = h->d_wrec.as<WinRec>(); s.win_base = h->d_wbase.as<int>(); s.wout = h->d_wout.as<uint8_t>(); s.wout_cap = wout_cap;
   s.cons = h->d_cons.as<char>(); s.zflag = h->d_zflag.as<uint8_t>(); s.wout2 = h->d_wout2.as<uint8_t>(); s.wout2_cap = h->win_out2_cap;
   DBG("stitch\n");
@@ -834,13 +887,13 @@ static int run_polish(c3_handle* h, float* ms_prep, float* ms_win, float* ms_st)
   HIPCHK(hipMemcpyAsync(cnt_all, h->d_counter.p, 256, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   memcpy(cnt, cnt_all, 64);
-  if (n_win > 0) h->tm.n_win_redo = cnt_all[W_CNT_OVF];
+  if (n_win > 0) h->tm.n_win_redo += cnt_all[W_CNT_OVF];
   if (n_win > 0) DBG("window: second launch %d; given up: backbone %d scratch %d nodes %d consensus %d\n", cnt_all[W_CNT_OVF], cnt_all[W_CNT_WHY], cnt_all[W_CNT_WHY + 1], cnt_all[W_CNT_WHY + 2], cnt_all[W_CNT_WHY + 3]);
-  if (n_win > 0) { h->tm.cells_polish += *(long long*)(cnt + 2); h->tm.cells_polish_computed += *(long long*)(cnt + 4); h->tm.n_band_layers = cnt[6]; h->tm.n_band_fallback = cnt[7]; h->tm.n_band_mismatch = cnt[8]; if (cnt[8]) fprintf(stderr, "c3poa: band verify mismatch in window %d layer %d (R = %d): last differing base q = %d, band row %d, full row %d, row of q+1 = %d\n", cnt[9], cnt[10], cnt[11], cnt[12], cnt[13], cnt[14], cnt[15]); }
-  HIPCHK(hipEventElapsedTime(ms_prep, h->ev[5], h->ev[6]));
-  HIPCHK(hipEventElapsedTime(ms_win, h->ev[7], h->ev[8]));
-  HIPCHK(hipEventElapsedTime(ms_st, h->ev[8], h->ev[9]));
-  h->tm.n_windows = n_win;
+  if (n_win > 0) { h->tm.cells_polish += *(long long*)(cnt + 2); h->tm.cells_polish_computed += *(long long*)(cnt + 4); h->tm.n_band_layers += cnt[6]; h->tm.n_band_fallback += cnt[7]; h->tm.n_band_mismatch += cnt[8]; if (cnt[8]) fprintf(stderr, "c3poa: band verify mismatch in window %d layer %d (R = %d): last differing base q = %d, band row %d, full row %d, row of q+1 = %d\n", cnt[9], cnt[10], cnt[11], cnt[12], cnt[13], cnt[14], cnt[15]); }
+  { float a_, b_, c_;
+    HIPCHK(hipEventElapsedTime(&a_, h->ev[5], h->ev[6])); HIPCHK(hipEventElapsedTime(&b_, h->ev[7], h->ev[8])); HIPCHK(hipEventElapsedTime(&c_, h->ev[8], h->ev[9]));
+    *ms_prep += a_; *ms_win += b_; *ms_st += c_; }
+  h->tm.n_windows += n_win;
   return 0;
 }
 
@@ -856,7 +909,7 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
   // per-run figures start from zero: repeated runs of one resident batch (bench.py, tools/) must not accumulate
   if (stages & C3_STAGE_CONK) { h->tm.ms_conk = 0; h->tm.cells_conk = 0; }
   if (stages & C3_STAGE_PEAKS) h->tm.ms_peaks = 0;
-  if (stages & C3_STAGE_POA) { h->tm.ms_poa = 0; h->tm.cells_poa = 0; }
+  if (stages & C3_STAGE_POA) { h->tm.ms_poa = 0; h->tm.cells_poa = 0; h->tm.ms_poa_tail = 0; }
   if (stages & C3_STAGE_POLISH) { h->tm.ms_prep = h->tm.ms_window = h->tm.ms_stitch = 0; h->tm.cells_polish = 0; h->tm.cells_polish_computed = 0; h->tm.n_band_layers = h->tm.n_band_fallback = h->tm.n_band_mismatch = 0; h->tm.n_windows = 0; h->tm.n_win_redo = 0; }
   HIPCHK(hipEventRecord(t0, h->stream));
   if (stages & C3_STAGE_CONK) { if ((rc = run_conk(h))) return rc; h->tm.cells_conk = 0; for (int i = 0; i < h->n; ++i) h->tm.cells_conk += (h->off[i + 1] - h->off[i]) * (int64_t)h->max_spl; }
@@ -870,7 +923,7 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
     DBG("run: work list ready (%zu reads)\n", h->work.size());
     HIPCHK(hipEventRecord(t3, h->stream));
     if (stages & C3_STAGE_POA) {
-      if ((rc = run_poa(h))) return rc;
+      if ((rc = run_poa(h, (stages & C3_STAGE_POLISH) != 0))) return rc;
     }
     HIPCHK(hipEventRecord(t4, h->stream));
     if (stages & C3_STAGE_POA) {
@@ -883,7 +936,34 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
       DBG("run: poa done\n");
       HIPCHK(hipEventElapsedTime(&ms, t3, t4)); h->tm.ms_poa = ms;
     }
-    if (stages & C3_STAGE_POLISH) { if ((rc = run_polish(h, &ms_prep, &ms_win, &ms_st))) return rc; }
+    h->n_windows = 0;
+    if ((stages & C3_STAGE_POLISH) && !h->tail_pending) { if ((rc = run_polish(h, h->work, h->d_work.as<int>(), &ms_prep, &ms_win, &ms_st))) return rc; }
+    if (h->tail_pending) {
+      // the last POA pass is running on stream_mw: polish everything else beside it, then the stragglers
+      std::vector<char> iss(h->n, 0);
+      for (int r : h->strag) iss[r] = 1;
+      h->work_main.clear();
+      for (int r : h->work) if (!iss[r]) h->work_main.push_back(r);          // (order kept: longest first)
+      HIPCHK(h->d_work_main.ensure(sizeof(int) * std::max<size_t>(h->work_main.size(), 1)));
+      if (!h->work_main.empty()) HIPCHK(hipMemcpyAsync(h->d_work_main.p, h->work_main.data(), sizeof(int) * h->work_main.size(), hipMemcpyHostToDevice, h->stream));
+      if ((rc = run_polish(h, h->work_main, h->d_work_main.as<int>(), &ms_prep, &ms_win, &ms_st))) return rc;
+      // ... the stragglers: their drafts exist once the last pass is done
+      HIPCHK(hipStreamWaitEvent(h->stream, h->ev_mw[1], 0));
+      const int ns_ = (int)h->strag.size();
+      const int* d_strag = h->d_overflow.as<int>() + (int)h->work.size();     // (= the last pass's work list, still in place)
+      HIPCHK(hipMemsetAsync(h->d_counter.as<int>() + 6, 0, 8, h->stream));
+      hipLaunchKernelGGL(k_draft_stats, dim3((ns_ + 255) / 256), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), d_strag, ns_, h->cfg.pol_window, h->d_counter.as<int>() + 6);
+      HIPCHK(hipGetLastError());
+      int cnt[16], cmw[4];
+      HIPCHK(hipMemcpyAsync(cnt, h->d_counter.p, 64, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipMemcpyAsync(cmw, h->d_counter_mw.p, 16, hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      h->tm.cells_poa += *(long long*)(cmw + 2);
+      h->poa_max_draft = cnt[6]; h->poa_sum_win = cnt[7];
+      { float t_ = 0; HIPCHK(hipEventElapsedTime(&t_, h->ev_mw[0], h->ev_mw[1])); h->tm.ms_poa_tail = t_; }
+      h->tail_pending = false;
+      if ((rc = run_polish(h, h->strag, d_strag, &ms_prep, &ms_win, &ms_st))) return rc;
+    }
   }
   HIPCHK(hipStreamSynchronize(h->stream));
   DBG("run: done\n");

@@ -13,6 +13,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <sched.h>
 #include <cerrno>
 #include <climits>
 #include <cmath>
@@ -34,6 +36,38 @@ namespace {
 
 // ---- growable host buffer, page-locked when a GPU runtime is present (plain malloc otherwise: pinning is a transfer
 //      optimisation, not a compute path) -------------------------------------------------------------------------
+// ---- process-wide cap on the native host threads that RUN at the same time.  Every GPU worker of stream.py brings two parser
+// threads and a writer that fans out into formatter threads; eight workers used to put ~100 runnable threads on a 16-core cgroup
+// quota, the quota was spent in the first sixth of every scheduler period and the whole process slept through the rest of it (8 workers
+// ran at 0.6x the rate of one: profiles/r04_host_ceiling_*).  Parsing a group, formatting a slice and writing a file now each hold one
+// of host_cores() slots while they run: the usable cores (affinity mask and cgroup quota; C3_HOST_THREADS overrides).
+int host_cores() {
+  static const int n = [] {
+    if (const char* e = getenv("C3_HOST_THREADS")) return std::max(1, atoi(e));
+    long c = sysconf(_SC_NPROCESSORS_ONLN);
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) c = std::min<long>(c, CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+      char q[64]; long long per = 0;
+      if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) c = std::min<long>(c, std::max<long>(1, (long)(atoll(q) / per)));
+      fclose(f);
+    }
+    return (int)std::max<long>(1, c);
+  }();
+  return n;
+}
+struct CpuSlots {
+  std::mutex mu; std::condition_variable cv; int free_ = host_cores();
+  void acquire() { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return free_ > 0; }); --free_; }
+  void release() { { std::lock_guard<std::mutex> lk(mu); ++free_; } cv.notify_one(); }
+};
+CpuSlots& cpu_slots() { static CpuSlots s; return s; }
+struct CpuSlot {                                   // (never nested: a holder that waits for other slot holders could starve them)
+  CpuSlot() { cpu_slots().acquire(); }
+  ~CpuSlot() { cpu_slots().release(); }
+  CpuSlot(const CpuSlot&) = delete; CpuSlot& operator=(const CpuSlot&) = delete;
+};
+
 struct HostBuf {
   char* p = nullptr; size_t cap = 0; bool pinned = false;
   ~HostBuf() { release(); }
@@ -42,6 +76,7 @@ struct HostBuf {
     if (pinned) (void)hipHostFree(p); else free(p);
     p = nullptr; cap = 0;
   }
+  bool want_pin = true;       // page-lock new allocations (readers of small inputs switch it off: see c3_reader::pin_policy)
   bool reserve(size_t need, size_t keep) {
     if (need <= cap) return true;
     size_t ncap = cap ? cap : (size_t)1 << 20;
@@ -49,7 +84,7 @@ struct HostBuf {
     char* q = nullptr; bool pin = false;
     static int can_pin = -1;
     if (can_pin < 0) { int n = 0; can_pin = (hipGetDeviceCount(&n) == hipSuccess && n > 0) ? 1 : 0; (void)hipGetLastError(); }
-    if (can_pin && hipHostMalloc((void**)&q, ncap, hipHostMallocDefault) == hipSuccess) pin = true;
+    if (can_pin && want_pin && hipHostMalloc((void**)&q, ncap, hipHostMallocDefault) == hipSuccess) pin = true;
     else { (void)hipGetLastError(); q = (char*)malloc(ncap); }
     if (getenv("C3_DEBUG")) fprintf(stderr, "[c3_io] host buffer %zu MiB %s\n", ncap >> 20, pin ? "page-locked" : "pageable");
     if (!q) return false;
@@ -297,7 +332,7 @@ extern "C" int c3_reader_open(const char* path, int n_sets, c3_reader** out) {
       rewind(f);
       r->bz = new Bgzf(); r->bz->fp = f;
       const char* e = getenv("C3_GZ_THREADS");
-      r->bz->threads = e ? std::max(1, atoi(e)) : (int)std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+      r->bz->threads = e ? std::max(1, atoi(e)) : std::min(8, host_cores());
     } else {
       if (f) fclose(f);
       r->gz = gzopen(path, "rb"); if (r->gz) gzbuffer(r->gz, 1 << 20);
@@ -425,12 +460,18 @@ extern "C" int c3_reader_next(c3_reader* r, int max_reads, int64_t max_bases, in
 // caller keeps a free list of sets and hands one back only after its group has been written.
 extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t max_bases, int min_len, c3_host_batch* out) {
   if (!r || !out || max_reads <= 0 || set < 0 || set >= (int)r->sets.size()) return C3_E_ARG;
+  CpuSlot slot_;                                   // one of the host's cores while this group is parsed
   r->cur = set;
   BatchSet& s = r->sets[(size_t)r->cur];
   s.name_off.assign(1, 0); s.off.assign(1, 0);
   if (!r->names_only && r->hint_bases) {
     // later sets are allocated once, with the size the previous groups needed (growth by copying only for the first)
-    const size_t want = r->hint_bases + r->hint_bases / 8 + 4096;
+    size_t want = r->hint_bases + r->hint_bases / 8 + 4096;
+    if (!r->gz && !r->bz && r->file_bytes) {       // ... but never more than this reader can still deliver (a set taken for the tail of a range)
+      const int64_t stop = r->range_end >= 0 ? std::min<int64_t>(r->range_end + 65536, (int64_t)r->file_bytes) : (int64_t)r->file_bytes;
+      const int64_t here = r->buf_off + (int64_t)r->beg;
+      want = std::min(want, (size_t)std::max<int64_t>(0, stop - here) / 2 + 65536);
+    }
     if (!s.seqs.reserve(want, 0) || !s.quals.reserve(want, 0)) return C3_E_NOMEM;
   }
   size_t nn = 0, nb = 0; int n = 0; int64_t n_short = 0;
@@ -487,6 +528,18 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
         deliver = (size_t)std::max<int64_t>(0, stop - here) / 2 + sb + sl + 4096;
       } else if ((r->gz || r->bz) && r->file_bytes) deliver = r->file_bytes * 16 + sb + sl + 4096;        // (compressed size: a generous bound)
       want = std::min(want, std::max(deliver, sb + sl + 4096));
+      // Page-locking costs ~0.15 s per GB and as much again to undo, i.e. about what THREE copies of the buffer from pageable memory lose
+      // against DMA: it pays when a buffer set is refilled several times, not when the whole input of this reader passes through its sets
+      // once or twice (eight workers over 2 M reads used to pin 50 GB for 20 GB of input: 7.8 s before the first batch, 5 s to let go --
+      // profiles/r05_host_ceiling_*).  Readers whose file / byte range holds less than C3_PIN_MIN_REFILLS (default 3) fillings of their
+      // sets use plain memory; C3_PIN_MIN_REFILLS=0 pins always.
+      {
+        const char* e = getenv("C3_PIN_MIN_REFILLS");
+        const double refills = e ? atof(e) : 3.0;
+        const double fill_all = (double)want * (double)r->sets.size();
+        const bool pin = refills <= 0 || deliver == (size_t)-1 || (double)deliver >= refills * fill_all;
+        for (BatchSet& o : r->sets) { o.seqs.want_pin = pin; o.quals.want_pin = pin; o.names.want_pin = pin; }
+      }
       if (!s.seqs.reserve(want, sb + sl) || !s.quals.reserve(want, sb + sl)) return C3_E_NOMEM;
       // ... and the other buffer sets of this reader right away: a page-lock issued later, while the GPU is busy, stalls the
       // running kernels for its whole duration (some 50 ms per 400 MiB)
@@ -693,12 +746,13 @@ extern "C" int c3_write_group(const c3_host_batch* b, const c3_read_result* res,
                               const char* const* sub_paths, int zero) {
   if (!b || !res || !cons_off || !splint_id || n_splints <= 0 || !cons_paths || !sub_paths) return C3_E_ARG;
   int T = 1;
-  if (b->n >= 4096) { T = 8; if (const char* e = getenv("C3_WRITER_THREADS")) T = std::max(1, std::min(64, atoi(e))); }
+  if (b->n >= 4096) { T = std::min(8, host_cores()); if (const char* e = getenv("C3_WRITER_THREADS")) T = std::max(1, std::min(64, atoi(e))); }
   const size_t NS = (size_t)n_splints;
   auto range = [&](int k, int* i0, int* i1) { *i0 = (int)((int64_t)b->n * k / T); *i1 = (int)((int64_t)b->n * (k + 1) / T); };
   auto run_all = [&](auto&& fn) {
+    auto slotted = [&](int k) { CpuSlot slot_; fn(k); };
     std::vector<std::thread> th;
-    for (int k = 0; k < T; ++k) { if (k + 1 < T) th.emplace_back(fn, k); else fn(k); }
+    for (int k = 0; k < T; ++k) { if (k + 1 < T) th.emplace_back(slotted, k); else slotted(k); }
     for (auto& x : th) x.join();
   };
   // phase 0: size of every (thread, kind, splint) slice from an upper bound of its records; one pooled arena holds them all
@@ -749,6 +803,7 @@ extern "C" int c3_write_group(const c3_host_batch* b, const c3_read_result* res,
     auto write_file = [&](size_t f) {
       FileJob& j = fjobs[f];
       std::lock_guard<std::mutex> turn(file_mutex(j.fd));
+      CpuSlot slot_;                               // (taken AFTER the file's turn: a writer that waits for its turn holds no core)
       off_t at = j.at; size_t i = 0;
       while (i < j.iov.size()) {
         const int cnt = (int)std::min<size_t>(j.iov.size() - i, 512);

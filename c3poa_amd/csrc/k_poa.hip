@@ -775,14 +775,14 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
 #ifdef C3_DEBUG_PUNT
     if (ncell + wd > c.cells_cap && lane == 0) atomicAdd(c.dbg + 12, 1ull);
 #endif
-    if (wd > c.cells_cap - ncell) return -4;                       // (ncell <= cells_cap: this form cannot wrap when the capacity sits near INT_MAX)
+    if (ncell + wd > c.cells_cap) return -4;                       // (cannot wrap: the host keeps every capacity max_q + 512 below INT_MAX -- run_poa; rewriting the compare cost the fast rows 3 % through the register allocation)
     const bool inl = !W32 && wd <= PW, toglobal = far || !inl;     // wd is scalar (beg / end pinned above)
     const bool qrow = qlds && (!WIDE || (max(beg - 1, 0) >= qwb && end <= qwb + PQW * 16));      // the row's query bases are in the LDS window
     const int fo = wave_first(u_nfar);                               // its cells in the far arena (when it keeps 32-bit cells / direction words)
 #ifdef C3_DEBUG_PUNT
     if ((toglobal || ovf) && fo + wd > c.far_cap() && lane == 0) { atomicAdd(c.dbg + 13, 1ull); atomicMax(c.dbg + 11, ((unsigned long long)(unsigned)fo << 32) | (unsigned)c.far_cap()); }
 #endif
-    if (toglobal || ovf) { if (wd > c.far_cap() - fo) return (!W32 && WIDE) ? -6 : -4; u_nfar = fo + wd; }      // (-6: the far arena of a 16-bit pass over LONG subreads -- a band that blew up to thousands of columns; such a read goes straight to the last pass, whose wide rows eight waves share)
+    if (toglobal || ovf) { if (fo + wd > c.far_cap()) return (!W32 && WIDE) ? -6 : -4; u_nfar = fo + wd; }      // (-6: the far arena of a 16-bit pass over LONG subreads -- a band that blew up to thousands of columns; such a read goes straight to the last pass, whose wide rows eight waves share)
     const int ro = ncell;
     const int ty = ovf ? 2 : (nin >= 2 ? 1 : 0);                   // cell format: byte / byte + predecessor byte / 32-bit word
     ncell += wd;
@@ -1262,6 +1262,8 @@ __global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
   c.chk = a.phases;
 #endif
 #ifdef C3_POA_MW
+  // (this pass may share its CUs with the persistent k_prep / k_window waves of the rest of the batch: its few waves are the long pole)
+  __builtin_amdgcn_s_setprio(3);
   if (threadIdx.x >= 64) {                      // the other waves: wide rows on request, nothing else
     const int wave = (int)(threadIdx.x >> 6);
     const int m8 = S3(a.p.poa_match), x8 = S3(-a.p.poa_mismatch);

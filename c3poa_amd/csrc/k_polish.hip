@@ -589,7 +589,9 @@ template <class T> __device__ __forceinline__ T* uni_ptr(T* p) {
 // inlined here the register allocator spilled the row loop's own arrays (eight scratch reloads per row, each waiting for
 // every older store).  As a function the rows get a register file of their own; the call costs a few dozen instructions
 // per LAYER.
-template <int CPL>
+template <int CPL, bool SECOND>
+// (SECOND: the two launches of k_window have different register budgets -- 80 VGPRs for the first, 96 for the full-size second -- and
+// a function shared by both would be compiled for the smaller occupancy: every launch gets row functions of its own)
 // (the context travels as scalars: a struct passed by value gets an 80-byte stack slot PER CALL SITE, and the kernel's scratch
 // segment -- sized for every wave slot of the device -- decides how long the process's first launch waits for the runtime)
 __device__ __attribute__((noinline)) int win_rows(int* cI, int* cE, int32_t* cH, uint8_t* cD, uint4* crdesc, int cK, int cn, int cNcap, long long chcap,
@@ -868,10 +870,21 @@ __device__ int win_rows_lin(WCtx& c, const C3Params& P, const uint32_t* pk, int 
 // rows' substitution table (up to 640 columns), ring and edge cells (sized for the widest band)
 #include "k_polish_band.h"
 __host__ __device__ __forceinline__ int win_mask_words(int Ncap) { return ((Ncap + 64) >> 6) + 1; }
-__host__ __device__ __forceinline__ size_t win_lds_bytes(int Lcap, int Ncap) {
+// `first`: the FIRST launch (k_window<false>).  The LDS allocator of gfx950 hands out granules of 1 280 bytes (160 KB / 128; measured
+// in round 5: at 6 656 bytes = six granules only 21 waves fit a CU, at 6 400 = five granules 24 do, and k_window runs 8 % faster: profiles/
+// r05_ab_window_6_waves_lds_granule.txt).  The first launch has no wide unbanded rows (their ring would need 5 KB), its consensus arrays are
+// capped by the host (Lcap) and the banded rows' LDS by C3_WIN_LDS_FIRST: a layer whose substitution table + ring do not fit runs unbanded
+// (checked per layer in win_rows_dispatch).  Graphs with many layers (large row bitmasks) simply take more LDS and fewer waves.
+#ifndef C3_WIN_LDS_FIRST
+#define C3_WIN_LDS_FIRST 6400
+#endif
+__host__ __device__ __forceinline__ size_t win_lds_bytes(int Lcap, int Ncap, bool first) {
   const size_t masks = (size_t)32 * win_mask_words(Ncap);
-  const size_t a = (size_t)Lcap * 6 + 16, b = masks + 4 * 5 * 64 * 4 + 64, c = masks + 4 * (size_t)wb_lds_dwords(639, 4), d = masks + 4 * (size_t)(W_TBW + W_QCAP);
-  size_t m = a > b ? a : b; m = m > c ? m : c; m = m > d ? m : d;
+  const size_t a = (size_t)Lcap * 6 + 16, b = masks + 4 * (first ? 2 : 5) * 64 * 4 + 64, d = masks + 4 * (size_t)(W_TBW + W_QCAP);
+  size_t c = masks + 4 * (size_t)wb_lds_dwords(639, 4);
+  size_t m = a > b ? a : b; m = m > d ? m : d;
+  if (first) { const size_t cap = m > (size_t)C3_WIN_LDS_FIRST ? m : (size_t)C3_WIN_LDS_FIRST; if (c > cap) c = cap; }
+  m = m > c ? m : c;
   return m;
 }
 
@@ -880,6 +893,7 @@ __device__ __forceinline__ int win_idx(int j, int cpl) { return cpl ? (j / cpl) 
 
 // cb_io: in = 0: not banded, k >= 1: banded with at least k cells per lane (a retry after a failed certificate asks for a wider
 // band); out = cells per lane of the band that ran (0 = the unbanded rows ran)
+template <bool SECOND>
 __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk, int qbeg, int Q, int R, int lane, int* cpl_out, int* rs_out, unsigned long long* dbg,
                                  unsigned long long* m2, unsigned long long* ma, unsigned long long* d0, unsigned long long* d1, int ring_off, int lds_ints, int begin, int end, int blen, int* cb_io, int* nblocks) {
   const int need = (Q + 1 + 63) / 64;
@@ -889,12 +903,8 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
   const int pm = max(max(abs(P.pol_match), abs(P.pol_mismatch)), abs(P.pol_gap));
   const bool ok16 = !(4 * pm * (max(R, Q) + 4) >= 31000 || 4 * (abs(P.pol_match) + abs(P.pol_gap)) * (Q + 4) >= 31000 || pm > 30 || P.pol_gap >= 0);
   if (!ok16) cpl = 0;
-#ifdef C3_EXP_NOWIDE
-  else if (need <= 2) cpl = 2; else if (need <= 4) cpl = 4; else cpl = 0;
-#else
   else if (need <= 2) cpl = 2; else if (need <= 4) cpl = 4; else if (need <= 6) cpl = 6; else if (need <= 8) cpl = 8;
   else if (need <= 10) cpl = 10; else cpl = 0;
-#endif
   // band width by the inflation of the graph (rows per backbone position of the layer): the more alternative nodes, the
   // weaker the certificate's bounds and the wider the band it needs (tools/band_model.py)
   const int span = end - begin + 1;
@@ -923,9 +933,9 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
     for (int rep_ = 0; rep_ < 2; ++rep_)
 #endif
     switch (cb) {
-      case 2: rc = win_rows_band<2>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); break;
-      case 3: rc = win_rows_band<3>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); break;
-      default: rc = win_rows_band<4>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); break;
+      case 2: rc = win_rows_band<2, SECOND>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); break;
+      case 3: rc = win_rows_band<3, SECOND>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); break;
+      default: rc = win_rows_band<4, SECOND>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off, *nblocks); break;
     }
     if (rc < 0) return rc;
     if (rc > 0) c.lob()[0] = INT32_MAX;        // a band that cannot hold a predecessor: the certificate fails by definition
@@ -939,15 +949,17 @@ __device__ int win_rows_dispatch(WCtx& c, const C3Params& P, const uint32_t* pk,
 #ifdef C3_PHASE_PROF
   dbg[5] += __builtin_readcyclecounter() - bd_t1;
 #endif
+  // the FIRST launch carries no unbanded rows wider than 256 columns and no linear fallback (its 80 registers and five LDS granules are
+  // sized for the banded rows): such a layer -- a band that failed three certificates, a layer the band geometry refuses, scores beyond
+  // 16-bit keys -- sends its window to the full-size launch, exactly as a layer beyond the first launch's DP scratch does
+  if (!SECOND && cpl != 2 && cpl != 4) return -1;
   switch (cpl) {
-    case 2: return win_rows<2>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
-    case 4: return win_rows<4>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
-#ifndef C3_EXP_NOWIDE
-    case 6: return win_rows<6>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
-    case 8: return win_rows<8>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
-    case 10: return win_rows<10>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
-#endif
-    default: return win_rows_lin(c, P, pk, qbeg, Q, R, lane);
+    case 2: return win_rows<2, SECOND>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+    case 4: return win_rows<4, SECOND>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off);
+    case 6: if (SECOND) return win_rows<6, true>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off); return -1;
+    case 8: if (SECOND) return win_rows<8, true>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off); return -1;
+    case 10: if (SECOND) return win_rows<10, true>(c.I, c.E, c.H, c.D, c.rdesc, c.K, c.n, c.Ncap, c.hcap, P.pol_match, P.pol_mismatch, P.pol_gap, pk, qbeg, Q, R, dbg, ring_off); return -1;
+    default: if (SECOND) return win_rows_lin(c, P, pk, qbeg, Q, R, lane); return -1;
   }
 }
 
@@ -1081,11 +1093,16 @@ __device__ __forceinline__ int win_consensus(WCtx& c, int* s_score, unsigned sho
 // 38 spilled outside the row loops) 86.9 ms per 32768 cfg2 reads; with the LDS sweep sized for 2*WL+30*NL nodes (6.9 KB
 // per wave, larger graphs fall back to global scratch) 5 waves/SIMD run 65.5 ms against 72.2 ms; 6 waves spill into the
 // row loops (76 ms).
+// Round 5: the first launch at SIX waves per SIMD (80 VGPRs; five LDS granules of 1 280 bytes): 30.9 -> 28.4 ms (cfg2), 59.1 -> 54.4 (cfg4),
+// 33.9 -> 31.1 (cfg3).  Round 4 had measured "6 waves: nothing" -- with 6 656 bytes of LDS, i.e. six granules and 21 resident waves.
 #ifndef C3_WIN_WAVES
-#define C3_WIN_WAVES 5
+#define C3_WIN_WAVES 6
+#endif
+#ifndef C3_WIN_WAVES2
+#define C3_WIN_WAVES2 5
 #endif
 template <bool SECOND>
-__global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
+__global__ __launch_bounds__(64, SECOND ? C3_WIN_WAVES2 : C3_WIN_WAVES) void k_window(WinArgs a) {
   const int lane = wave_lane();
   const int slot = blockIdx.x;
   WCtx c;
@@ -1101,7 +1118,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
   const int MW = win_mask_words(a.Ncap);
   unsigned long long* m2bits = (unsigned long long*)lds_dyn; unsigned long long* mabits = m2bits + MW;
   unsigned long long* d0bits = mabits + MW; unsigned long long* d1bits = d0bits + MW;         // band shift bits of every DP row (banded layers)
-  const int lds_ints = (int)(win_lds_bytes(a.Lcap, a.Ncap) / 4);    // = the launch's dynamic LDS
+  const int lds_ints = (int)(win_lds_bytes(a.Lcap, a.Ncap, !SECOND) / 4);    // = the launch's dynamic LDS
   PH_DECL
 
   for (;;) {
@@ -1264,7 +1281,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
         for (int attempt = 0; attempt < 4; ++attempt) {
           unsigned long long dbg_[6] = {0, 0, 0, 0, 0, 0};
           int nblocks = 0;
-          if (win_rows_dispatch(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, d0bits, d1bits, ring_off, lds_ints, l.begin, l.end, blen, &cb, &nblocks) < 0) { fail = SECOND ? 1 : 2; if (SECOND && lane == 0) atomicAdd(a.counter + W_CNT_WHY + 1, 1); break; }      // (2: the layer needs more DP scratch than this launch has -- the window goes to the full-size launch)
+          if (win_rows_dispatch<SECOND>(c, P, pk, l.qbeg, Q, R, lane, &cpl, &RS, dbg_, m2bits, mabits, d0bits, d1bits, ring_off, lds_ints, l.begin, l.end, blen, &cb, &nblocks) < 0) { fail = SECOND ? 1 : 2; if (SECOND && lane == 0) atomicAdd(a.counter + W_CNT_WHY + 1, 1); break; }      // (2: the layer needs more DP scratch than this launch has -- the window goes to the full-size launch)
 #ifdef C3_PHASE_PROF
           ph_acc_[10] += dbg_[0]; ph_acc_[11] += dbg_[1];
 #endif
@@ -1308,7 +1325,7 @@ __global__ __launch_bounds__(64, C3_WIN_WAVES) void k_window(WinArgs a) {
 #ifdef C3_EXP_X2_TB
         for (int tbrep = 0; tbrep < 2; ++tbrep)
 #endif
-        if (cb) win_traceback_band(c.I, c.E, c.D, c.rdesc, c.K, c.n, c.Ncap, cb, R, Q, (gbs == INT32_MIN) ? 0 : gbr, MW, Q > W_QCAP, tbp_);
+        if (cb) win_traceback_band<SECOND>(c.I, c.E, c.D, c.rdesc, c.K, c.n, c.Ncap, cb, R, Q, (gbs == INT32_MIN) ? 0 : gbr, MW, Q > W_QCAP, tbp_);
         else
         {
           unsigned* WD = (unsigned*)lds_dyn + ring_off;       // [64][4] dwords, behind the row-type bitmasks
@@ -1578,7 +1595,7 @@ __global__ __launch_bounds__(64) void k_stitch(StitchArgs a) {
 
 extern "C" void c3k_launch_prep(const PrepArgs* a, int slots, hipStream_t s) { hipLaunchKernelGGL(k_prep, dim3(slots), dim3(64), 0, s, *a); }
 extern "C" void c3k_launch_window(const WinArgs* a, int slots, hipStream_t s) {
-  const size_t lds = win_lds_bytes(a->Lcap, a->Ncap);
+  const size_t lds = win_lds_bytes(a->Lcap, a->Ncap, a->wlist == nullptr);
   if (a->wlist) hipLaunchKernelGGL(k_window<true>, dim3(slots), dim3(64), lds, s, *a);
   else hipLaunchKernelGGL(k_window<false>, dim3(slots), dim3(64), lds, s, *a);
 }

@@ -197,7 +197,7 @@ __device__ __forceinline__ void wb_park_edge(unsigned eaddr, const int (&h)[CB])
 
 // All banded rows of one layer.  Returns 0, 1 (a predecessor's band lies too far left: not banded) or -1 (scratch too small).
 // Results in lob[0..2]: the certificate bound, the best end-row score H[r][Q] (INT32_MIN: none inside the band), its row.
-template <int CB>
+template <int CB, bool SECOND>
 __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t* cH, uint8_t* cD, uint4* crdesc, int cK, int cn, int cNcap, long long chcap,
                                                        int mt_, int mm_, int g_, const uint32_t* pk_, int qbeg_, int Q_, int R_, unsigned long long* dbg_, int lds_off_, int nblocks_) {
   WCtx c;
@@ -465,6 +465,7 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
 #ifndef WB_TB_SHIFT
 #define WB_TB_SHIFT 3     /* columns the traceback windows of a block sit to the right of its diagonal */
 #endif
+template <bool SECOND>
 __device__ __attribute__((noinline)) void win_traceback_band(int* cI, int* cE, uint8_t* cD, uint4* crdesc, int cK, int cn, int cNcap, int CB_, int R_, int Q_, int r_,
                                                              int mw_, int big_, unsigned long long* prof_) {
   WCtx c;

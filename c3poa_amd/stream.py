@@ -123,9 +123,11 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
             r.close()
         n_ranges, cuts = 1, [0, -1]
         readers = [_lib.Reader(args.reads, n_sets=N_SETS)]
-    free_sets = [queue.Queue() for _ in range(n_ranges)]
+    # (last in, first out: a set that has just come back is the one refilled next, so a reader only ever allocates -- and page-locks -- as many
+    # sets as it really has in flight at once; first in, first out walked through all five even when two would do)
+    free_sets = [queue.LifoQueue() for _ in range(n_ranges)]
     for fs in free_sets:
-        for j in range(N_SETS):
+        for j in reversed(range(N_SETS)):
             fs.put(j)
     free_results = queue.Queue()
     for _k in range(4 * n_work + 2):                # run -> fetch -> (queue of 2) -> write: four batches per worker can hold one

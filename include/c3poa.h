@@ -92,6 +92,8 @@ typedef struct {
   int64_t n_band_mismatch;                  /* C3_DEBUG_BAND=verify only: accepted band layers whose traceback differs from the full matrix's (must be 0) */
   int64_t n_win_redo;                       /* windows with a layer beyond the first launch's DP scratch, redone by the full-size second launch of k_window */
   int64_t n_poa_redo16;                     /* of n_poa_redo: reads redone by the LAST POA pass (32-bit cells, a workgroup of eight waves per read) -- a score did not fit the 16-bit cells of the first passes, or the far arena of a pass overflowed (long subreads: a band that blew up goes straight there) */
+  float ms_poa_tail;                        /* the last POA pass when it ran on a stream of its own BESIDE k_prep / k_window of the other reads (its reads are polished by a small tail afterwards); 0 when it ran in series (then it is part of ms_poa).  Not part of ms_total */
+  float pad_;
 } c3_timing;
 
 typedef struct c3_handle c3_handle;

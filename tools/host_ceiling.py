@@ -115,6 +115,14 @@ def _gen(job):
     return "".join(st)
 
 
+def _cpu_stat():
+    """cgroup v2 CPU accounting of this container (usage, throttling by the CPU quota)"""
+    try:
+        return {l.split()[0]: int(l.split()[1]) for l in open("/sys/fs/cgroup/cpu.stat").read().splitlines() if len(l.split()) == 2}
+    except Exception:
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("n", type=int, nargs="?", default=1000000)
@@ -162,15 +170,19 @@ def main():
             os.makedirs(out + "Splint1")
             args = types.SimpleNamespace(out_path=out, reads=fq, groupSize=1000, lencutoff=1000, mdistcutoff=500, zero=True, compress_output=False)
             st = {}
+            cg0, tm0 = _cpu_stat(), os.times()
             t0 = time.time()
             assigner = _lib.Assigner(psl, ["Splint1"])
             t_psl = time.time() - t0
             n = stream.run(args, sd, assigner, {"Splint1"}, w, stats=st)
             dt = time.time() - t0
             assigner.close()
+            cg1, tm1 = _cpu_stat(), os.times()
+            cpu = {"user_s": round(tm1.user - tm0.user, 2), "sys_s": round(tm1.system - tm0.system, 2),
+                   "cgroup": {k: cg1[k] - cg0.get(k, 0) for k in cg1 if k in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec")}}
             osz = sum(os.path.getsize(out + "Splint1/" + f) for f in os.listdir(out + "Splint1"))
             print(json.dumps({"workers": w, "reads": n, "seconds": round(dt, 2), "reads_per_s": round(n / dt, 1), "input_GB": round(size / 1e9, 2),
-                              "output_GB": round(osz / 1e9, 2), "gz": "bgzf" if a.bgzf else a.gz, "gz_threads": os.environ.get("C3_GZ_THREADS"), "ranges": st.get("ranges"), "psl_table_s": round(t_psl, 2),
+                              "output_GB": round(osz / 1e9, 2), "gz": "bgzf" if a.bgzf else a.gz, "gz_threads": os.environ.get("C3_GZ_THREADS"), "ranges": st.get("ranges"), "psl_table_s": round(t_psl, 2), "host_threads": os.environ.get("C3_HOST_THREADS"), "cpu": cpu,
                               "stage_s": {k: round(st[k], 2) for k in ("parse", "assign", "upload", "fetch", "write", "wait_in", "wait_out") if k in st}}))
             shutil.rmtree(out, ignore_errors=True)
     finally:
