@@ -329,6 +329,28 @@ def test_tiny_input_does_not_pin_gigabytes(tmp_path):
     rd.close(); rr.close()
 
 
+def test_sets_taken_for_the_tail_of_an_input_are_sized_by_what_is_left(tmp_path):
+    """round 5: a buffer set that is first used late in a file / byte range is sized by the bytes the reader can still deliver, not by
+    the largest group so far -- in particular a set taken when NOTHING is left (the call that finds the end of the input) stays empty.
+    Eight workers over a 20 GB input used to page-lock 50 GB this way: every range walked through its five sets at full batch size
+    although two groups emptied it.  (Measured with the round-4 library on this very input: 3.06 x the file size reserved; now 1.5 x.)"""
+    base = [(r[0], r[1], r[2]) for r in synth.generate("cfg1", n_reads=400)]
+    recs = [("%s_%d" % (n, c), sq, q) for c in range(15) for n, sq, q in base]
+    p = str(tmp_path / "m.fastq")
+    _write_fastq(p, recs)
+    size = os.path.getsize(p)
+    rd = _lib.Reader(p, n_sets=5)
+    got, per_set, ns = [], [], []
+    for k in range(5):                                    # a first-in-first-out free list: every call takes a set nobody has used yet
+        hb = rd.next(2500, 0, 1 << 30, set_index=k)
+        got += [hb.read(i) for i in range(hb.n)]
+        per_set.append(rd.reserved_bytes()); ns.append(hb.n)
+    assert ns == [2500, 2500, 1000, 0, 0] and got == recs
+    assert per_set[-1] < 1.8 * size, (per_set, size)
+    assert per_set[4] - per_set[2] < (8 << 20), per_set                      # the two calls that found nothing reserved next to nothing
+    rd.close()
+
+
 def test_writer_appends_at_the_real_end_after_a_truncate(tmp_path):
     """reservations are keyed by the file and live only while a writer is in flight: truncating (or replacing) an output file
     between two c3_write_group calls -- without c3_writer_reset -- must not leave a NUL-filled hole"""
