@@ -22,7 +22,7 @@ EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_warm_device
            "c3_reader_open", "c3_reader_open_range", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_reader_next_set", "c3_reader_noqual", "c3_reader_reserved_bytes", "c3_reader_range_lost", "c3_write_group",
            "c3_scan_adapters", "c3_match_index", "c3_match_index_batch",
            "c3_assign_open", "c3_assign_close", "c3_assign_batch", "c3_assign_seen", "c3_write_splint_psl",
-           "c3_host_alloc", "c3_host_free", "c3_writer_reset"]
+           "c3_host_alloc", "c3_host_free", "c3_writer_reset", "c3_compress_file"]
 
 
 class Config(C.Structure):
@@ -116,6 +116,7 @@ def load():
     lib.c3_host_free.argtypes = [vp]
     lib.c3_host_free.restype = None
     lib.c3_writer_reset.restype = None
+    lib.c3_compress_file.argtypes = [cp, cp, C.c_int, C.c_int]
     lib.c3_reader_open.argtypes = [cp, C.c_int, C.POINTER(vp)]
     lib.c3_reader_open_range.argtypes = [cp, C.c_int, C.c_int64, C.c_int64, C.POINTER(vp)]
     lib.c3_reader_close.argtypes = [vp]
@@ -693,6 +694,18 @@ class Assigner:
             self.close()
         except Exception:
             pass
+
+
+def compress_file(src, dst=None, level=6, threads=0, remove=True):
+    """-co (C3POa.py:86-99, C3POa_postprocessing.py -co): src -> dst (default src + '.gz') as a BGZF-layout gzip file, deflated by
+    `threads` threads (0 = the usable cores); removes src afterwards, as the reference's gzip step leaves only the .gz"""
+    dst = dst or src + ".gz"
+    rc = load().c3_compress_file(_b(src), _b(dst), int(level), int(threads))
+    if rc != 0:
+        raise C3Error("c3_compress_file(%s -> %s): error %d" % (src, dst, rc))
+    if remove:
+        os.remove(src)
+    return dst
 
 
 def write_group(hb, res, cons_buf, cons_off, splint_ids, cons_paths, sub_paths, zero=True):

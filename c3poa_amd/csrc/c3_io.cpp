@@ -826,6 +826,78 @@ extern "C" int c3_write_group(const c3_host_batch* b, const c3_read_result* res,
   return ok ? C3_E_OK : C3_E_ARG;
 }
 
+// ---- -co: the output files compressed by every core instead of one Python thread (C3POa.py:86-99 writes the final file through
+// gzip.open line by line).  BGZF layout: independent members of BGZF_BLOCK input bytes, so the file is an ordinary multi-member gzip file
+// for every other reader and a parallel one for c3_reader_open.
+namespace {
+const size_t BGZF_BLOCK = 0xff00;             // input bytes per member (bgzip's choice: the deflated member stays below 64 KiB)
+// one member: header with the 'BC' subfield, raw deflate, CRC32 + ISIZE.  Returns its size (0: failed).
+size_t bgzf_deflate(const unsigned char* in, size_t n, int level, unsigned char* out, size_t cap) {
+  if (cap < 26 + n + n / 1000 + 64) return 0;
+  z_stream z; memset(&z, 0, sizeof(z));
+  if (deflateInit2(&z, level, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return 0;
+  z.next_in = const_cast<unsigned char*>(in); z.avail_in = (unsigned)n;
+  z.next_out = out + 18; z.avail_out = (unsigned)(cap - 26);
+  const int rc = deflate(&z, Z_FINISH);
+  const size_t clen = z.total_out;
+  deflateEnd(&z);
+  if (rc != Z_STREAM_END) return 0;
+  const size_t total = 18 + clen + 8;
+  if (total > 65536) return 0;                 // (cannot happen at BGZF_BLOCK input bytes: deflate expands by < 0.1 % + 5 bytes per 16 KiB)
+  static const unsigned char hd[12] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0};
+  memcpy(out, hd, 12);
+  out[12] = 'B'; out[13] = 'C'; out[14] = 2; out[15] = 0;
+  out[16] = (unsigned char)((total - 1) & 255); out[17] = (unsigned char)((total - 1) >> 8);
+  const unsigned long crc = crc32(crc32(0L, Z_NULL, 0), in, (unsigned)n);
+  unsigned char* t = out + 18 + clen;
+  for (int k = 0; k < 4; ++k) { t[k] = (unsigned char)(crc >> (8 * k)); t[4 + k] = (unsigned char)(n >> (8 * k)); }
+  return total;
+}
+}  // namespace
+
+extern "C" int c3_compress_file(const char* src, const char* dst, int level, int threads) {
+  if (!src || !dst || level < 0 || level > 9) return C3_E_ARG;
+  if (level == 0) level = 6;
+  const int T = threads > 0 ? std::min(threads, 256) : host_cores();
+  FILE* fi = fopen(src, "rb");
+  if (!fi) return C3_E_ARG;
+  FILE* fo = fopen(dst, "wb");
+  if (!fo) { fclose(fi); return C3_E_ARG; }
+  // a stretch = T x 64 members: read, deflated by T threads (members dealt round-robin), written in order; the next stretch is read while
+  // this one is written
+  const size_t per = 64, nb = (size_t)T * per, in_cap = nb * BGZF_BLOCK, out_slot = 65536 + 64;
+  std::vector<unsigned char> in(in_cap), out(nb * out_slot);
+  std::vector<size_t> osz(nb);
+  bool ok = true;
+  for (;;) {
+    const size_t got = fread(in.data(), 1, in_cap, fi);
+    if (got == 0) { if (ferror(fi)) ok = false; break; }
+    const size_t nblk = (got + BGZF_BLOCK - 1) / BGZF_BLOCK;
+    std::atomic<bool> good{true};
+    auto work = [&](size_t t0) {
+      CpuSlot slot_;
+      for (size_t b = t0; b < nblk; b += (size_t)T) {
+        const size_t o = b * BGZF_BLOCK, n = std::min(BGZF_BLOCK, got - o);
+        osz[b] = bgzf_deflate(in.data() + o, n, level, out.data() + b * out_slot, out_slot);
+        if (!osz[b]) { good = false; return; }
+      }
+    };
+    std::vector<std::thread> th;
+    for (size_t t = 1; t < (size_t)T && t < nblk; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto& x : th) x.join();
+    if (!good) { ok = false; break; }
+    for (size_t b = 0; b < nblk && ok; ++b) ok = fwrite(out.data() + b * out_slot, 1, osz[b], fo) == osz[b];
+    if (!ok || got < in_cap) break;
+  }
+  static const unsigned char eof_member[28] = {0x1f, 0x8b, 8, 4, 0, 0, 0, 0, 0, 0xff, 6, 0, 'B', 'C', 2, 0, 0x1b, 0, 3, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  if (ok) ok = fwrite(eof_member, 1, 28, fo) == 28;
+  fclose(fi);
+  if (fclose(fo) != 0) ok = false;
+  if (!ok) { unlink(dst); return C3_E_ARG; }
+  return C3_E_OK;
+}
+
 // ---- oligo-dT index matcher of the post-processing step (C3POa_postprocessing.py:266-285, match_index) ----------
 // seq is slid over every index (file order); the Levenshtein distance of seq[p : p+len(idx)] to idx is taken for every
 // position where the slice has the full length (at a position where it is too short for index k the reference breaks

@@ -209,9 +209,9 @@ def write_fasta_file(args, path, adapter_dict, reads, seq_to_idx, idx_to_seq, ma
 
 
 def _gzip_in_place(path):
-    with open(path, "rb") as src, gzip.open(path + ".gz", "wb") as dst:
-        shutil.copyfileobj(src, dst, 1 << 24)
-    os.remove(path)
+    # (native, every core: c3_compress_file writes independent gzip members; C3POa_postprocessing.py -co gzips its outputs)
+    from . import _lib
+    _lib.compress_file(path, path + ".gz", level=6)
 
 
 def run(args):

@@ -9,10 +9,8 @@ The reference's -g (group size) only decides how reads are partitioned into <spl
 concatenated and deleted at the end (C3POa.py:259-271); here a GPU batch is max(-g, GPU_BATCH_READS) reads (or
 C3_GPU_BATCH_READS when set) and records are appended to the final files directly (same output tree, no double write).
 """
-import gzip
 import os
 import queue
-import shutil
 import sys
 import threading
 import time
@@ -375,11 +373,11 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
                     pass
         t["adapter_set"] = sorted(seen)
     if compress:                                                        # -co (C3POa.py:88-90)
+        # every core deflates (c3_compress_file: independent gzip members in the BGZF layout -- any gzip reader takes the file, this
+        # package's reader inflates it in parallel); the reference pushes the whole output through ONE gzip.open stream, line by line
         for p in cons_paths + sub_paths:
             if os.path.exists(p):
-                with open(p, "rb") as src, gzip.open(p + ".gz", "wb", compresslevel=6) as dst:
-                    shutil.copyfileobj(src, dst, 1 << 24)
-                os.remove(p)
+                _lib.compress_file(p, p + ".gz", level=6)
     if stats is not None:
         stats.update(t)
     if os.environ.get("C3_STREAM_STATS"):

@@ -278,6 +278,13 @@ int c3_write_group(const c3_host_batch* b, const c3_read_result* res, const char
  * c3_writer_reset forgets all reservations (start of a run; never while c3_write_group calls are in flight). */
 void c3_writer_reset(void);
 
+/* -co / --compress_output (C3POa.py:46-47; cat_files writes the final file through gzip.open, C3POa.py:86-99; C3POa_postprocessing.py -co):
+ * src is compressed into dst as a gzip file made of independent members of <= 64 KiB in the BGZF layout (each header carries the
+ * member's size in a 'BC' extra subfield; the empty end-of-file member closes it) -- every gzip reader inflates it (zcat, Python's
+ * gzip, mm.fastx_read), and c3_reader_open inflates its members in parallel.  `threads` deflate at once (0 = the usable host cores),
+ * `level` 1..9 (0 = zlib's default 6).  Host code.  C3_E_ARG: a file cannot be opened / written; the partial dst is removed. */
+int c3_compress_file(const char* src, const char* dst, int level, int threads);
+
 /* splint assignment from the PSL (bin/preprocess.py:22-45) without per-read host objects: rows with qBaseInsert < 50 and
  * matches > 50 count, per read the row with the most matches wins (the earliest on ties).  Host code. */
 typedef struct c3_assign c3_assign;

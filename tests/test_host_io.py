@@ -475,3 +475,46 @@ def test_bgzf_input_is_inflated_in_parallel_and_equals_the_plain_file(tmp_path, 
     # names-only pass and the length cut-off behave as on plain input
     got, short, _z = _all(str(tmp_path / "b301_0.fastq.gz"), 6, min_len=sorted(len(r[1]) for r in recs)[5])
     assert short == 5 and len(got) == 18
+
+
+def test_compress_file_is_gzip_for_everybody_and_bgzf_for_this_reader(tmp_path, monkeypatch):
+    """-co (C3POa.py:46-47,86-99: the final files are written through gzip.open): c3_compress_file deflates independent members on
+    several threads.  The result must be what any gzip reader expects (Python's gzip gives the bytes back), carry the BGZF size
+    subfield in every member (this package's reader then inflates it in parallel -- and yields the same records), end with the empty
+    end-of-file member, work for an empty and for a multi-stretch input, with one thread or many, and leave no partial file behind on
+    an error"""
+    import gzip as _gz
+    recs = [(r[0], r[1], r[2]) for r in synth.generate("cfg1", n_reads=300)]
+    src = str(tmp_path / "sub.fastq")
+    _write_fastq(src, recs)
+    data = open(src, "rb").read()
+    eof = bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000")
+    for threads, level in ((1, 1), (3, 6), (0, 9)):
+        dst = str(tmp_path / ("o%d.gz" % threads))
+        assert _lib.compress_file(src, dst, level=level, threads=threads, remove=False) == dst
+        z = open(dst, "rb").read()
+        assert _gz.decompress(z) == data and z.endswith(eof)
+        assert z[:4] == b"\x1f\x8b\x08\x04" and z[12:16] == b"BC\x02\x00"
+        nm = 0; at = 0                                                      # walk the members by their size subfields
+        while at < len(z):
+            at += int.from_bytes(z[at + 16:at + 18], "little") + 1; nm += 1
+        assert at == len(z) and nm == (len(data) + 0xff00 - 1) // 0xff00 + 1
+        monkeypatch.setenv("C3_GZ_THREADS", "4")
+        assert _all(dst, 64)[0] == recs                                     # the parallel BGZF path of the native reader
+    assert len(z) < 0.6 * len(data)
+    # empty input -> just the end-of-file member; default name + removal of the source (what -co does)
+    e = str(tmp_path / "empty.fasta")
+    open(e, "w").close()
+    assert _lib.compress_file(e) == e + ".gz" and not os.path.exists(e) and open(e + ".gz", "rb").read() == eof and _gz.decompress(eof) == b""
+    # an input of several stretches (threads x 64 members each)
+    big = str(tmp_path / "big.txt")
+    blob = (data * 4)[:9 * 1024 * 1024 + 12345]
+    open(big, "wb").write(blob)
+    _lib.compress_file(big, big + ".gz", threads=2, remove=False)
+    assert _gz.decompress(open(big + ".gz", "rb").read()) == blob
+    # errors: a source that does not exist, a destination that cannot be created
+    with pytest.raises(_lib.C3Error):
+        _lib.compress_file(str(tmp_path / "nope"), str(tmp_path / "nope.gz"))
+    with pytest.raises(_lib.C3Error):
+        _lib.compress_file(src, str(tmp_path / "no_such_dir" / "x.gz"), remove=False)
+    assert os.path.exists(src)
