@@ -195,6 +195,21 @@ __device__ __forceinline__ void wb_park_edge(unsigned eaddr, const int (&h)[CB])
                  :: "s"(emask), "v"(eaddr), "v"(h[0]), "v"(h[CB > 1 ? 1 : 0]), "v"(h[CB > 2 ? 2 : 0]), "v"(h[CB > 3 ? 3 : 0]) : "memory");
 }
 
+// inclusive max-scan of signed 16-bit keys in the low halves (the high halves are don't-care on input, zero on output): v_max_i16 takes DPP
+// like every VOP2, so the scan needs no sign extension first.  Hand-written because the hazard recogniser does not look inside inline
+// assembly: a DPP instruction reading a register the previous vector instruction wrote needs two wait states (s_nop 1).
+__device__ __forceinline__ int wb_scan_max16(int x) {
+  asm volatile("s_nop 1\n\t"
+               "v_max_i16_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_max_i16_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_max_i16_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_max_i16_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_max_i16_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"
+               "v_max_i16_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf"
+               : "+v"(x));       // (the compiler adds the wait states in front of whatever reads x next: it knows the statement wrote it)
+  return x;
+}
+
 // All banded rows of one layer.  Returns 0, 1 (a predecessor's band lies too far left: not banded) or -1 (scratch too small).
 // Results in lob[0..2]: the certificate bound, the best end-row score H[r][Q] (INT32_MIN: none inside the band), its row.
 template <int CB, bool SECOND>
@@ -263,23 +278,35 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
   // one row ends: horizontal gap inside the band (in-lane prefix + one cross-lane max-scan over y = H - g * offset), new
   // hcur, 2 direction bits per cell on top of the accumulator.  PIDX: the predecessor that set the cell sits in bits 16..21
   // of key (rows with several predecessors) and goes to the row's index bytes.
+  // Trimmed by hand in round 5 (-3 % of k_window at cfg2, -2 % at cfg3 / cfg4; the compiler's version of the fast row was ~56 vector
+  // instructions, this is ~43): the first term starts the in-lane maximum (no -infinity to max against), the scan runs on the 16-bit
+  // keys themselves (v_max_i16 takes DPP: no sign extension), the direction bits of the lane's cells are gathered with and / shift-or
+  // and enter the accumulator through ONE v_alignbit (it was shift, and, shift, or per cell and a shift + or for the word), and the LDS
+  // address of the parked edge cells is a register that counts up (it was a 64-bit multiply-add per row).  What is left of the gap to
+  // a hand-written row are five to eight register copies where the three row kinds merge; giving the runs of fast rows a loop of
+  // their own removes them there (36 instructions per row) and doubles them everywhere else: 28.5 -> 30.7 ms, not shipped.
 #define WB_ROW_TAIL(PIDX)                                                                                        \
     {                                                                                                            \
-      int run = W_NEG16;                                                                                         \
-      _Pragma("unroll") for (int cc = 0; cc < CB; ++cc) run = max16(run, key[cc] - g41[cc]);                    \
-      int ex = wave_shr1(wave_scan_max(__builtin_amdgcn_sbfe(run, 0, 16)), W_NEG16);                             \
-      unsigned w2 = 0, pidx = 0;                                                                                 \
+      int yv[CB];                                                                                                \
+      _Pragma("unroll") for (int cc = 0; cc < CB; ++cc) yv[cc] = key[cc] - g41[cc];                             \
+      int run = yv[0];                                                                                           \
+      _Pragma("unroll") for (int cc = 1; cc < CB; ++cc) run = max16(run, yv[cc]);                               \
+      int ex = wave_shr1(wb_scan_max16(run), W_NEG16);                                                           \
+      unsigned pidx = 0;                                                                                         \
+      int k2[CB];                                                                                                \
       _Pragma("unroll") for (int cc = 0; cc < CB; ++cc) {                                                       \
-        const int k2 = max16(key[cc], (ex & ~3) + g41[cc]);                                                      \
-        ex = max16(ex, key[cc] - g41[cc]);                                                                       \
-        hcur[cc] = k2 & ~3;                                                                                      \
-        w2 |= ((unsigned)k2 & 3u) << (32 - BPR + 2 * cc);                                                        \
+        k2[cc] = max16(key[cc], (ex & ~3) + g41[cc]);                                                            \
+        if (cc + 1 < CB) ex = max16(ex, yv[cc]);                                                                 \
+        hcur[cc] = k2[cc] & ~3;                                                                                  \
         if (PIDX) pidx |= (((unsigned)key[cc] >> 16) & 63u) << (8 * cc);                                         \
       }                                                                                                          \
-      dacc = (dacc >> BPR) | w2;                                                                                 \
+      unsigned tb = (unsigned)k2[CB - 1];                                                                        \
+      _Pragma("unroll") for (int cc = CB - 2; cc >= 0; --cc) tb = (tb << 2) | ((unsigned)k2[cc] & 3u);          \
+      dacc = __builtin_amdgcn_alignbit(tb, dacc, BPR);                                                           \
       if (PIDX) GP(unsigned, PX)[(unsigned)r * 64u + (unsigned)lane] = pidx;                                     \
-      wb_park_edge<CB>(ebase + (unsigned)(li & (WB_EROWS - 1)) * (2u * WB_EROW), hcur);                                             \
+      wb_park_edge<CB>(eaddr, hcur);                                                                             \
     }
+#define WB_ROW_TAIL_FAST() WB_ROW_TAIL(false)
 #define WB_RING_WRITE()                                                                                          \
     {                                                                                                            \
       unsigned short* sp_ = ring + (r & (WB_RING - 1)) * SLOT;                                                   \
@@ -295,9 +322,11 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
     const int cnt = min(64, R - rb + 1);
     for (int half_ = 0; half_ < 64 && half_ < cnt; half_ += WB_EROWS) {
     const int hend_ = min(half_ + WB_EROWS, cnt);
+    unsigned eaddr = ebase - 2u * WB_EROW;                                  // LDS address of this lane's parked edge cells of the row (slot li & 31): counts up
     for (int li = half_; li < hend_; ++li) {
       const int r = rb + li;
       const unsigned dx = (unsigned)__builtin_amdgcn_readlane((int)dblk.x, li);
+      eaddr += 2u * WB_EROW;
       int key[CB];
       if (dx & (1u << 20)) {
         // FAST ROW: the row above, band shift 0 or 1
@@ -318,7 +347,7 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
             const int hv = cc + 1 < CB ? hcur[cc + 1 < CB ? cc + 1 : cc] : hnext;
             key[cc] = max16(hcur[cc] + tv[cc], hv + cV);
           }
-          WB_ROW_TAIL(false)
+          WB_ROW_TAIL_FAST()
         } else {
           int tv[CB];
 #pragma unroll
@@ -329,7 +358,7 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
             const int hd = cc == 0 ? hleft : hcur[cc > 0 ? cc - 1 : 0];
             key[cc] = max16(hd + tv[cc], hcur[cc] + cV);
           }
-          WB_ROW_TAIL(false)
+          WB_ROW_TAIL_FAST()
         }
         if (dx & (1u << 23)) WB_RING_WRITE()
       } else {
@@ -442,6 +471,7 @@ __device__ __attribute__((noinline)) int win_rows_band(int* cI, int* cE, int32_t
     }
   }
 #undef WB_ROW_TAIL
+#undef WB_ROW_TAIL_FAST
 #undef WB_RING_WRITE
   best = wave_max(best);
   const int gbs = wave_max(ebs);
