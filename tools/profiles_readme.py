@@ -22,6 +22,9 @@ NOTES = {   # what each further file of the round is (facts about HOW it was mad
     "ab_poa_register_allocation.txt": "`k_poa` with / without two edits outside its row loops: +3.5 % with both, back to round 4's time with both removed",
     "ab_compiler_flags.txt": "`tools/experiments/ab_r05_flags.sh`: `k_poa.hip` / `k_polish.hip` rebuilt with ten backend options each (scheduling strategies, metric bias, no post-RA scheduler, SGPR-spill pre-allocation, -O2 ...): none beats the default build beyond run-to-run noise, `max-ilp` / `max-memory-clause` lose 9-13 %",
     "ab_window_mask_stamps.txt": "`tools/experiments/ab_r05_mask_stamps.sh`: `k_window`'s sub-graph fixpoint with per-turn stamps instead of a clearing sweep (one sweep and one barrier less per turn) against the shipped clearing sweep: no faster (cfg2 +0.5 %, cfg3 -0.4 %, cfg4 +0.6 %); not shipped",
+    "ab_window_row_trim.txt": "`tools/experiments/ab_r05_rowtrim.sh`: `k_window` before the hand-trimmed row tail (base), with it in the fast rows (rowtrim), in all banded rows (rowtrim2 = shipped)",
+    "ab_window_run_loop.txt": "the same with runs of fast rows as a loop of their own (runloop2): fewer instructions per fast row, more register copies everywhere else, slower; not shipped",
+    "ab_tb_uniform.txt": "`tools/experiments/ab_r05_tb_uniform.sh`: `k_window`'s traceback bookkeeping (row, column, ballot shift) kept in scalar registers (tbuni: 69 vector instructions fewer, 103 scalar more) against the shipped vector form (tbvec): cfg2 -0.9 %, cfg3 +0.3 %, cfg4 -0.2 %, inside run-to-run noise; not shipped",
     "pmc_mem_cfg2.txt": "`tools/pmc_mem.sh 32768 cfg2`: TA / TCP / UTCL1 / TCC counters per kernel (one group per pass)",
     "vmem_rates_gfx950.txt": "`tools/ubench/vmem_rates.hip`: CU-cycles per vector memory instruction by shape, 24 / 12 / 4 waves per CU",
     "tmpfs_write_one_file_pwrite_mmap.txt": "`tools/experiments/tmpfs_write_bench.cpp`: one tmpfs file by `pwrite` / `mmap` from 1-16 threads against one file per thread",
