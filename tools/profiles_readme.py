@@ -25,6 +25,9 @@ NOTES = {   # what each further file of the round is (facts about HOW it was mad
     "ab_window_row_trim.txt": "`tools/experiments/ab_r05_rowtrim.sh`: `k_window` before the hand-trimmed row tail (base), with it in the fast rows (rowtrim), in all banded rows (rowtrim2 = shipped)",
     "ab_window_run_loop.txt": "the same with runs of fast rows as a loop of their own (runloop2): fewer instructions per fast row, more register copies everywhere else, slower; not shipped",
     "ab_tb_uniform.txt": "`tools/experiments/ab_r05_tb_uniform.sh`: `k_window`'s traceback bookkeeping (row, column, ballot shift) kept in scalar registers (tbuni: 69 vector instructions fewer, 103 scalar more) against the shipped vector form (tbvec): cfg2 -0.9 %, cfg3 +0.3 %, cfg4 -0.2 %, inside run-to-run noise; not shipped",
+    "ab_poa_near_rows_two_columns_per_lane.txt": "`tools/experiments/ab_r05_near_pair.sh` with `tools/experiments/k_poa_near_pair.patch` applied: `k_poa`'s near rows of 65-128 columns with two columns per lane, in both instances / in the WIDE instance only, against the shipped two chunks of 64 (_nopair): cfg2 +1.5 %, cfg4 -1.5 % / cfg4 -0.7 %, cfgL +1.1 %; not shipped",
+    "phase_occupancy_cfg2.txt": "`tools/phase_occupancy.py 16384 cfg2` (phase-profiling build): rows and graph phases of `k_poa` / `k_window` at 3-6 resident waves per SIMD, each fitted as a + b / w and extrapolated to the hardware's eight",
+    "two_handles_side_by_side.txt": "`tools/experiments/two_handles.py`: two handles fed from two host threads against one handle running the same batches in series: cfg2 +2.0 %, cfg4 +0.6 %",
     "pmc_mem_cfg2.txt": "`tools/pmc_mem.sh 32768 cfg2`: TA / TCP / UTCL1 / TCC counters per kernel (one group per pass)",
     "vmem_rates_gfx950.txt": "`tools/ubench/vmem_rates.hip`: CU-cycles per vector memory instruction by shape, 24 / 12 / 4 waves per CU",
     "tmpfs_write_one_file_pwrite_mmap.txt": "`tools/experiments/tmpfs_write_bench.cpp`: one tmpfs file by `pwrite` / `mmap` from 1-16 threads against one file per thread",
