@@ -17,6 +17,9 @@
 
 // One anti-diagonal step of the R cells a lane owns.  The substitution score is a signed-byte table per splint row
 // (tbl[k] byte r = score against read base r), so one v_bfe_i32 replaces compare + select; rc8 = 8 * read base.
+// a - b over unsigned 16-bit values, saturating at zero (result zero-extended)
+__device__ __forceinline__ int subsat_u16(int a, int b) { int d; asm("v_sub_u16_e64 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
+
 template <int R, bool CHECK>
 __device__ __forceinline__ void conk_step(int rc8, bool kill, int (&hprev)[R], int (&P)[R], int& W,
                                           int& up_prev, const int (&tbl)[R], int penalty) {
@@ -28,9 +31,11 @@ __device__ __forceinline__ void conk_step(int rc8, bool kill, int (&hprev)[R], i
   for (int k = 0; k < R; ++k) {
     // H <= match * splint length fits 16 bits: v_max_i16 issues at twice the rate of v_max_i32 / v_max3 (tools/ubench/valu_cost.hip);
     // its result is zero-extended, so the 32-bit diagonal sums below add clean values
+    // (the gap candidate leaves its subtraction saturated at zero -- v_sub_u16 with the clamp bit, same issue rate as the plain one --
+    // so the cell's own "max with 0" is gone: max(d + s, m, 0) == max(d + s, max(m, 0)); six vector instructions per cell instead of seven)
     int s = __builtin_amdgcn_sbfe(tbl[k], rc8, 8);
-    int m = max16(u, hprev[k]) - penalty;
-    int hh = max16(max16(d + s, m), 0);
+    int m = subsat_u16(max16(u, hprev[k]), penalty);
+    int hh = max16(d + s, m);
     if (CHECK) hh = kill ? 0 : hh;
     d = hprev[k];
     hprev[k] = hh;
