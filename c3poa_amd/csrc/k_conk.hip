@@ -3,7 +3,7 @@
 // Replaces conk.conk(splint, seq, 20) at /root/reference/C3POa.py:123 (conk is an un-vendored
 // Cython dependency; spec frozen in DESIGN.md 4.1 and restated by oracle/c3o_signal.c:c3o_conk).
 //
-// Mapping (MI355X-first, no LDS, no atomics): ONE WAVE PER READ.  Lane l owns R consecutive
+// Mapping (MI355X-first, no atomics; LDS only as a per-lane score table): ONE WAVE PER READ.  Lane l owns R consecutive
 // splint rows (64*R >= S; padding rows sit on top and can never score), and at step t works on
 // read column j = t - l, so the 64 lanes form a systolic anti-diagonal.  The only cross-lane
 // traffic is two DPP wave_shr:1 moves per step: the bottom-row H of the lane above, and the
@@ -15,14 +15,21 @@
 #include "c3_args.h"
 
 
-// One anti-diagonal step of the R cells a lane owns.  The substitution score is a signed-byte table per splint row
-// (tbl[k] byte r = score against read base r), so one v_bfe_i32 replaces compare + select; rc8 = 8 * read base.
 // a - b over unsigned 16-bit values, saturating at zero (result zero-extended)
 __device__ __forceinline__ int subsat_u16(int a, int b) { int d; asm("v_sub_u16_e64 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b)); return d; }
 
+// One anti-diagonal step of the R cells a lane owns.  The kernel is bound by vector issue and nothing else (102 % of the issue
+// cycles, profiles/r05_sq_counters_*), so whatever can leave the vector ALU does: the substitution score of a cell is a signed
+// BYTE READ FROM LDS -- the lane's table row k holds the four scores of splint row k as one dword (byte r = score against read
+// base r), the address is the lane's table + the read base of this step, the row is the instruction's immediate offset -- issued
+// on the LDS port beside the other waves' vector instructions (it was a v_bfe_i32 per cell: 4.2 issue cycles of 15.8).
+// trc = this lane's table + read base.
 template <int R, bool CHECK>
-__device__ __forceinline__ void conk_step(int rc8, bool kill, int (&hprev)[R], int (&P)[R], int& W,
-                                          int& up_prev, const int (&tbl)[R], int penalty) {
+__device__ __forceinline__ void conk_step(const signed char* trc, bool kill, int (&hprev)[R], int (&P)[R], int& W,
+                                          int& up_prev, int penalty) {
+  int sc[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) sc[k] = trc[k * 256];
   int up = wave_shr1z(hprev[R - 1]);
   int recv = wave_shr1z(W);
   int u = up, d = up_prev;
@@ -30,12 +37,11 @@ __device__ __forceinline__ void conk_step(int rc8, bool kill, int (&hprev)[R], i
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     // H <= match * splint length fits 16 bits: v_max_i16 issues at twice the rate of v_max_i32 / v_max3 (tools/ubench/valu_cost.hip);
-    // its result is zero-extended, so the 32-bit diagonal sums below add clean values
-    // (the gap candidate leaves its subtraction saturated at zero -- v_sub_u16 with the clamp bit, same issue rate as the plain one --
-    // so the cell's own "max with 0" is gone: max(d + s, m, 0) == max(d + s, max(m, 0)); six vector instructions per cell instead of seven)
-    int s = __builtin_amdgcn_sbfe(tbl[k], rc8, 8);
+    // its result is zero-extended, so the 32-bit diagonal sums below add clean values.
+    // The gap candidate leaves its subtraction saturated at zero (v_sub_u16 with the clamp bit, same issue rate as the plain one), so
+    // the cell's own "max with 0" is gone: max(d + s, m, 0) == max(d + s, max(m, 0)).  Five vector instructions per cell (seven in round 4).
     int m = subsat_u16(max16(u, hprev[k]), penalty);
-    int hh = max16(d + s, m);
+    int hh = max16(d + sc[k], m);
     if (CHECK) hh = kill ? 0 : hh;
     d = hprev[k];
     hprev[k] = hh;
@@ -55,6 +61,11 @@ template <int R, bool SCAN>
 __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
   const int lane = wave_lane();
   const int n_items = SCAN ? a.b.n * a.n_spl * 2 : a.b.n;
+  // score tables of the four waves of the block: [wave][row k][lane] dwords.  A lane only ever reads the dwords it wrote itself, and a
+  // wave's LDS operations complete in order: no barrier anywhere (lanes l and l + 32 share a bank and never the same half-wave pass)
+  __shared__ unsigned score_tab[4 * R * 64];
+  unsigned* const T = score_tab + (threadIdx.x >> 6) * (R * 64);
+  const signed char* const tbase = (const signed char*)(T + lane);
   for (;;) {
     int item = 0;
     if (lane == 0) item = atomicAdd(a.counter, 1);
@@ -76,12 +87,12 @@ __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
     int32_t* track = a.track + off;
     const int pad = 64 * R - S;
     const int mm4 = (a.mismatch & 255) * 0x01010101;
-    int tbl[R], hprev[R], P[R];
+    int hprev[R], P[R];
 #pragma unroll
     for (int k = 0; k < R; ++k) {
       int i = lane * R + k - pad;
       int code = (i >= 0) ? (int)sp[i] : 5;              // padding rows (and splint N) never match
-      tbl[k] = code < 4 ? (mm4 & ~(255 << (8 * code))) | ((a.match & 255) << (8 * code)) : mm4;
+      T[k * 64 + lane] = code < 4 ? (mm4 & ~(255 << (8 * code))) | ((a.match & 255) << (8 * code)) : mm4;
       hprev[k] = 0; P[k] = 0;
     }
     int W = 0, up_prev = 0;
@@ -103,17 +114,15 @@ __global__ __launch_bounds__(256) void k_conk(ConkArgs a) {
       if (fast) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-          const int rc8 = s >= 2 ? (int)((x >> (2 * s - 3)) & 24) : (int)((x << (3 - 2 * s)) & 24);
-          conk_step<R, false>(rc8, false, hprev, P, W, up_prev, tbl, pen);
+          conk_step<R, false>(tbase + ((x >> (2 * s)) & 3), false, hprev, P, W, up_prev, pen);
           o[s] = P[R - 1];
           if (SCAN) { int d = d0 + s; if (d >= 0 && d < L) { ssum += P[R - 1]; if (P[R - 1] > smax) { smax = P[R - 1]; sarg = d; } } }
         }
       } else {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-          const int rc8 = s >= 2 ? (int)((x >> (2 * s - 3)) & 24) : (int)((x << (3 - 2 * s)) & 24);
           const bool oob = (unsigned)(jb + s) >= (unsigned)L;
-          conk_step<R, true>(rc8, oob, hprev, P, W, up_prev, tbl, pen);
+          conk_step<R, true>(tbase + ((x >> (2 * s)) & 3), oob, hprev, P, W, up_prev, pen);
           o[s] = P[R - 1];
           if (SCAN) { int d = d0 + s; if (d >= 0 && d < L) { ssum += P[R - 1]; if (P[R - 1] > smax) { smax = P[R - 1]; sarg = d; } } }
         }
