@@ -28,6 +28,9 @@ NOTES = {   # what each further file of the round is (facts about HOW it was mad
     "ab_poa_near_rows_two_columns_per_lane.txt": "`tools/experiments/ab_r05_near_pair.sh` with `tools/experiments/k_poa_near_pair.patch` applied: `k_poa`'s near rows of 65-128 columns with two columns per lane, in both instances / in the WIDE instance only, against the shipped two chunks of 64 (_nopair): cfg2 +1.5 %, cfg4 -1.5 % / cfg4 -0.7 %, cfgL +1.1 %; not shipped",
     "phase_occupancy_cfg2.txt": "`tools/phase_occupancy.py 16384 cfg2` (phase-profiling build): rows and graph phases of `k_poa` / `k_window` at 3-6 resident waves per SIMD, each fitted as a + b / w and extrapolated to the hardware's eight",
     "two_handles_side_by_side.txt": "`tools/experiments/two_handles.py`: two handles fed from two host threads against one handle running the same batches in series: cfg2 +2.0 %, cfg4 +0.6 %",
+    "ab_conk_saturating_subtract.txt": "`tools/experiments/ab_r05_conk.sh` (first form): `k_conk` with the gap candidate's subtraction saturating at zero (six vector instructions per cell) against round 4's seven (_oldconk): 8.2 -> 7.1 ms per 32 768 cfg2 reads",
+    "ab_conk_scores_from_lds.txt": "`tools/experiments/ab_r05_conk.sh`: `k_conk` with the substitution scores as LDS byte reads (five vector instructions per cell) against the v_bfe_i32 form (_conk6): 7.1 -> 6.0 ms",
+    "ab_peaks_blocked_smoothing.txt": "`tools/experiments/ab_r05_peaks_sg.sh`: `k_peaks` with the smoothing passes run once / twice (old_1 / old_2: their marginal cost) and with four outputs per thread as real calls (new_*), inlined (inl), inlined within 96 registers (inl5) and with tiles of 944 outputs (inl5b): no variant beats the shipped kernel",
     "pmc_mem_cfg2.txt": "`tools/pmc_mem.sh 32768 cfg2`: TA / TCP / UTCL1 / TCC counters per kernel (one group per pass)",
     "vmem_rates_gfx950.txt": "`tools/ubench/vmem_rates.hip`: CU-cycles per vector memory instruction by shape, 24 / 12 / 4 waves per CU",
     "tmpfs_write_one_file_pwrite_mmap.txt": "`tools/experiments/tmpfs_write_bench.cpp`: one tmpfs file by `pwrite` / `mmap` from 1-16 threads against one file per thread",
