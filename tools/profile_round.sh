@@ -14,5 +14,5 @@ echo "python3 bench.py $ARGS" > $R/command.txt
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/stats -o s -- python3 bench.py $ARGS > $R/bench_stats.json 2> $R/stats.err
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/fetch -o b -- python3 bench.py $ARGS > $R/bench_fetch.json 2> $R/fetch.err
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/write -o b -- python3 bench.py $ARGS > $R/bench_write.json 2> $R/write.err
-python3 bench.py --cfg $CFG --steps 3 --warmup 1 $* > $R/bench.json 2> $R/bench.err
+python3 bench.py --cfg $CFG --steps 3 --warmup 2 $* > $R/bench.json 2> $R/bench.err
 ls -la $R $R/stats | head -30
