@@ -549,7 +549,8 @@ __device__ void win_build_desc(WCtx& c, int R, int lane, unsigned long long* m2,
 // predecessor row number t of DP row r (descriptor order); rows with more than 4 masked
 // predecessors walk the in-edge list
 __device__ int win_pred_row(const WCtx& c, const uint4& de, int r, int t) {
-  if (!((de.x >> 16) & 1)) return (t == 0) ? (de.y & 0xffff) : (t == 1) ? (de.y >> 16) : (t == 2) ? (de.z & 0xffff) : (de.z >> 16);
+  // (branch-free: as a chain of ?: the compiler built four nested EXEC-mask branches into every traceback step)
+  if (!((de.x >> 16) & 1)) { const unsigned w = (t & 2) ? de.z : de.y; return (int)((w >> ((t & 1) << 4)) & 0xffffu); }
   const int v = c.rows()[r];
   int seen = 0;
   for (int k = 0; k < c.n_in()[v]; ++k) { int pr = c.rowof()[c.in_from()[EI(v, k)]]; if (pr >= 0) { if (seen == t) return pr; ++seen; } }

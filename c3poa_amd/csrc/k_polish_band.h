@@ -123,7 +123,9 @@ __device__ int win_build_desc_band(WCtx& c, int R, int Q, int begin, int end, in
       // backbone position reached so far -> band start (non-decreasing)
       const int bbs = max(wave_scan_max(live && v[u] < blen ? v[u] : -1), bbc);
       bbc = wave_bcast(bbs, 63);
-      const int cen = (int)(((long long)(bbs - begin + 1) * Q + span / 2) / span);
+      // (32-bit: 0 <= bbs - begin + 1 <= span <= Ncap and Q <= 1000, the product stays below 2^31 -- the 64-bit division was ~150 vector
+      // instructions per 64 rows, as much as three fast rows)
+      const int cen = (int)(((unsigned)(bbs - begin + 1) * (unsigned)Q + (unsigned)(span / 2)) / (unsigned)span);
       const int lo = min(max(cen - WLf, 0), lomax);
       const int lop = wave_shr1(lo, loc);                               // lo of the row above
       loc = wave_bcast(lo, 63);
