@@ -393,7 +393,7 @@ __device__ void poa_sweep_desc(Ctx& c, int lane, int Q, bool qlds, const int PR)
 // immediate operand then; otherwise they are read from the parameters (SGPRs, most of them spilled into VGPR lanes: one
 // v_readlane per use in the row loop)
 template <bool W32, bool DEF, bool WIDE>
-__device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, long long* cells PHA) {
+__device__ __forceinline__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, long long* cells PHA) {
   constexpr int PR = WIDE ? 3 : C3_NARROW_PR, PW = WIDE ? C3_WIDE_PW : 128, PWT = PADL + PW + PADR, NCHMAX = PW / 64;
   constexpr int RING_CELLS = WIDE ? RING_CELLS_W : RING_CELLS_N, PQW = WIDE ? PQW_W : PQW_N;
   static_assert(PR * PWT == RING_CELLS, "ring geometry");
@@ -1127,6 +1127,28 @@ __device__ int poa_align(Ctx& c, const C3Params& P, int qb, int Q, int lane, lon
 // fuse the aligned subread into the graph, parallel over its bases: vq[q] = graph row node aligned to
 // base q (-1 = insertion).  Every graph node is touched by at most one base, so targets, new-node
 // ids (prefix sum), anchors (prefix max) and the Q+1 edges are all independent.
+// poa_align as a REAL CALL, for the WIDE instance (subreads beyond 1 792 bases: cfg4, cfgL).  Inlined into the kernel that instance spilled
+// 176-220 bytes per lane around its row loops; as a function of its own -- the slot pointers and sizes copied into scalars at entry, so
+// that nothing in the row loop goes through the Ctx reference -- it runs cfgL's alignments 11 % faster and cfg4's 2.7 %
+// (profiles/r05_ab_poa_align_call.txt).  The NARROW instance is the other way round (+10 % as a call) and stays inlined.
+__device__ __forceinline__ void* uni_ptr64(const void* p) {
+  const unsigned long long u = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+  return (void*)(((unsigned long long)hi << 32) | lo);
+}
+template <bool W32, bool DEF, bool WIDE>
+__device__ __attribute__((noinline)) int poa_align_call(Ctx& c_in, const C3Params& P_in, int qb_in, int Q_in, int lane, long long* cells PHA) {
+  Ctx c = c_in; const C3Params P = P_in;
+  const int qb = __builtin_amdgcn_readfirstlane(qb_in), Q = __builtin_amdgcn_readfirstlane(Q_in);
+  c.I = (int*)uni_ptr64(c.I); c.E = (int*)uni_ptr64(c.E); c.C = (char*)uni_ptr64(c.C); c.B8 = (uint8_t*)uni_ptr64(c.B8);
+  c.score_ = (long long*)uni_ptr64(c.score_); c.desc_ = (uint4*)uni_ptr64(c.desc_); c.jump_ = (int*)uni_ptr64(c.jump_); c.path_ = (int*)uni_ptr64(c.path_);
+  c.pk = (const uint32_t*)uni_ptr64(c.pk);
+  c.K = __builtin_amdgcn_readfirstlane(c.K); c.n = __builtin_amdgcn_readfirstlane(c.n); c.Ncap = __builtin_amdgcn_readfirstlane(c.Ncap);
+  c.cells_cap = __builtin_amdgcn_readfirstlane(c.cells_cap); c.far_shift = __builtin_amdgcn_readfirstlane(c.far_shift);
+  c.osel = __builtin_amdgcn_readfirstlane(c.osel); c.rb_span = __builtin_amdgcn_readfirstlane(c.rb_span);
+  return poa_align<W32, DEF, WIDE>(c, P, qb, Q, lane, cells PHP);
+}
+
 __device__ int poa_fuse(Ctx& c, bool first, int qb, int Q, int* path, int lane PHA) {
   const int n_old = c.n, K = c.K;
   int* vq = c.mpl();                                  // filled by poa_align's traceback
@@ -1311,7 +1333,7 @@ __global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
       int poff = 0;
       for (int s = 0; s < ns && !fail; ++s) {
         const int qb = wave_first(info->sub_beg[s]), Q = wave_first(info->sub_end[s]) - qb;
-        if (s > 0) { const int rc = poa_align<W32, DEF, WIDE>(c, a.p, qb, Q, lane, &cells PHP); if (rc < 0) { fail = (rc == -4 || rc == -5 || rc == -6) ? 2 : 1; punted = rc == -5 || rc == -6; break; } }
+        if (s > 0) { int rc; if constexpr (WIDE && !W32) rc = poa_align_call<W32, DEF, WIDE>(c, a.p, qb, Q, lane, &cells PHP); else rc = poa_align<W32, DEF, WIDE>(c, a.p, qb, Q, lane, &cells PHP); if (rc < 0) { fail = (rc == -4 || rc == -5 || rc == -6) ? 2 : 1; punted = rc == -5 || rc == -6; break; } }
         if (poa_fuse(c, s == 0, qb, Q, c.path() + poff, lane PHP) < 0) { fail = 2; break; }                 // node capacity
         poff += Q;
       }
