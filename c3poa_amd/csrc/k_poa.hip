@@ -176,6 +176,9 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 #ifndef C3_NEAR
 #define C3_NEAR 1
 #endif
+#ifndef C3_EXP_CALL_NARROW
+#define C3_EXP_CALL_NARROW 0   /* experiment: poa_align as a real call in the NARROW instances too */
+#endif
 // Ring geometry, two instances of the kernel (same LDS footprint): NARROW = 6 rows of 128 cells (two chunks of 64; a predecessor
 // up to 5 rows back is read from LDS: 99.7 % of them at cfg4) for subreads up to 1792 bases, whose bands stay below 128 columns,
 // with the whole packed subread in LDS; WIDE = 3 rows of 256 cells (up to four chunks) with a SLIDING query window of 960
@@ -1137,8 +1140,8 @@ __device__ __forceinline__ void* uni_ptr64(const void* p) {
   return (void*)(((unsigned long long)hi << 32) | lo);
 }
 template <bool W32, bool DEF, bool WIDE>
-__device__ __attribute__((noinline)) int poa_align_call(Ctx& c_in, const C3Params& P_in, int qb_in, int Q_in, int lane, long long* cells PHA) {
-  Ctx c = c_in; const C3Params P = P_in;
+__device__ __attribute__((noinline)) int poa_align_call(Ctx c, const C3Params& P_in, int qb_in, int Q_in, int lane, long long* cells PHA) {
+  const C3Params P = P_in;            // (Ctx by VALUE: a reference would put the caller's copy in memory for the rest of the kernel)
   const int qb = __builtin_amdgcn_readfirstlane(qb_in), Q = __builtin_amdgcn_readfirstlane(Q_in);
   c.I = (int*)uni_ptr64(c.I); c.E = (int*)uni_ptr64(c.E); c.C = (char*)uni_ptr64(c.C); c.B8 = (uint8_t*)uni_ptr64(c.B8);
   c.score_ = (long long*)uni_ptr64(c.score_); c.desc_ = (uint4*)uni_ptr64(c.desc_); c.jump_ = (int*)uni_ptr64(c.jump_); c.path_ = (int*)uni_ptr64(c.path_);
@@ -1333,7 +1336,7 @@ __global__ __launch_bounds__(64, C3_POA_WAVES) void k_poa(PoaArgs a) {
       int poff = 0;
       for (int s = 0; s < ns && !fail; ++s) {
         const int qb = wave_first(info->sub_beg[s]), Q = wave_first(info->sub_end[s]) - qb;
-        if (s > 0) { int rc; if constexpr (WIDE && !W32) rc = poa_align_call<W32, DEF, WIDE>(c, a.p, qb, Q, lane, &cells PHP); else rc = poa_align<W32, DEF, WIDE>(c, a.p, qb, Q, lane, &cells PHP); if (rc < 0) { fail = (rc == -4 || rc == -5 || rc == -6) ? 2 : 1; punted = rc == -5 || rc == -6; break; } }
+        if (s > 0) { int rc; if constexpr ((WIDE || C3_EXP_CALL_NARROW) && !W32) rc = poa_align_call<W32, DEF, WIDE>(c, a.p, qb, Q, lane, &cells PHP); else rc = poa_align<W32, DEF, WIDE>(c, a.p, qb, Q, lane, &cells PHP); if (rc < 0) { fail = (rc == -4 || rc == -5 || rc == -6) ? 2 : 1; punted = rc == -5 || rc == -6; break; } }
         if (poa_fuse(c, s == 0, qb, Q, c.path() + poff, lane PHP) < 0) { fail = 2; break; }                 // node capacity
         poff += Q;
       }
