@@ -31,6 +31,8 @@
 #include <vector>
 
 #include "../../include/c3poa.h"
+#include "c3_inflate.hpp"
+#include <sys/mman.h>
 
 namespace {
 
@@ -123,8 +125,22 @@ struct Bgzf {
   std::atomic<bool> eof{false}, bad{false};  // (written by the prefetch thread, read by the parser)
 };
 
+// plain gzip input read with the own decoder (c3_inflate.hpp): see gzfast_chunk
+struct GzFast {
+  static const size_t W = 32768, CHUNK = (size_t)4 << 20;
+  int fd = -1; const uint8_t* map = nullptr; size_t size = 0, at = 0;
+  c3inf::Inflater inf; bool in_member = false; size_t hist = 0; int members = 0;
+  std::vector<uint8_t> win;
+  std::thread th; std::mutex mu; std::condition_variable cv;
+  std::vector<char> ready[2]; bool full[2] = {false, false}; int prod = 0, cons = 0; size_t cpos = 0;
+  struct End { size_t off; uint32_t crc, isize; };
+  std::vector<End> ends[2];                 // members that end inside the chunk: offset of the end, the trailer's CRC-32 and length
+  uint32_t run_crc = 0; uint64_t run_len = 0; bool run_init = false;      // the parser's side: CRC of the member so far (checked there: the inflating thread is the slow one)
+  bool done = false, bad = false, stop = false, started = false;
+};
+
 struct c3_reader {
-  FILE* fp = nullptr; gzFile gz = nullptr; Bgzf* bz = nullptr;
+  FILE* fp = nullptr; gzFile gz = nullptr; Bgzf* bz = nullptr; GzFast* gzf = nullptr;
   std::vector<char> buf; size_t beg = 0, end = 0; bool eof = false; bool gz_bad = false;
   std::vector<BatchSet> sets; int cur = -1;
   std::string err;
@@ -157,17 +173,118 @@ bool bgzf_inflate(const unsigned char* m, size_t msz, char* out, size_t osz) {
   const size_t xlen = (size_t)m[10] | ((size_t)m[11] << 8);
   const size_t hdr = 12 + xlen;
   if (msz < hdr + 8) return false;
-  z_stream z; memset(&z, 0, sizeof(z));
-  if (inflateInit2(&z, -15) != Z_OK) return false;
-  z.next_in = const_cast<unsigned char*>(m + hdr); z.avail_in = (unsigned)(msz - hdr - 8);
-  z.next_out = (unsigned char*)out; z.avail_out = (unsigned)osz;
-  const int rc = inflate(&z, Z_FINISH);
-  const bool ok = rc == Z_STREAM_END && z.avail_out == 0;
-  inflateEnd(&z);
-  if (!ok) return false;
+  static const bool use_zlib = getenv("C3_GZ_ZLIB") != nullptr;      // (the zlib path stays for comparison)
+  if (use_zlib) {
+    z_stream z; memset(&z, 0, sizeof(z));
+    if (inflateInit2(&z, -15) != Z_OK) return false;
+    z.next_in = const_cast<unsigned char*>(m + hdr); z.avail_in = (unsigned)(msz - hdr - 8);
+    z.next_out = (unsigned char*)out; z.avail_out = (unsigned)osz;
+    const int rc = inflate(&z, Z_FINISH);
+    const bool ok = rc == Z_STREAM_END && z.avail_out == 0;
+    inflateEnd(&z);
+    if (!ok) return false;
+  } else {
+    // own decoder (c3_inflate.hpp): the member's size is known, so it runs to exactly osz bytes and must then find the end of the stream
+    static thread_local c3inf::Inflater inf;
+    inf.reset(m + hdr, m + msz - 8);
+    size_t pos = 0;
+    if (inf.run((uint8_t*)out, &pos, osz + 1, osz, 0) != 1 || pos != osz) return false;
+  }
   const unsigned char* t = m + msz - 8;
   const unsigned long crc = (unsigned long)t[0] | ((unsigned long)t[1] << 8) | ((unsigned long)t[2] << 16) | ((unsigned long)t[3] << 24);
   return crc32(crc32(0L, Z_NULL, 0), (const unsigned char*)out, (unsigned)osz) == crc;
+}
+
+// ---- plain gzip input with the own decoder: the file is mapped, a thread of its own inflates it chunk by chunk (32 KiB of history in
+// front of every chunk) and checks every member's CRC-32 and length; the parser copies finished chunks.  Concatenated members are one
+// stream, as for gzread; bytes after the last member that are not a gzip header end the input (zlib: "trailing garbage ignored").
+// header of the member at g->at: false when it is not a gzip member
+bool gzfast_header(GzFast* g) {
+  const uint8_t* p = g->map + g->at; const size_t n = g->size - g->at;
+  if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xe0)) return false;
+  const int flg = p[3]; size_t q = 10;
+  if (flg & 4) { if (q + 2 > n) return false; q += 2 + ((size_t)p[q] | ((size_t)p[q + 1] << 8)); }
+  if (flg & 8) { while (q < n && p[q]) ++q; ++q; }
+  if (flg & 16) { while (q < n && p[q]) ++q; ++q; }
+  if (flg & 2) q += 2;
+  if (q + 8 > n) return false;
+  g->inf.reset(p + q, g->map + g->size); g->in_member = true; g->hist = 0;
+  return true;
+}
+// one chunk into out (at most CHUNK bytes): bytes produced, 0 at the end of the input, -1 on a damaged stream
+long gzfast_chunk(GzFast* g, std::vector<char>& out, std::vector<GzFast::End>& ends) {
+  out.clear(); ends.clear();
+  while (out.size() < GzFast::CHUNK / 2) {
+    if (!g->in_member) {
+      if (g->at >= g->size) break;
+      if (!gzfast_header(g)) { if (g->members == 0) return -1; break; }      // (trailing bytes that are not a member)
+    }
+    uint8_t* base = g->win.data() + GzFast::W;
+    size_t pos = 0;
+    const int rc = g->inf.run(base, &pos, GzFast::CHUNK - out.size(), GzFast::CHUNK + 512, g->hist);
+    if (rc < 0) return -1;
+    out.insert(out.end(), (const char*)base, (const char*)base + pos);
+    // the last 32 KiB become the history in front of the next chunk
+    if (pos >= GzFast::W) { memcpy(g->win.data(), base + pos - GzFast::W, GzFast::W); g->hist = GzFast::W; }
+    else { memmove(g->win.data(), g->win.data() + pos, GzFast::W); g->hist = std::min(GzFast::W, g->hist + pos); }
+    if (rc == 1) {
+      const uint8_t* t = g->inf.byte_pos();
+      if (t + 8 > g->map + g->size) return -1;
+      const uint32_t crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+      const uint32_t isz = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+      ends.push_back({out.size(), crc, isz});                               // (checked by the parser's side: gzfast_verify)
+      g->at = (size_t)(t + 8 - g->map); g->in_member = false; ++g->members;
+    }
+  }
+  return (long)out.size();
+}
+void gzfast_thread(GzFast* g) {
+  for (;;) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [g] { return g->stop || !g->full[g->prod]; });
+    if (g->stop) return;
+    lk.unlock();
+    const long n = gzfast_chunk(g, g->ready[g->prod], g->ends[g->prod]);
+    lk.lock();
+    if (n < 0) { g->bad = true; g->done = true; g->cv.notify_all(); return; }
+    if (n == 0) { g->done = true; g->cv.notify_all(); return; }
+    g->full[g->prod] = true; g->prod ^= 1; g->cv.notify_all();
+  }
+}
+// CRC-32 and length of every member that ends in this chunk, and the running CRC of the one that goes on
+bool gzfast_verify(GzFast* g, const std::vector<char>& c, const std::vector<GzFast::End>& ends) {
+  if (!g->run_init) { g->run_crc = (uint32_t)crc32(0L, Z_NULL, 0); g->run_len = 0; g->run_init = true; }
+  size_t s0 = 0;
+  auto feed = [&](size_t to) {
+    for (size_t p = s0; p < to;) { const size_t k = std::min<size_t>(to - p, (size_t)1 << 30); g->run_crc = (uint32_t)crc32(g->run_crc, (const unsigned char*)c.data() + p, (unsigned)k); p += k; }
+    g->run_len += to - s0; s0 = to;
+  };
+  for (const GzFast::End& e : ends) {
+    feed(e.off);
+    if (g->run_crc != e.crc || (uint32_t)g->run_len != e.isize) return false;
+    g->run_crc = (uint32_t)crc32(0L, Z_NULL, 0); g->run_len = 0;
+  }
+  feed(c.size());
+  return true;
+}
+long gzfast_read(GzFast* g, char* dst, size_t room) {
+  if (!g->started) { g->started = true; g->win.resize(GzFast::W + GzFast::CHUNK + 1024); g->th = std::thread(gzfast_thread, g); }
+  std::unique_lock<std::mutex> lk(g->mu);
+  g->cv.wait(lk, [g] { return g->full[g->cons] || g->done; });
+  if (!g->full[g->cons]) return g->bad ? -1 : 0;
+  lk.unlock();
+  std::vector<char>& c = g->ready[g->cons];
+  if (g->cpos == 0 && !gzfast_verify(g, c, g->ends[g->cons])) { g->bad = true; return -1; }      // (before a byte of the chunk is handed out)
+  const size_t k = std::min(room, c.size() - g->cpos);
+  memcpy(dst, c.data() + g->cpos, k); g->cpos += k;
+  if (g->cpos == c.size()) { lk.lock(); g->full[g->cons] = false; g->cons ^= 1; g->cpos = 0; g->cv.notify_all(); }
+  return (long)k;
+}
+void gzfast_close(GzFast* g) {
+  if (g->started) { { std::lock_guard<std::mutex> lk(g->mu); g->stop = true; } g->cv.notify_all(); g->th.join(); }
+  if (g->map) munmap((void*)g->map, g->size);
+  if (g->fd >= 0) close(g->fd);
+  delete g;
 }
 
 // next stretch of the file: up to `max_members` members read, located by their headers, inflated by b->threads threads
@@ -258,10 +375,11 @@ bool refill(c3_reader* r) {
   if (r->end == r->buf.size()) r->buf.resize(r->buf.size() * 2);
   size_t room = r->buf.size() - r->end;
   long got = r->bz ? bgzf_read(r->bz, r->buf.data() + r->end, room)
+           : r->gzf ? gzfast_read(r->gzf, r->buf.data() + r->end, room)
            : r->gz ? (long)gzread(r->gz, r->buf.data() + r->end, (unsigned)std::min<size_t>(room, 1u << 30))
                    : (long)fread(r->buf.data() + r->end, 1, room, r->fp);
   if (got < 0 && r->bz) r->err = "BGZF input: a member is damaged (size, inflate or CRC)";
-  if (got < 0 && !r->bz && r->gz) r->gz_bad = true;                  // (reported by c3_reader_next: never a silently shorter file)
+  if (got < 0 && !r->bz && (r->gz || r->gzf)) r->gz_bad = true;                  // (reported by c3_reader_next: never a silently shorter file)
   if (got <= 0) { r->eof = true; return false; }
   r->end += (size_t)got;
   return true;
@@ -335,11 +453,25 @@ extern "C" int c3_reader_open(const char* path, int n_sets, c3_reader** out) {
       r->bz->threads = e ? std::max(1, atoi(e)) : std::min(8, host_cores());
     } else {
       if (f) fclose(f);
-      r->gz = gzopen(path, "rb"); if (r->gz) gzbuffer(r->gz, 1 << 20);
+      // any other gzip file: the own decoder over the mapped file (C3_GZ_ZLIB: zlib's gzread, one stream at ~275 MB/s)
+      // (a file that is not gzip at all despite its name stays with gzread, which passes such files through)
+      if (!getenv("C3_GZ_ZLIB") && got >= 3 && hd[0] == 0x1f && hd[1] == 0x8b && hd[2] == 8) {
+        const int fd = open(path, O_RDONLY);
+        struct stat sb;
+        if (fd >= 0 && fstat(fd, &sb) == 0 && sb.st_size >= 18) {
+          void* mp = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+          if (mp != MAP_FAILED) {
+            (void)madvise(mp, (size_t)sb.st_size, MADV_SEQUENTIAL);
+            r->gzf = new GzFast(); r->gzf->fd = fd; r->gzf->map = (const uint8_t*)mp; r->gzf->size = (size_t)sb.st_size;
+          }
+        }
+        if (!r->gzf && fd >= 0) close(fd);
+      }
+      if (!r->gzf) { r->gz = gzopen(path, "rb"); if (r->gz) gzbuffer(r->gz, 1 << 20); }
     }
   }
   else r->fp = fopen(path, "rb");
-  if (!r->gz && !r->fp && !r->bz) { delete r; return C3_E_ARG; }
+  if (!r->gz && !r->fp && !r->bz && !r->gzf) { delete r; return C3_E_ARG; }
   { FILE* f = fopen(path, "rb"); if (f) { fseek(f, 0, SEEK_END); long z = ftell(f); r->file_bytes = z > 0 ? (size_t)z : 0; fclose(f); } }
   r->buf.resize((size_t)16 << 20);
   r->sets.resize((size_t)std::max(1, n_sets));
@@ -421,9 +553,31 @@ extern "C" int c3_reader_open_range(const char* path, int n_sets, int64_t beg, i
   }
 }
 
+// test hook (tests/test_inflate.py): raw DEFLATE stream `in` decoded by the own decoder into out[0..cap), through a window of `chunk`
+// bytes with 32 KiB of history in front of it -- the way gzfast_chunk drives it (chunk = 0: in one piece, the way bgzf_inflate does).
+// Returns the size, -1 on an error, -2 when cap is too small.
+extern "C" long c3_debug_inflate(const unsigned char* in, size_t n, unsigned char* out, size_t cap, size_t chunk) {
+  static thread_local c3inf::Inflater inf;
+  inf.reset(in, in + n);
+  if (chunk == 0) { size_t pos = 0; const int rc = inf.run(out, &pos, cap + 1, cap, 0); return rc == 1 ? (long)pos : (rc == 0 ? -2 : -1); }
+  const size_t W = 32768;
+  std::vector<uint8_t> win(W + chunk + 1024);
+  size_t total = 0, hist = 0;
+  for (;;) {
+    uint8_t* base = win.data() + W; size_t pos = 0;
+    const int rc = inf.run(base, &pos, chunk, chunk + 512, hist);
+    if (rc < 0) return -1;
+    if (total + pos > cap) return -2;
+    memcpy(out + total, base, pos); total += pos;
+    if (pos >= W) { memcpy(win.data(), base + pos - W, W); hist = W; } else { memmove(win.data(), win.data() + pos, W); hist = std::min(W, hist + pos); }
+    if (rc == 1) return (long)total;
+  }
+}
+
 extern "C" void c3_reader_close(c3_reader* r) {
   if (!r) return;
   if (r->gz) gzclose(r->gz);
+  if (r->gzf) gzfast_close(r->gzf);
   if (r->fp) fclose(r->fp);
   if (r->bz) { if (r->bz->pre_on) r->bz->pre.join(); if (r->bz->fp) fclose(r->bz->fp); delete r->bz; }
   delete r;
@@ -467,7 +621,7 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
   if (!r->names_only && r->hint_bases) {
     // later sets are allocated once, with the size the previous groups needed (growth by copying only for the first)
     size_t want = r->hint_bases + r->hint_bases / 8 + 4096;
-    if (!r->gz && !r->bz && r->file_bytes) {       // ... but never more than this reader can still deliver (a set taken for the tail of a range)
+    if (!r->gz && !r->gzf && !r->bz && r->file_bytes) {       // ... but never more than this reader can still deliver (a set taken for the tail of a range)
       const int64_t stop = r->range_end >= 0 ? std::min<int64_t>(r->range_end + 65536, (int64_t)r->file_bytes) : (int64_t)r->file_bytes;
       const int64_t here = r->buf_off + (int64_t)r->beg;
       want = std::min(want, (size_t)std::max<int64_t>(0, stop - here) / 2 + 65536);
@@ -522,11 +676,11 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
       // file / byte range (the other half are qualities), and only as many buffer sets as those bytes can fill are page-locked
       // now (a 100-read input used to pin ten buffers of max_reads reads each)
       size_t deliver = (size_t)-1;
-      if (!r->gz && !r->bz && r->file_bytes) {
+      if (!r->gz && !r->gzf && !r->bz && r->file_bytes) {
         const int64_t stop = r->range_end >= 0 ? std::min<int64_t>(r->range_end + (int64_t)(4 * sl + 4096), (int64_t)r->file_bytes) : (int64_t)r->file_bytes;
         const int64_t here = r->buf_off + (int64_t)r->beg;
         deliver = (size_t)std::max<int64_t>(0, stop - here) / 2 + sb + sl + 4096;
-      } else if ((r->gz || r->bz) && r->file_bytes) deliver = r->file_bytes * 16 + sb + sl + 4096;        // (compressed size: a generous bound)
+      } else if ((r->gz || r->gzf || r->bz) && r->file_bytes) deliver = r->file_bytes * 16 + sb + sl + 4096;        // (compressed size: a generous bound)
       want = std::min(want, std::max(deliver, sb + sl + 4096));
       // Page-locking costs ~0.15 s per GB and as much again to undo, i.e. about what THREE copies of the buffer from pageable memory lose
       // against DMA: it pays when a buffer set is refilled several times, not when the whole input of this reader passes through its sets

@@ -1,0 +1,139 @@
+"""The reader's own DEFLATE decoder (c3poa_amd/csrc/c3_inflate.hpp) against zlib: every block type, every level / strategy / window size,
+history across chunk borders, damaged streams.  CPU only (the decoder is host code; the library loads without a GPU)."""
+import ctypes as C
+import gzip
+import os
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+from c3poa_amd import _lib
+
+
+def _read_all(path):
+    rd = _lib.Reader(path, n_sets=2)
+    out = []
+    while True:
+        hb = rd.next(700)
+        if hb.n == 0:
+            break
+        out += [hb.read(i) for i in range(hb.n)]
+    rd.close()
+    return out
+
+
+def _inflate(raw, size, chunk):
+    lib = _lib.load()
+    lib.c3_debug_inflate.restype = C.c_long
+    lib.c3_debug_inflate.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t]
+    out = C.create_string_buffer(size + 1)
+    n = lib.c3_debug_inflate(raw, len(raw), out, size, chunk)
+    return n, out.raw[:max(n, 0)]
+
+
+def _deflate(data, level, strategy=zlib.Z_DEFAULT_STRATEGY, wbits=15, flush_every=0):
+    co = zlib.compressobj(level, zlib.DEFLATED, -wbits, 9, strategy)
+    if not flush_every:
+        return co.compress(data) + co.flush()
+    out = b""
+    for i in range(0, len(data), flush_every):          # sync / full flushes: empty stored blocks, byte alignment in mid-stream
+        out += co.compress(data[i:i + flush_every]) + co.flush(zlib.Z_FULL_FLUSH if (i // flush_every) % 2 else zlib.Z_SYNC_FLUSH)
+    return out + co.flush()
+
+
+def _payloads(seed):
+    rng = random.Random(seed)
+    nprng = np.random.default_rng(seed)
+    fq = []
+    for i in range(400):
+        n = rng.randint(50, 3000)
+        seq = "".join(rng.choice("ACGT") for _ in range(n))
+        if i % 7 == 0:
+            seq = seq[:n // 3] + "A" * (n // 3) + "AT" * (n // 6)                       # homopolymers, short periods (distance 1 / 2 matches)
+        q = "".join(chr(rng.randint(33, 73)) for _ in range(len(seq))) if i % 3 else "I" * len(seq)
+        fq.append("@read%d\n%s\n+\n%s\n" % (i, seq, q))
+    yield ("".join(fq)).encode()
+    yield bytes(nprng.integers(0, 256, 300000, dtype=np.uint8))                          # incompressible: stored blocks / literals only
+    yield bytes(nprng.integers(0, 4, 200000, dtype=np.uint8))                            # tiny alphabet: long codes on rare symbols
+    yield b"\x00" * 100000 + b"abc" * 30000 + bytes(range(256)) * 50                     # runs, period 3, all byte values
+    yield b""                                                                            # an empty stream
+    yield b"x"
+    # far matches: a block repeated at the maximum distance
+    blk = bytes(nprng.integers(0, 256, 32768, dtype=np.uint8))
+    yield blk + blk + blk[:5000]
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_every_kind_of_stream_matches_zlib(seed):
+    n_cases = 0
+    for data in _payloads(seed):
+        for level, strategy, wbits, fe in [(0, zlib.Z_DEFAULT_STRATEGY, 15, 0), (1, zlib.Z_DEFAULT_STRATEGY, 15, 0), (6, zlib.Z_DEFAULT_STRATEGY, 15, 0),
+                                           (9, zlib.Z_DEFAULT_STRATEGY, 15, 0), (6, zlib.Z_FIXED, 15, 0), (6, zlib.Z_HUFFMAN_ONLY, 15, 0), (6, zlib.Z_RLE, 15, 0),
+                                           (6, zlib.Z_FILTERED, 12, 0), (9, zlib.Z_DEFAULT_STRATEGY, 9, 0), (5, zlib.Z_DEFAULT_STRATEGY, 15, 7001)]:
+            raw = _deflate(data, level, strategy, wbits, fe)
+            for chunk in (0, 1 << 16, 40000, 1 << 20):
+                n, got = _inflate(raw, len(data), chunk)
+                assert n == len(data) and got == data, (len(data), level, strategy, wbits, fe, chunk, n)
+                n_cases += 1
+    assert n_cases > 200
+
+
+def test_damaged_streams_are_errors_or_caught_by_the_length():
+    rng = random.Random(5)
+    data = ("".join("@r%d\n%s\n+\n%s\n" % (i, "".join(rng.choice("ACGT") for _ in range(500)), "5" * 500) for i in range(200))).encode()
+    raw = _deflate(data, 6)
+    bad = 0
+    for k in range(300):
+        b = bytearray(raw)
+        pos = rng.randrange(len(b)); b[pos] ^= 1 << rng.randrange(8)
+        n, got = _inflate(bytes(b), len(data) + 70000, 1 << 16)
+        # a flipped bit either breaks the stream (an error), changes its length, or changes bytes (the reader's CRC-32 check catches those)
+        if n < 0 or got != data:
+            bad += 1
+    assert bad >= 295
+    # truncation is always an error
+    for cut in (1, 2, 10, len(raw) // 2, len(raw) - 1):
+        n, _ = _inflate(raw[:cut], len(data), 0)
+        assert n < 0
+
+
+def test_gz_files_of_every_layout_through_the_reader(tmp_path):
+    """plain gzip files (one member, several members, header fields, trailing zeros) read by c3_reader with the own decoder"""
+    rng = random.Random(11)
+    recs = [("r%d" % i, "".join(rng.choice("ACGT") for _ in range(rng.randint(100, 4000))), None) for i in range(1500)]
+    recs = [(n, s, "".join(chr(rng.randint(40, 70)) for _ in s)) for n, s, _ in recs]
+    text = "".join("@%s\n%s\n+\n%s\n" % r for r in recs).encode()
+    third = len(text) // 3
+    cut1 = text.rfind(b"\n@", 0, third) + 1; cut2 = text.rfind(b"\n@", 0, 2 * third) + 1
+    layouts = {
+        "one.gz": gzip.compress(text, 6),
+        "three.gz": gzip.compress(text[:cut1], 1) + gzip.compress(text[cut1:cut2], 9) + gzip.compress(text[cut2:], 0),
+        "pad.gz": gzip.compress(text, 4) + b"\0" * 512,
+    }
+    import io
+    buf = io.BytesIO()
+    with gzip.GzipFile(filename="reads_with_a_name.fastq", mode="wb", fileobj=buf, compresslevel=7) as g:
+        g.write(text)
+    layouts["named.gz"] = buf.getvalue()
+    for name, blob in layouts.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        assert _read_all(str(p)) == recs, name
+    # a member whose CRC is wrong
+    blob = bytearray(layouts["one.gz"]); blob[-6] ^= 0x40
+    p = tmp_path / "crc.gz"; p.write_bytes(bytes(blob))
+    with pytest.raises(ValueError):
+        _read_all(str(p))
+
+
+def test_a_text_file_named_gz_and_an_empty_gz(tmp_path):
+    """gzread passes a file through that is not gzip at all: that behaviour stays; an empty gzip member is an empty input"""
+    recs = [("a", "ACGTACGT", "IIIIIIII"), ("b", "TTTT", "5555")]
+    p = tmp_path / "plain.fastq.gz"
+    p.write_text("".join("@%s\n%s\n+\n%s\n" % r for r in recs))
+    assert _read_all(str(p)) == recs
+    p2 = tmp_path / "empty.fastq.gz"
+    p2.write_bytes(gzip.compress(b""))
+    assert _read_all(str(p2)) == []
