@@ -93,6 +93,23 @@ struct Inflater {
     }
     return true;
   }
+  // TWO LITERALS PER LOOKUP: where a first-level index holds a literal of L1 bits and its remaining 11 - L1 bits decide a second
+  // literal of L2 <= 11 - L1 bits, the entry becomes both (value = first | second << 8, extra field = 1, length = L1 + L2).  FASTQ
+  // deflates to literals for the most part (quality strings: 5-7 bit codes), and Huffman decoding is one dependent lookup per
+  // symbol: pairs halve that chain.
+  static void pair_literals(uint32_t* tab) {
+    uint32_t one[1 << LIT_BITS];
+    memcpy(one, tab, sizeof(one));
+    for (unsigned i = 0; i < (1u << LIT_BITS); ++i) {
+      const uint32_t e = one[i];
+      if ((e & (K_MASK | K_VALID)) != (K_LIT | K_VALID)) continue;
+      const unsigned l1 = e_len(e);
+      if (l1 >= (unsigned)LIT_BITS) continue;
+      const uint32_t e2 = one[i >> l1];
+      if ((e2 & (K_MASK | K_VALID)) != (K_LIT | K_VALID) || l1 + e_len(e2) > (unsigned)LIT_BITS) continue;
+      tab[i] = mk(K_LIT, e_val(e) | (e_val(e2) << 8), 1, l1 + e_len(e2));
+    }
+  }
   static uint32_t lit_entry(int sym, int len) {
     static const uint16_t lbase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
     static const uint8_t lext[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
@@ -135,6 +152,7 @@ struct Inflater {
         uint8_t l[288]; for (int i = 0; i < 144; ++i) l[i] = 8; for (int i = 144; i < 256; ++i) l[i] = 9; for (int i = 256; i < 280; ++i) l[i] = 7; for (int i = 280; i < 288; ++i) l[i] = 8;
         uint8_t d[32]; for (int i = 0; i < 32; ++i) d[i] = 5;
         if (!build(l, 288, fixed_lit, LIT_BITS, LIT_TABLE, lit_entry) || !build(d, 32, fixed_dist, DIST_BITS, DIST_TABLE, dist_entry)) return false;
+        pair_literals(fixed_lit);
         fixed_built = true;
       }
       memcpy(lit, fixed_lit, sizeof(lit)); memcpy(dist, fixed_dist, sizeof(dist));
@@ -166,7 +184,9 @@ struct Inflater {
       while (rep--) lens[i++] = (uint8_t)val;
     }
     if (lens[256] == 0) return false;                                // no end-of-block code
-    return build(lens, (int)hlit, lit, LIT_BITS, LIT_TABLE, lit_entry) && build(lens + hlit, (int)hdist, dist, DIST_BITS, DIST_TABLE, dist_entry);
+    if (!build(lens, (int)hlit, lit, LIT_BITS, LIT_TABLE, lit_entry) || !build(lens + hlit, (int)hdist, dist, DIST_BITS, DIST_TABLE, dist_entry)) return false;
+    pair_literals(lit);
+    return true;
   }
 
   // Decode into out[pos ..): stops BETWEEN symbols as soon as pos >= soft (the caller's chunk is full), at the end of the stream, or on an
@@ -205,18 +225,16 @@ struct Inflater {
           while (in <= in_fast && pos < out_fast) {
             refill_fast();
             uint32_t e = lit[bitbuf & LM];
+            // up to three lookups of literals (one or two bytes each, at most 11 bits each) out of one refill
+#define C3INF_LIT() { bitbuf >>= e_len(e); bitcnt -= e_len(e); const uint32_t v_ = e_val(e), two_ = e_extra(e); out[pos] = (uint8_t)v_; out[pos + 1] = (uint8_t)(v_ >> 8); pos += 1 + two_; e = lit[bitbuf & LM]; }
             if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) {
-              bitbuf >>= e_len(e); bitcnt -= e_len(e); out[pos++] = (uint8_t)e_val(e);
-              e = lit[bitbuf & LM];
+              C3INF_LIT()
               if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) {
-                bitbuf >>= e_len(e); bitcnt -= e_len(e); out[pos++] = (uint8_t)e_val(e);
-                e = lit[bitbuf & LM];
-                if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) {
-                  bitbuf >>= e_len(e); bitcnt -= e_len(e); out[pos++] = (uint8_t)e_val(e);
-                  e = lit[bitbuf & LM];
-                }
+                C3INF_LIT()
+                if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) C3INF_LIT()
               }
             }
+#undef C3INF_LIT
             // e: the next symbol, looked up with >= 23 valid bits left
             if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) continue;                 // (a fourth literal: after the next refill)
             if ((e & (K_MASK | K_VALID)) != (K_LEN | K_VALID)) break;                    // second-level code, end of block, damaged: the careful loop
@@ -251,13 +269,10 @@ struct Inflater {
         bitbuf >>= e_len(e); bitcnt -= e_len(e);
         const uint32_t kind = e & K_MASK;
         if (kind == K_LIT) {
-          if (pos >= cap) { *pos_io = pos; return -1; }
+          const unsigned nl = 1 + e_extra(e);                        // one literal, or a pair
+          if (nl > cap - pos) { *pos_io = pos; return -1; }
           out[pos++] = (uint8_t)e_val(e);
-          // a second literal out of the same refill (the common case in text)
-          if (fast) {
-            uint32_t e2 = lit[bitbuf & ((1u << LIT_BITS) - 1)];
-            if ((e2 & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) { bitbuf >>= e_len(e2); bitcnt -= e_len(e2); out[pos++] = (uint8_t)e_val(e2); }
-          }
+          if (nl == 2) out[pos++] = (uint8_t)(e_val(e) >> 8);
           continue;
         }
         if (kind == K_EOB) { in_block = false; if (final_block) stream_end = true; break; }
