@@ -108,7 +108,7 @@ struct BatchSet {
 // BGZF input (bgzip / htslib): a gzip file made of independent members of <= 64 KiB whose header carries the member's size
 // (extra subfield 'B','C'), so the members of a stretch of the file can be located WITHOUT inflating them and inflated by several
 // threads at once -- a plain gzip stream is one zlib state and inflates at ~275 MB/s whatever the machine (27 k reads/s:
-// profiles/r04_host_ceiling_gz.txt).  Plain gzip stays on gzread.
+// profiles/r04_host_ceiling_gz.txt).  Plain gzip: one stream, inflated by the own decoder on a thread beside the parser (GzFast below).
 struct BgzfStretch {
   std::vector<unsigned char> comp;          // compressed members of the stretch, back to back
   std::vector<size_t> coff, csz, doff;      // per member: offset / size in comp, offset of its data in dec
