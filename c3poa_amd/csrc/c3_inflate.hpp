@@ -1,12 +1,12 @@
 // c3_inflate.hpp -- a DEFLATE (RFC 1951) decoder for the reader of c3_io.cpp (host only, no GPU code).
 //
 // Why not zlib's: the input side of the command line (C3POa.py:201,239 reads `.gz` through Python's gzip) is one zlib stream per
-// plain gzip file, and zlib inflates FASTQ at ~275 MB/s whatever the machine -- 27 k reads/s, a fifteenth of one GPU
-// (profiles/r04_host_ceiling_gz.txt).  This decoder is written for exactly this job: the WHOLE compressed input is in memory
+// plain gzip file, and zlib inflates FASTQ at ~300 MB/s whatever the machine -- 27-31 k reads/s, a fifteenth of one GPU
+// (profiles/r04_host_ceiling_gz.txt, profiles/r05_inflate_bench_gpu_box_host.txt: 30.8 -> 49.8 k reads/s with this decoder).  This decoder is written for exactly this job: the WHOLE compressed input is in memory
 // (the file is mapped), so there is no input-starvation state; it stops only BETWEEN symbols (when the caller's output chunk is
 // full), so the resumable state is the bit buffer, the input position and the current block's tables; literals and matches are
-// decoded from an 11-bit first-level table with a 64-bit bit buffer that is refilled once per symbol pair, matches are copied
-// eight bytes at a time.  Every member's CRC-32 and length are checked by the caller (zlib's crc32): a decoding error cannot
+// decoded from an 11-bit first-level table (two literals per entry where both codes fit) with a 64-bit bit buffer that is refilled
+// once per three lookups, matches are copied eight bytes at a time.  Every member's CRC-32 and length are checked by the caller (zlib's crc32): a decoding error cannot
 // pass silently.  The algorithm is the published one (RFC 1951 3.2; table-driven canonical Huffman decoding as in every fast
 // inflater); the code is this repository's own.
 #pragma once
@@ -16,8 +16,8 @@
 
 namespace c3inf {
 
-// table entries (32 bits):  bits 0-7 code length (bits to drop for the code itself), bits 8-15 extra-bit count / sub-table bits,
-// bits 16-30 literal byte / length base / distance base / sub-table offset, and the kind in the low flags of byte 3's top bit + kind field
+// table entries (32 bits):  bits 0-7 code length (bits to drop for the code itself), bits 8-12 extra-bit count / sub-table bits / 1 = "two
+// literals", bits 13-28 literal byte(s) / length base / distance base / sub-table offset, bits 29-30 the kind, bit 31 = the entry exists
 enum : uint32_t { K_LIT = 0u << 29, K_LEN = 1u << 29, K_EOB = 2u << 29, K_SUB = 3u << 29, K_MASK = 3u << 29, K_VALID = 1u << 31 };
 static inline uint32_t mk(uint32_t kind, uint32_t val, uint32_t extra, uint32_t len) { return K_VALID | kind | (val << 8 << 5) | (extra << 8) | len; }
 static inline uint32_t e_len(uint32_t e) { return e & 0xffu; }
@@ -25,7 +25,10 @@ static inline uint32_t e_extra(uint32_t e) { return (e >> 8) & 0x1fu; }
 static inline uint32_t e_val(uint32_t e) { return (e >> 13) & 0xffffu; }
 
 const int LIT_BITS = 11, DIST_BITS = 8;
-const int LIT_TABLE = (1 << LIT_BITS) + 1024, DIST_TABLE = (1 << DIST_BITS) + 512;     // first level + room for the second-level tables
+// first level + room for the second-level tables.  Enough for every complete code: a prefix whose longest code is sb bits beyond the first
+// level holds at least sb + 1 codes, so the second level is at most 57 x 16 = 912 entries for the 286 literal / length codes (sb <= 4) and
+// 3 x 128 + 32 = 416 for the 30 distance codes (sb <= 7)
+const int LIT_TABLE = (1 << LIT_BITS) + 1024, DIST_TABLE = (1 << DIST_BITS) + 512;
 
 struct Inflater {
   const uint8_t* in = nullptr; const uint8_t* in_end = nullptr;
