@@ -137,3 +137,22 @@ def test_a_text_file_named_gz_and_an_empty_gz(tmp_path):
     p2 = tmp_path / "empty.fastq.gz"
     p2.write_bytes(gzip.compress(b""))
     assert _read_all(str(p2)) == []
+
+
+def test_the_deepest_huffman_trees():
+    """Fibonacci-like symbol frequencies force 12- to 15-bit codes: the second-level tables"""
+    rng = random.Random(3)
+    fib = [1, 1]
+    while len(fib) < 32:
+        fib.append(fib[-1] + fib[-2])
+    for nsym in (20, 26, 31):
+        syms = []
+        for i in range(nsym):
+            syms += [i * 5 + 3] * min(fib[i], 60000)
+        rng.shuffle(syms)
+        data = bytes(syms)
+        for strategy in (zlib.Z_HUFFMAN_ONLY, zlib.Z_DEFAULT_STRATEGY):
+            raw = _deflate(data, 9, strategy)
+            for chunk in (0, 50000):
+                n, got = _inflate(raw, len(data), chunk)
+                assert n == len(data) and got == data, (nsym, strategy, chunk, n)
