@@ -19,7 +19,7 @@ EXPORTS = ["c3_default_config", "c3_version", "c3_device_count", "c3_warm_device
            "c3_batch_upload", "c3_batch_stage", "c3_batch_commit", "c3_batch_assign", "c3_batch_run", "c3_batch_sync", "c3_batch_results", "c3_batch_results_snapshot", "c3_batch_results_fetch", "c3_batch_timing",
            "c3_fetch_track", "c3_fetch_smoothed", "c3_fetch_raw_peaks", "c3_fetch_draft", "c3_fetch_msa2",
            "c3_call_peaks", "c3_poa_msa", "c3_pairwise_consensus", "c3_determine_consensus", "c3_zero_repeats", "c3_scan_splints",
-           "c3_reader_open", "c3_reader_open_range", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_reader_next_set", "c3_reader_noqual", "c3_reader_reserved_bytes", "c3_reader_range_lost", "c3_write_group",
+           "c3_reader_open", "c3_reader_open_range", "c3_reader_close", "c3_reader_error", "c3_reader_names_only", "c3_reader_next", "c3_reader_next_set", "c3_reader_noqual", "c3_reader_reserved_bytes", "c3_reader_range_lost", "c3_bgzf_size", "c3_write_group",
            "c3_scan_adapters", "c3_match_index", "c3_match_index_batch",
            "c3_assign_open", "c3_assign_close", "c3_assign_batch", "c3_assign_seen", "c3_write_splint_psl",
            "c3_host_alloc", "c3_host_free", "c3_writer_reset", "c3_compress_file"]
@@ -128,6 +128,7 @@ def load():
     for fn in (lib.c3_reader_noqual, lib.c3_reader_reserved_bytes):
         fn.argtypes = [vp]; fn.restype = C.c_int64
     lib.c3_reader_range_lost.argtypes = [vp]
+    lib.c3_bgzf_size.argtypes = [C.c_char_p]; lib.c3_bgzf_size.restype = C.c_int64
     lib.c3_reader_next.argtypes = [vp, C.c_int, C.c_int64, C.c_int, C.POINTER(HostBatchStruct)]
     lib.c3_reader_next_set.argtypes = [vp, C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(HostBatchStruct)]
     lib.c3_write_group.argtypes = [C.POINTER(HostBatchStruct), vp, vp, vp, vp, C.c_int, C.POINTER(cp), C.POINTER(cp), C.c_int]
@@ -640,6 +641,12 @@ class Reader:
             self.close()
         except Exception:
             pass
+
+
+def bgzf_size(path):
+    """c3_bgzf_size: inflated size of a BGZF (bgzip) file, -1 when it is not BGZF from end to end -- the length that byte ranges of a
+    Reader(..., byte_range=) over such a file are cut from"""
+    return int(load().c3_bgzf_size(_b(str(path))))
 
 
 def write_splint_psl(hb, table, splint_id, strand, splint_names, splint_lens, match, path):

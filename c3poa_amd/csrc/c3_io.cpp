@@ -123,6 +123,9 @@ struct Bgzf {
   size_t dpos = 0;                          // unread part of st[cur].dec starts here
   std::thread pre; bool pre_on = false, pre_ok = false;
   std::atomic<bool> eof{false}, bad{false};  // (written by the prefetch thread, read by the parser)
+  size_t skip = 0;                          // inflated bytes to drop before the first one handed out (a reader that starts inside a member)
+  std::vector<int64_t> icoff, idoff;        // member table, built on demand (range readers): offset in the file / in the inflated stream
+  int64_t itotal = -1;                      // inflated size of the whole file once the table is complete
 };
 
 // plain gzip input read with the own decoder (c3_inflate.hpp): see gzfast_chunk
@@ -354,6 +357,52 @@ bool bgzf_next_stretch(Bgzf* bz, BgzfStretch* b, size_t max_members = 512) {
 
 // bytes of the inflated file, in order.  While the parser works through one stretch the next one is read and inflated on a
 // thread of its own (which fans out to b->threads inflaters): the reader thread only waits when inflating is the slower side
+// Member table of a BGZF file WITHOUT inflating anything: every member's header gives its size, its last four bytes the size of its data.
+// Complete table -> bz->itotal; false when a member is not BGZF (or the file is cut short).
+bool bgzf_index(Bgzf* bz) {
+  if (bz->itotal >= 0) return true;
+  const int fd = fileno(bz->fp);
+  struct stat sb; if (fstat(fd, &sb) != 0) return false;
+  const int64_t fsz = (int64_t)sb.st_size;
+  bz->icoff.clear(); bz->idoff.clear();
+  int64_t off = 0, d = 0;
+  std::vector<unsigned char> hd(12 + 65536);
+  while (off < fsz) {
+    ssize_t got = pread(fd, hd.data(), 18, (off_t)off);
+    if (got < 18) return false;
+    size_t msz = bgzf_member_size(hd.data(), 18);
+    if (!msz) {                                                       // (the BC subfield is not the first one)
+      const size_t xlen = (size_t)hd[10] | ((size_t)hd[11] << 8);
+      if (hd[0] != 0x1f || hd[1] != 0x8b || !(hd[3] & 4)) return false;
+      got = pread(fd, hd.data(), 12 + xlen, (off_t)off);
+      if (got < (ssize_t)(12 + xlen)) return false;
+      msz = bgzf_member_size(hd.data(), 12 + xlen);
+      if (!msz) return false;
+    }
+    if (msz < 26 || off + (int64_t)msz > fsz) return false;
+    unsigned char t[4];
+    if (pread(fd, t, 4, (off_t)(off + (int64_t)msz - 4)) != 4) return false;
+    const int64_t isz = (int64_t)t[0] | ((int64_t)t[1] << 8) | ((int64_t)t[2] << 16) | ((int64_t)t[3] << 24);
+    if (isz > 65536) return false;
+    bz->icoff.push_back(off); bz->idoff.push_back(d);
+    d += isz; off += (int64_t)msz;
+  }
+  bz->itotal = d;
+  return true;
+}
+// continue at byte `doff` of the inflated stream: the member that holds it is inflated again from its start, the bytes before are dropped
+bool bgzf_seek(Bgzf* bz, int64_t doff) {
+  if (!bgzf_index(bz)) return false;
+  if (bz->pre_on) { bz->pre.join(); bz->pre_on = false; }
+  bz->st[0].dend = bz->st[1].dend = 0; bz->cur = 0; bz->dpos = 0; bz->eof = false; bz->bad = false;
+  if (doff >= bz->itotal) { bz->eof = true; bz->skip = 0; return fseek(bz->fp, 0, SEEK_END) == 0; }
+  // last member whose data starts at or before doff
+  size_t lo = 0, hi = bz->idoff.size();
+  while (hi - lo > 1) { const size_t m = (lo + hi) / 2; if (bz->idoff[m] <= doff) lo = m; else hi = m; }
+  bz->skip = (size_t)(doff - bz->idoff[lo]);
+  return fseeko(bz->fp, (off_t)bz->icoff[lo], SEEK_SET) == 0;
+}
+
 long bgzf_read(Bgzf* b, char* dst, size_t room) {
   if (b->dpos == b->st[b->cur].dend) {
     if (b->pre_on) { b->pre.join(); b->pre_on = false; if (b->pre_ok) { b->cur ^= 1; b->dpos = 0; } else b->st[b->cur].dend = b->dpos = 0; }
@@ -363,6 +412,11 @@ long bgzf_read(Bgzf* b, char* dst, size_t room) {
     if (!b->eof) { BgzfStretch* nx = &b->st[b->cur ^ 1]; b->pre_on = true; b->pre = std::thread([b, nx]() { b->pre_ok = bgzf_next_stretch(b, nx); }); }
   }
   BgzfStretch& c = b->st[b->cur];
+  if (b->skip) {                                                    // (after bgzf_seek: the part of the first member before the target)
+    const size_t d = std::min(b->skip, c.dend - b->dpos);
+    b->dpos += d; b->skip -= d;
+    if (b->dpos == c.dend) return bgzf_read(b, dst, room);
+  }
   const size_t k = std::min(room, c.dend - b->dpos);
   memcpy(dst, c.dec.data() + b->dpos, k);
   b->dpos += k;
@@ -512,11 +566,58 @@ int record_starts_at(const char* buf, size_t n, size_t p, bool fastq, bool at_eo
 extern "C" int c3_reader_open_range(const char* path, int n_sets, int64_t beg, int64_t end, c3_reader** out) {
   if (!path || !out || beg < 0) return C3_E_ARG;
   size_t n = strlen(path);
-  if (n > 3 && strcmp(path + n - 3, ".gz") == 0) return C3_E_ARG;              // a gzip stream cannot be entered in the middle
+  const bool dotgz = n > 3 && strcmp(path + n - 3, ".gz") == 0;
   int rc = c3_reader_open(path, n_sets, out);
   if (rc != C3_E_OK) return rc;
   c3_reader* r = *out;
+  // a plain gzip stream cannot be entered in the middle; a BGZF file can: its members are located without inflating them, and the
+  // range is given in bytes of the INFLATED file (c3_bgzf_size), so everything below works on one linear coordinate as for plain files
+  if (dotgz && !r->bz) { c3_reader_close(r); *out = nullptr; return C3_E_ARG; }
   r->range_end = end;
+  if (r->bz) {
+    Bgzf* bz = r->bz;
+    if (!bgzf_index(bz)) { c3_reader_close(r); *out = nullptr; return C3_E_ARG; }
+    r->file_bytes = (size_t)bz->itotal;                             // (inflated size: the coordinate of the ranges)
+    if (!getenv("C3_GZ_THREADS")) bz->threads = std::min(bz->threads, 3);      // (one of several readers: three inflating threads keep one parser busy)
+    if (beg == 0) return C3_E_OK;
+    auto read_at = [&](int64_t at, char* dst, size_t want) -> long {  // up to `want` inflated bytes from offset `at`
+      if (!bgzf_seek(bz, at)) return -1;
+      size_t have = 0;
+      while (have < want) { const long g = bgzf_read(bz, dst + have, want - have); if (g < 0) return -1; if (g == 0) break; have += (size_t)g; }
+      return (long)have;
+    };
+    char c0 = 0;
+    if (read_at(0, &c0, 1) < 0) { c3_reader_close(r); *out = nullptr; return C3_E_ARG; }
+    const bool fastq = c0 == '@';
+    std::vector<char> win((size_t)8 << 20);
+    int64_t at = beg - 1;
+    for (;;) {
+      const long g = read_at(at, win.data(), win.size());
+      if (g < 0) { c3_reader_close(r); *out = nullptr; return C3_E_ARG; }
+      const size_t got = (size_t)g;
+      if (got == 0) { r->eof = true; r->buf_off = at; return C3_E_OK; }
+      size_t p = 0; bool found = false, grow = false;
+      while (p < got) {
+        const char* nl = (const char*)memchr(win.data() + p, '\n', got - p);
+        if (!nl) break;
+        p = (size_t)(nl - win.data()) + 1;
+        if (p >= got) break;
+        const int st = record_starts_at(win.data(), got, p, fastq, got < win.size());
+        if (st == 1) { found = true; break; }
+        if (st < 0) { grow = got == win.size(); break; }
+      }
+      if (found) {
+        at += (int64_t)p;
+        if (!bgzf_seek(bz, at)) { c3_reader_close(r); *out = nullptr; return C3_E_ARG; }
+        r->buf_off = at;
+        if (end >= 0 && at >= end) r->eof = true;
+        return C3_E_OK;
+      }
+      if (grow && win.size() < ((size_t)1 << 30)) { win.resize(win.size() * 4); continue; }
+      if (got < win.size()) { r->eof = true; r->buf_off = at; r->range_lost = beg < bz->itotal - 1 && got > 1; return C3_E_OK; }
+      at += (int64_t)got - 1;
+    }
+  }
   if (beg == 0) return C3_E_OK;
   int c0 = fgetc(r->fp);
   const bool fastq = c0 == '@';
@@ -602,6 +703,19 @@ extern "C" int64_t c3_reader_reserved_bytes(const c3_reader* r) {
 // 1 when c3_reader_open_range found bytes but no record start in its range (multi-line FASTQ cannot be entered in the middle):
 // the records of that range would be lost, so the caller has to read the file with ONE reader instead
 extern "C" int c3_reader_range_lost(const c3_reader* r) { return r && r->range_lost ? 1 : 0; }
+// Inflated size of a BGZF file (every member located by its header, none inflated), -1 when the file is not BGZF from end to end: the
+// caller cuts [0, size) into ranges for c3_reader_open_range, as it cuts a plain file by its byte size
+extern "C" int64_t c3_bgzf_size(const char* path) {
+  if (!path) return -1;
+  FILE* f = fopen(path, "rb");
+  if (!f) return -1;
+  unsigned char hd[18];
+  if (fread(hd, 1, 18, f) != 18 || !bgzf_member_size(hd, 18)) { fclose(f); return -1; }
+  Bgzf bz; bz.fp = f;
+  const bool ok = bgzf_index(&bz);
+  fclose(f);
+  return ok ? bz.itotal : -1;
+}
 
 // One group of reads.  Records shorter than min_len are skipped and counted in out->n_short (C3POa.py:202-204,240-241).
 // Stops after max_reads kept reads or once max_bases kept bases are exceeded (0 = no limit).  out->n == 0 at end of file.

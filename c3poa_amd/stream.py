@@ -100,6 +100,12 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
     # round-robin order of the ranges, and the file order itself with a single range).
     size = os.path.getsize(args.reads)
     splittable = not str(args.reads).endswith(".gz") and size > 0
+    if str(args.reads).endswith(".gz") and not os.environ.get("C3_NO_BGZF"):
+        # BGZF (bgzip) input: members are located by their headers, so the INFLATED file is cut into ranges like a plain one
+        # (a plain gzip stream cannot be entered in the middle: one reader, one inflating thread beside it)
+        isz = _lib.bgzf_size(args.reads)
+        if isz > 0:
+            size, splittable = isz, True
     per_gpu = max(1, int(os.environ.get("C3_READERS_PER_GPU", READERS_PER_GPU)))
     min_range = int(os.environ.get("C3_MIN_RANGE_BYTES", MIN_RANGE_BYTES))
     n_ranges = max(1, min(n_work * per_gpu, size // max(min_range, 1))) if splittable else 1

@@ -246,6 +246,11 @@ int c3_reader_open(const char* path, int n_sets, c3_reader** out);
  * after beg, ends before the first record starting at or after end (end < 0: end of file), so ranges that tile the file
  * read every record exactly once -- one reader per GPU worker (C3POa.py:236-256 sharded 1000-read groups over a pool) */
 int c3_reader_open_range(const char* path, int n_sets, int64_t beg, int64_t end, c3_reader** out);
+/* BGZF (bgzip) input can be cut into ranges as well -- its members are located by their headers without inflating them: the inflated
+ * size of the file (-1: not BGZF from end to end), and c3_reader_open_range over [beg, end) in bytes of the INFLATED file.  A plain
+ * gzip stream cannot be entered in the middle: c3_reader_open_range refuses it (C3_E_ARG), one c3_reader_open reads it.
+ * (C3POa.py:201,239 read .gz through one Python gzip stream; the read sharding is C3POa.py:236-256) */
+int64_t c3_bgzf_size(const char* path);
 void c3_reader_close(c3_reader* r);
 const char* c3_reader_error(const c3_reader* r);
 /* records without a quality line seen so far (FASTA).  The reference cannot process them (C3POa.py:167 takes ord() of every

@@ -518,3 +518,57 @@ def test_compress_file_is_gzip_for_everybody_and_bgzf_for_this_reader(tmp_path, 
     with pytest.raises(_lib.C3Error):
         _lib.compress_file(src, str(tmp_path / "no_such_dir" / "x.gz"), remove=False)
     assert os.path.exists(src)
+
+
+def test_bgzf_input_in_byte_ranges_equals_one_reader(tmp_path):
+    """a BGZF file cut into ranges of its INFLATED bytes (c3_bgzf_size + c3_reader_open_range): every record exactly once, in order,
+    for cuts at every kind of place (inside records, on member borders, past the end); a plain gzip file refuses ranges"""
+    import gzip
+    import random
+    rng = random.Random(21)
+    recs = [("r%d" % i, "".join(rng.choice("ACGT") for _ in range(rng.randint(30, 9000))), None) for i in range(900)]
+    recs = [(n, s, "".join(chr(rng.randint(35, 73)) for _ in s)) for n, s, _ in recs]
+    fq = str(tmp_path / "a.fastq")
+    with open(fq, "w") as fh:
+        for r in recs:
+            fh.write("@%s\n%s\n+\n%s\n" % r)
+    bg = str(tmp_path / "a_bgzf.fastq.gz")
+    _lib.compress_file(fq, bg, level=3, remove=False)
+    size = _lib.bgzf_size(bg)
+    assert size == os.path.getsize(fq)
+
+    def read_range(path, beg, end):
+        rd = _lib.Reader(path, n_sets=2, byte_range=(beg, end))
+        out = []
+        while True:
+            hb = rd.next(300)
+            if hb.n == 0:
+                break
+            out += [hb.read(i) for i in range(hb.n)]
+        lost = rd.range_lost()
+        rd.close()
+        assert not lost
+        return out
+
+    for n_ranges in (2, 3, 7, 16):
+        cuts = [size * k // n_ranges for k in range(n_ranges)] + [-1]
+        got = []
+        for k in range(n_ranges):
+            got += read_range(bg, cuts[k], cuts[k + 1])
+        assert got == recs, n_ranges
+    # cuts on member borders (65 280 inflated bytes per member) and at random places
+    for trial in range(6):
+        cuts = sorted(set([0] + [rng.choice([65280 * rng.randrange(1, size // 65280), rng.randrange(1, size)]) for _ in range(5)])) + [-1]
+        got = []
+        for k in range(len(cuts) - 1):
+            got += read_range(bg, cuts[k], cuts[k + 1])
+        assert got == recs, cuts
+    assert read_range(bg, size + 5, -1) == []
+    # plain gzip: not BGZF, no ranges
+    gz = str(tmp_path / "plain.fastq.gz")
+    with gzip.open(gz, "wt") as fh:
+        for r in recs[:50]:
+            fh.write("@%s\n%s\n+\n%s\n" % r)
+    assert _lib.bgzf_size(gz) == -1
+    with pytest.raises(OSError):
+        _lib.Reader(gz, byte_range=(100, -1))
