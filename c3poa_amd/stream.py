@@ -100,9 +100,10 @@ def run(args, splint_dict, assigner, adapter_set=None, n_dev=1, stats=None, find
     # round-robin order of the ranges, and the file order itself with a single range).
     size = os.path.getsize(args.reads)
     splittable = not str(args.reads).endswith(".gz") and size > 0
-    if str(args.reads).endswith(".gz") and not os.environ.get("C3_NO_BGZF"):
-        # BGZF (bgzip) input: members are located by their headers, so the INFLATED file is cut into ranges like a plain one
-        # (a plain gzip stream cannot be entered in the middle: one reader, one inflating thread beside it)
+    if str(args.reads).endswith(".gz") and os.environ.get("C3_BGZF_RANGES") and not os.environ.get("C3_NO_BGZF"):
+        # BGZF (bgzip) input CAN be cut into ranges of its inflated bytes like a plain file (c3_bgzf_size, c3_reader_open_range) -- opt-in:
+        # on the 16-core quota of the GPU boxes it does not pay (one reader with eight inflating threads feeds 120-150 k reads/s, the
+        # inflating itself is ~10 core-seconds per million reads; 2 / 4 / 8 ranges: 122 / 110 / 75 k, profiles/r05_host_ceiling_bgzf_ranges.txt)
         isz = _lib.bgzf_size(args.reads)
         if isz > 0:
             size, splittable = isz, True

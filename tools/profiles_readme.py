@@ -38,6 +38,7 @@ NOTES = {   # what each further file of the round is (facts about HOW it was mad
     "cli_3m_tmpfs_final_kernels.log": "`tools/cli_throughput.py 3000000 --dir /dev/shm` at the round's final kernels: 283.6 k reads/s end to end (10.6 s: 7.2 s in the device loop = 415 k reads/s, the rest is the process's fixed cost)",
     "inflate_bench_gpu_box_host.txt": "`tools/inflate_bench.py 200000` on the GPU box's host (CPU only): the native reader over a plain `.gz` FASTQ and the same file in BGZF layout, zlib (`C3_GZ_ZLIB=1`) against the own decoder, alternating: plain gzip 30.8 -> 49.8 k reads/s, BGZF ~150 k either way",
     "cli_500k_gz_own_decoder_ab.log": "`tools/cli_throughput.py 500000 --dir /dev/shm --gz --ab C3_GZ_ZLIB=1`: the command line end to end on a plain `.gz` input, four alternating runs: 27.1 k reads/s with zlib, 36.6 k with the own decoder (13.4 s of which ~2.5 s are the process's fixed cost)",
+    "host_ceiling_bgzf_ranges.txt": "`tools/host_ceiling.py 1000000 --dir /dev/shm --workers 1,2,4 --bgzf` with the BGZF input cut into ranges of its inflated bytes (2 / 4 / 8 ranges): 122 / 110 / 75 k reads/s on the 16-core quota -- no better than one reader with eight inflating threads, so the ranges stay opt-in (`C3_BGZF_RANGES=1`)",
     "pmc_mem_cfg2.txt": "`tools/pmc_mem.sh 32768 cfg2`: TA / TCP / UTCL1 / TCC counters per kernel (one group per pass)",
     "vmem_rates_gfx950.txt": "`tools/ubench/vmem_rates.hip`: CU-cycles per vector memory instruction by shape, 24 / 12 / 4 waves per CU",
     "tmpfs_write_one_file_pwrite_mmap.txt": "`tools/experiments/tmpfs_write_bench.cpp`: one tmpfs file by `pwrite` / `mmap` from 1-16 threads against one file per thread",
