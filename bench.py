@@ -42,7 +42,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 # per-GPU reads per step: BASELINE.json configs (cfg3: 1M reads over 8 GPUs)
-DEFAULT_READS = {"cfg1": 1000, "cfg2": 100000, "cfg3": 125000, "cfg4": 100000, "cfg5": 131072, "cfgL": 50000}
+DEFAULT_READS = {"cfg1": 1000, "cfg2": 100000, "cfg3": 125000, "cfg4": 100000, "cfg5": 131072, "cfgL": 50000, "cfg2e15": 100000, "cfg2e20": 100000}
 WORKLOAD_TEXT = {
     "cfg1": "5 kb, 3x1.5 kb repeats (plumbing case)",
     "cfg2": "5 kb, 3x1.5 kb repeats, Splint1, 10% error",
@@ -50,6 +50,8 @@ WORKLOAD_TEXT = {
     "cfg4": "20 kb, 12 subreads, -d 1500 (wide adaptive band)",
     "cfg5": "cfg2 shape, one GPU batch of the streamed CLI",
     "cfgL": "not a BASELINE config: long inserts (3 / 6 kb, 3-5 repeats, reads of 10-32 kb) -- the subread-length axis",
+    "cfg2e15": "not a BASELINE config: the cfg2 shape at 15 % errors (every rate x 1.5) -- the error-rate axis, where raw ONT R2C2 reads live",
+    "cfg2e20": "not a BASELINE config: the cfg2 shape at 20 % errors (every rate x 2.0)",
 }
 
 
@@ -64,7 +66,7 @@ def kernel_src_sha():
     return hsh.hexdigest()[:16]
 
 
-PROFILE_TAGS = ("r05", "r04", "r03", "r02", "r01")
+PROFILE_TAGS = ("r06", "r05", "r04", "r03", "r02", "r01")
 SIMDS = 1024              # 256 CUs x 4 SIMDs
 
 
@@ -80,11 +82,13 @@ def pmc_traffic_lookup(profiles_dir, cfg, reads, dom, sha):
         except Exception:
             continue
         if pm.get("kernel_src_sha") == sha:
-            return t_, "profiles/%s (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024; kernel sources %s = this build)" % (name, sha)
+            # every kernel of the step (one launch each per step, but for the two launches of k_window that the file already sums)
+            tot = float(sum(v.get("hbm_bytes_per_launch", 0.0) for v in pm["kernels"].values()))
+            return t_, "profiles/%s (rocprofv3 --pmc, (2*FETCH_SIZE+WRITE_SIZE)*1024; kernel sources %s = this build)" % (name, sha), tot
         # measured on other kernels than the ones running here: not this run's traffic
         return None, "none for this build (kernel sources %s; profiles/%s was measured on %s: %.4g bytes per launch)" % (
-            sha, name, pm.get("kernel_src_sha", "an earlier round's kernels"), t_)
-    return None, None
+            sha, name, pm.get("kernel_src_sha", "an earlier round's kernels"), t_), None
+    return None, None, None
 
 
 def valu_lookup(profiles_dir, cfg, dom, sha):
@@ -101,11 +105,12 @@ def valu_lookup(profiles_dir, cfg, dom, sha):
             return {"insts_per_cell": None, "busy_frac": None,
                     "source": "none for this build (kernel sources %s; profiles/%s was measured on %s: %.3f vector wave-instructions per cell)" % (
                         sha, name, sq.get("kernel_src_sha", "an earlier round's kernels"), k.get("insts_per_cell") or 0.0)}
+        cpi = k.get("cycles_per_inst") or sq.get("cycles_per_inst_assumed") or 0.0
         return {"insts_per_cell": k.get("insts_per_cell"), "busy_frac": k.get("busy_frac"),
-                "insts_per_simd_cycle": k.get("insts_per_simd_cycle"), "cycles_per_inst_assumed": sq.get("cycles_per_inst_assumed"),
+                "insts_per_simd_cycle": k.get("insts_per_simd_cycle"), "cycles_per_inst": cpi,
                 "source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU / SQ_BUSY_CYCLES on tools/phase_prof.py %s %s; busy_frac = vector wave-instructions x "
-                          "%.2f issue cycles (mean of the two instruction classes of tools/ubench/valu_cost.hip) / SIMD cycles of the kernel; kernel sources %s = this build)" % (
-                              name, sq.get("reads"), cfg, sq.get("cycles_per_inst_assumed") or 0.0, sha)}
+                          "%.2f issue cycles (this kernel's own instruction mix priced with the two classes of tools/ubench/valu_cost.hip: tools/isa_cpi.py) "
+                          "/ SIMD cycles of the kernel; kernel sources %s = this build)" % (name, sq.get("reads"), cfg, cpi, sha)}
     return {"insts_per_cell": None, "busy_frac": None, "source": None}
 
 
@@ -201,7 +206,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--parity-reads", type=int, default=1024, help="random reads of the last batch (of every config run) checked against the oracle after the timed region")
     ap.add_argument("--other-configs", default="auto",
-                    help="comma list of further configs run for 3 steps after the headline (rank 0, N=1): 'auto' = cfg3,cfg4,cfgL "
+                    help="comma list of further configs run for 3 steps after the headline (rank 0, N=1): 'auto' = cfg3,cfg4,cfgL,cfg2e15 "
                          "when the headline is cfg2 at full size, 'none' = skip")
     ap.add_argument("--other-unique", type=int, default=0, help="distinct reads generated for each of the other configs (0 = all distinct, no tiling)")
     a = ap.parse_args(argv)
@@ -230,7 +235,7 @@ def main():
     # inputs of the other configs too (rank 0, N=1): the fork pool must run before anything touches the GPU
     others = a.other_configs
     if others == "auto":
-        others = "cfg3,cfg4,cfgL" if (a.cfg == "cfg2" and a.reads >= 100000) else "none"
+        others = "cfg3,cfg4,cfgL,cfg2e15" if (a.cfg == "cfg2" and a.reads >= 100000) else "none"
     other_recs = {}
     if rank == 0 and world == 1 and others != "none":
         for c in [x for x in others.split(",") if x]:
@@ -360,7 +365,7 @@ def main():
         # HBM traffic of the dominant kernel: PMC counters cannot be collected from inside this process; the number
         # comes from the committed rocprofv3 passes of THIS command when the workload matches
         sha = kernel_src_sha()
-        traffic, tsrc = pmc_traffic_lookup(os.path.join(ROOT, "profiles"), a.cfg, a.reads, dom, sha)
+        traffic, tsrc, traffic_total = pmc_traffic_lookup(os.path.join(ROOT, "profiles"), a.cfg, a.reads, dom, sha)
         valu = valu_lookup(os.path.join(ROOT, "profiles"), a.cfg, dom, sha)
         out = {
             "metric": "R2C2 reads->consensus/sec", "value": round(value, 1), "unit": "reads/s",
@@ -380,6 +385,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom.replace("ms_", "k_"), "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                          "traffic": traffic, "traffic_source": tsrc,
+                         # all kernels of one step together (PMC), and how many times the algorithmic bytes that is: the state of the DP never has to
+                         # leave a CU, so everything above ~1x is scratch the kernels chose to keep in memory (direction cells, graph arrays)
+                         "traffic_total": traffic_total,
+                         "traffic_over_algorithmic": (round(traffic_total / alg_bytes, 1) if traffic_total else None),
                          "alg_bytes_per_launch": alg_bytes,
                          "kernel_ms": {k: round(v, 3) for k, v in avg.items()},
                          "run_host_ms": {k: round(float(np.mean(v)), 3) for k, v in host_ms.items()},
@@ -387,12 +396,12 @@ def main():
                          "cells_polish_full_matrix": int(tm["cells_polish"]), "cells_polish_computed": int(tm["cells_polish_computed"]),
                          "band_layers": int(tm["n_band_layers"]), "band_fallback_layers": int(tm["n_band_fallback"]),
                          "windows": int(tm["n_windows"]), "windows_second_launch": int(tm["n_win_redo"]),
-                         "cells_poa": int(tm["cells_poa"]), "poa_gcells_per_s": round(tm["cells_poa"] / (avg["ms_poa"] * 1e-3) / 1e9, 1),
+                         "cells_poa": int(tm["cells_poa"]), "poa_gcells_per_s": round(tm["cells_poa"] / ((avg["ms_poa"] + float(tm.get("ms_poa_tail", 0.0))) * 1e-3) / 1e9, 1),
                          "poa_second_pass_reads": int(tm["n_poa_redo"]), "poa_reads_beyond_16bit": int(tm["n_poa_redo16"]),
                          # cell updates per second of kernel time.  gcups_computed counts the cells the kernels COMPUTE (conk + POA + the banded
                          # polish rows); gcups_full_matrices counts what the oracle's full polish matrices hold (the figure printed as "gcups"
                          # until round 4) -- the band's certificate makes the two results identical, not the two amounts of work
-                         "gcups_computed": round((tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish_computed"]) / (sum(avg.values()) * 1e-3) / 1e9, 2),
+                         "gcups_computed": round((tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish_computed"]) / ((sum(avg.values()) + float(tm.get("ms_poa_tail", 0.0))) * 1e-3) / 1e9, 2),
                          "gcups_full_matrices": round(cells / (sum(avg.values()) * 1e-3) / 1e9, 2),
                          # what binds the dominant kernel is vector instruction issue, not HBM: instructions per counted cell and the
                          # share of the SIMDs' issue cycles they fill, from the committed SQ-counter pass of this build (None otherwise)
@@ -459,9 +468,11 @@ def run_other_config(cfg, device, recs, gen_s, steps=3, check=True, parity_reads
     o = {"value": round(n * steps / dt, 1), "unit": "reads/s", "reads_per_step": n, "steps": steps, "ms_per_step": round(dt / steps * 1e3, 2),
          "kernel_ms": {k: round(float(np.mean(v)), 2) for k, v in kms.items()},
          "cells": int(tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish"]), "cells_polish_computed": int(tm["cells_polish_computed"]),
-         "gcups_computed": round((tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish_computed"]) / (sum(float(np.mean(v)) for v in kms.values()) * 1e-3) / 1e9, 2),
-         "band_fallback_layers": int(tm["n_band_fallback"]), "band_layers": int(tm["n_band_layers"]), "windows_second_launch": int(tm["n_win_redo"]),
-         "cells_poa": int(tm["cells_poa"]), "poa_gcells_per_s": round(tm["cells_poa"] / (float(np.mean(kms["ms_poa"])) * 1e-3) / 1e9, 1),
+         # (the last POA pass runs beside the polish on a stream of its own: its cells are in cells_poa, so its time joins the denominator -- kernel
+         # time, not wall time: an overlapped kernel counts twice, which under-states the rate rather than inflating it)
+         "gcups_computed": round((tm["cells_conk"] + tm["cells_poa"] + tm["cells_polish_computed"]) / ((sum(float(np.mean(v)) for v in kms.values()) + float(tm.get("ms_poa_tail", 0.0))) * 1e-3) / 1e9, 2),
+         "band_fallback_layers": int(tm["n_band_fallback"]), "band_layers": int(tm["n_band_layers"]), "windows": int(tm["n_windows"]), "windows_second_launch": int(tm["n_win_redo"]),
+         "cells_poa": int(tm["cells_poa"]), "poa_gcells_per_s": round(tm["cells_poa"] / ((float(np.mean(kms["ms_poa"])) + float(tm.get("ms_poa_tail", 0.0))) * 1e-3) / 1e9, 1),
          "poa_second_pass_reads": int(tm["n_poa_redo"]), "poa_reads_beyond_16bit": int(tm["n_poa_redo16"]),
          "ms_poa_last_pass_beside_polish": round(float(tm.get("ms_poa_tail", 0.0)), 2),       # (its own stream, overlapped: not in kernel_ms)
          "consensus_ok": int((res["status"] == 0).sum()), "identity_vs_truth_mean": round(float(np.mean(idents)), 5),

@@ -735,9 +735,17 @@ static int run_poa(c3_handle* h, bool polish_follows) {
         HIPCHK(h->d_counter_mw.ensure(512));
         HIPCHK(hipMemsetAsync(h->d_counter_mw.p, 0, 512, h->stream_mw));       // (the main stream is idle: its passes were waited for above)
         HIPCHK(hipEventRecord(h->ev_mw[0], h->stream_mw));
+        h->tail_pending = true;                 // (set BEFORE the launch: every error return from here on waits for stream_mw -- TailGuard in c3_batch_run)
         if ((rc = launch_poa(h, ovB, cnt[5], Ncap_full, K, Pcap, cells_worst, nullptr, nullptr, 24, 0, &h->d_counter_mw, h->stream_mw))) return rc;
         HIPCHK(hipEventRecord(h->ev_mw[1], h->stream_mw));
-        h->tail_pending = true;
+        // the batch without the stragglers (order kept: longest first): what the polish beside the last pass works on, and what the
+        // draft statistics below may read -- the stragglers' C3Info is being written by the last pass right now
+        std::vector<char> iss(h->n, 0);
+        for (int r : h->strag) iss[r] = 1;
+        h->work_main.clear();
+        for (int r : h->work) if (!iss[r]) h->work_main.push_back(r);
+        HIPCHK(h->d_work_main.ensure(sizeof(int) * std::max<size_t>(h->work_main.size(), 1)));
+        if (!h->work_main.empty()) HIPCHK(hipMemcpyAsync(h->d_work_main.p, h->work_main.data(), sizeof(int) * h->work_main.size(), hipMemcpyHostToDevice, h->stream));
       } else {
         h->strag.clear();
         HIPCHK(hipMemsetAsync(h->d_counter.p, 0, 4, h->stream));
@@ -751,14 +759,20 @@ static int run_poa(c3_handle* h, bool polish_follows) {
     HIPCHK(hipGetLastError());
   }
   HIPCHK(hipMemcpyAsync(h->phase_poa, h->d_counter.as<char>() + 64, 128, hipMemcpyDeviceToHost, h->stream));
-  hipLaunchKernelGGL(k_draft_stats, dim3((nw + 255) / 256), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), h->d_work.as<int>(), nw, h->cfg.pol_window, h->d_counter.as<int>() + 6);
-  HIPCHK(hipGetLastError());
+  {
+    const int* dw_ = h->tail_pending ? h->d_work_main.as<int>() : h->d_work.as<int>();
+    const int nw_ = h->tail_pending ? (int)h->work_main.size() : nw;
+    if (nw_ > 0) hipLaunchKernelGGL(k_draft_stats, dim3((nw_ + 255) / 256), dim3(256), 0, h->stream, h->d_info.as<C3Info>(), dw_, nw_, h->cfg.pol_window, h->d_counter.as<int>() + 6);
+    HIPCHK(hipGetLastError());
+  }
   return 0;
 }
 
 // k_prep -> k_window (two launches) -> k_stitch over one work list (the whole batch, or -- when the last POA pass runs beside it -- the
 // batch without the stragglers and then the stragglers alone); times and counters ADD to h->tm (c3_batch_run zeroes them)
-static int run_polish(c3_handle* h, const std::vector<int>& work, const int* d_work, float* ms_prep, float* ms_win, float* ms_st) {
+// max_draft / sum_win: longest draft and window count of THIS work list as k_draft_stats measured them (-1: the drafts did not come from
+// k_poa of this batch -- the tables are sized from bounds).  Arguments, not handle state: the tail's sizing must not replace the batch's
+static int run_polish(c3_handle* h, const std::vector<int>& work, const int* d_work, int max_draft, long long sum_win, float* ms_prep, float* ms_win, float* ms_st) {
   const int nw = (int)work.size();
   DBG("polish: nw=%d\n", nw);
   HIPCHK(h->d_cons.ensure((size_t)h->total + 64));
@@ -770,9 +784,9 @@ static int run_polish(c3_handle* h, const std::vector<int>& work, const int* d_w
     wcap += (2 * h->sum[i].max_sub + WL - 1) / WL + 1;
   }
   int NLcap = max_ns + 2, NWcap = (2 * max_q + WL - 1) / WL + 1;
-  if (h->poa_max_draft >= 0) {       // the drafts exist: the window tables are sized for them, not for a bound (a draft is a path of the graph and can be longer than twice the longest subread)
-    NWcap = (h->poa_max_draft + WL - 1) / WL + 1;
-    wcap = (long long)h->poa_sum_win + 8;
+  if (max_draft >= 0) {       // the drafts exist: the window tables are sized for them, not for a bound (a draft is a path of the graph and can be longer than twice the longest subread)
+    NWcap = (max_draft + WL - 1) / WL + 1;
+    wcap = sum_win + 8;
   }
   const int64_t ecap = ((int64_t)(max_dang + 2) / 3 + 2) * 256;    // 2-bit directions: one dword per lane and three piece rows
   const size_t per_slot_prep = (size_t)ecap + (size_t)NLcap * NWcap * 8;
@@ -903,6 +917,9 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
   int rc;
   float ms;
   hipEvent_t t0 = h->ev[0], t1 = h->ev[1], t2 = h->ev[2], t3 = h->ev[3], t4 = h->ev[4];
+  // any return while the last POA pass is still running on stream_mw (a failing run_polish, a HIPCHK) waits for it first: the next call
+  // may free or reuse s_poa_* / d_overflow / d_info under the running kernel otherwise
+  struct TailGuard { c3_handle* h; ~TailGuard() { if (h->tail_pending) { (void)hipStreamSynchronize(h->stream_mw); h->tail_pending = false; h->strag.clear(); } } } tail_guard{h};
   DBG("run: start n=%d\n", h->n);
   const auto wall0 = std::chrono::steady_clock::now();
   const double alloc0 = g_alloc_ms;
@@ -937,16 +954,12 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
       HIPCHK(hipEventElapsedTime(&ms, t3, t4)); h->tm.ms_poa = ms;
     }
     h->n_windows = 0;
-    if ((stages & C3_STAGE_POLISH) && !h->tail_pending) { if ((rc = run_polish(h, h->work, h->d_work.as<int>(), &ms_prep, &ms_win, &ms_st))) return rc; }
+    if ((stages & C3_STAGE_POLISH) && !h->tail_pending) { if ((rc = run_polish(h, h->work, h->d_work.as<int>(), h->poa_max_draft, h->poa_sum_win, &ms_prep, &ms_win, &ms_st))) return rc; }
     if (h->tail_pending) {
-      // the last POA pass is running on stream_mw: polish everything else beside it, then the stragglers
-      std::vector<char> iss(h->n, 0);
-      for (int r : h->strag) iss[r] = 1;
-      h->work_main.clear();
-      for (int r : h->work) if (!iss[r]) h->work_main.push_back(r);          // (order kept: longest first)
-      HIPCHK(h->d_work_main.ensure(sizeof(int) * std::max<size_t>(h->work_main.size(), 1)));
-      if (!h->work_main.empty()) HIPCHK(hipMemcpyAsync(h->d_work_main.p, h->work_main.data(), sizeof(int) * h->work_main.size(), hipMemcpyHostToDevice, h->stream));
-      if ((rc = run_polish(h, h->work_main, h->d_work_main.as<int>(), &ms_prep, &ms_win, &ms_st))) return rc;
+      // the last POA pass is running on stream_mw: polish everything else beside it (run_poa built work_main and measured ITS drafts:
+      // poa_max_draft / poa_sum_win hold the main list's figures at this point), then the stragglers
+      const int main_draft = h->poa_max_draft; const long long main_win = h->poa_sum_win;
+      if ((rc = run_polish(h, h->work_main, h->d_work_main.as<int>(), main_draft, main_win, &ms_prep, &ms_win, &ms_st))) return rc;
       // ... the stragglers: their drafts exist once the last pass is done
       HIPCHK(hipStreamWaitEvent(h->stream, h->ev_mw[1], 0));
       const int ns_ = (int)h->strag.size();
@@ -959,10 +972,13 @@ extern "C" int c3_batch_run(c3_handle* h, int stages) {
       HIPCHK(hipMemcpyAsync(cmw, h->d_counter_mw.p, 16, hipMemcpyDeviceToHost, h->stream));
       HIPCHK(hipStreamSynchronize(h->stream));
       h->tm.cells_poa += *(long long*)(cmw + 2);
-      h->poa_max_draft = cnt[6]; h->poa_sum_win = cnt[7];
+      // the handle keeps the figures of the WHOLE batch (a later c3_batch_run(C3_STAGE_POLISH) on this resident batch sizes its window
+      // tables from them); the stragglers' own figures only size the tail below
+      const int strag_draft = cnt[6]; const long long strag_win = cnt[7];
+      h->poa_max_draft = std::max(main_draft, strag_draft); h->poa_sum_win = (int)std::min<long long>(main_win + strag_win, 0x7fffffff);
       { float t_ = 0; HIPCHK(hipEventElapsedTime(&t_, h->ev_mw[0], h->ev_mw[1])); h->tm.ms_poa_tail = t_; }
       h->tail_pending = false;
-      if ((rc = run_polish(h, h->strag, d_strag, &ms_prep, &ms_win, &ms_st))) return rc;
+      if ((rc = run_polish(h, h->strag, d_strag, strag_draft, strag_win, &ms_prep, &ms_win, &ms_st))) return rc;
     }
   }
   HIPCHK(hipStreamSynchronize(h->stream));

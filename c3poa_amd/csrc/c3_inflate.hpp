@@ -41,15 +41,16 @@ struct Inflater {
   void reset(const uint8_t* p, const uint8_t* e) { in = p; in_end = e; bitbuf = 0; bitcnt = 0; in_block = final_block = stream_end = false; stored_left = 0; }
 
   // canonical Huffman table: lens[0..n) code lengths (0 = unused), PB first-level bits.  kind_of(sym) builds the entry for a symbol.
-  // Returns false on an over-subscribed set, or an incomplete one (allowed: exactly one code of length 1 -- RFC 1951 3.2.7, one distance code)
+  // Returns false on an over-subscribed set, or an incomplete one (allowed where allow_single: exactly one code of length 1 -- RFC 1951
+  // 3.2.7, one distance code; zlib accepts the same for the literal / length set and for no other: the code-length alphabet must be complete)
   template <class F>
-  static bool build(const uint8_t* lens, int n, uint32_t* tab, int PB, int cap, F entry_of) {
+  static bool build(const uint8_t* lens, int n, uint32_t* tab, int PB, int cap, F entry_of, bool allow_single = true) {
     int count[16] = {0};
     for (int i = 0; i < n; ++i) count[lens[i]]++;
     if (count[0] == n) { for (int i = 0; i < (1 << PB); ++i) tab[i] = 0; return true; }       // no codes at all (a block without distances)
     int left = 1;
     for (int l = 1; l <= 15; ++l) { left = (left << 1) - count[l]; if (left < 0) return false; }
-    const bool single = (n - count[0] == 1) && count[1] == 1;
+    const bool single = allow_single && (n - count[0] == 1) && count[1] == 1;
     if (left > 0 && !single) return false;
     int offs[16]; offs[1] = 0;
     for (int l = 1; l < 15; ++l) offs[l + 1] = offs[l] + count[l];
@@ -170,7 +171,7 @@ struct Inflater {
     uint8_t cl[19] = {0};
     for (uint32_t i = 0; i < hclen; ++i) { uint32_t v3; if (!take(3, &v3)) return false; cl[order[i]] = (uint8_t)v3; }
     uint32_t cltab[(1 << 7) + 8];
-    if (!build(cl, 19, cltab, 7, (1 << 7) + 8, [](int sym, int len) { return mk(K_LIT, (uint32_t)sym, 0, (uint32_t)len); })) return false;
+    if (!build(cl, 19, cltab, 7, (1 << 7) + 8, [](int sym, int len) { return mk(K_LIT, (uint32_t)sym, 0, (uint32_t)len); }, false)) return false;
     uint8_t lens[320] = {0};
     for (uint32_t i = 0; i < hlit + hdist;) {
       if (bitcnt < 7 + 7) refill_safe();
@@ -223,9 +224,8 @@ struct Inflater {
         // (<= 20), a second one the distance (<= 28).  FASTQ deflates to literals for the most part: this path decides the rate.
         {
           const size_t out_fast = cap >= 274 ? (soft < cap - 274 ? soft : cap - 274) : 0;
-          const uint8_t* const in_fast = in_end - 16;
           const uint32_t LM = (1u << LIT_BITS) - 1;
-          while (in <= in_fast && pos < out_fast) {
+          while ((size_t)(in_end - in) >= 16 && pos < out_fast) {      // (not `in <= in_end - 16`: a stream shorter than 16 bytes would form a pointer before its start)
             refill_fast();
             uint32_t e = lit[bitbuf & LM];
             // up to three lookups of literals (one or two bytes each, at most 11 bits each) out of one refill

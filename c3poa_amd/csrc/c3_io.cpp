@@ -53,6 +53,21 @@ int host_cores() {
       char q[64]; long long per = 0;
       if (fscanf(f, "%63s %lld", q, &per) == 2 && strcmp(q, "max") != 0 && per > 0) c = std::min<long>(c, std::max<long>(1, (long)(atoll(q) / per)));
       fclose(f);
+    } else {
+      // cgroup v1 hosts: the CFS quota of the cpu controller (-1 = none)
+      long long quota = -1, per = 0;
+      for (const char* dir : {"/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"}) {
+        char path[128];
+        snprintf(path, sizeof(path), "%s/cpu.cfs_quota_us", dir);
+        FILE* fq = fopen(path, "r");
+        if (!fq) continue;
+        const bool okq = fscanf(fq, "%lld", &quota) == 1; fclose(fq);
+        snprintf(path, sizeof(path), "%s/cpu.cfs_period_us", dir);
+        FILE* fp = fopen(path, "r");
+        const bool okp = fp && fscanf(fp, "%lld", &per) == 1; if (fp) fclose(fp);
+        if (okq && okp && quota > 0 && per > 0) c = std::min<long>(c, std::max<long>(1, (long)(quota / per)));
+        break;
+      }
     }
     return (int)std::max<long>(1, c);
   }();
@@ -1133,7 +1148,9 @@ extern "C" int c3_compress_file(const char* src, const char* dst, int level, int
   if (!fo) { fclose(fi); return C3_E_ARG; }
   // a stretch = T x 64 members: read, deflated by T threads (members dealt round-robin), written in order; the next stretch is read while
   // this one is written
-  const size_t per = 64, nb = (size_t)T * per, in_cap = nb * BGZF_BLOCK, out_slot = 65536 + 64;
+  // (capped at 32 x 16 members -- 67 MB of buffers -- whatever T: T x 64 members were 1.1 GB of transient host memory on a 128-core host,
+  // beside the page-locked reader sets at the end of a run; the threads beyond 32 still share the stretch round-robin)
+  const size_t per = T > 8 ? 16 : 64, nb = (size_t)std::min(T, 32) * per < (size_t)T ? (size_t)T : (size_t)std::min(T, 32) * per, in_cap = nb * BGZF_BLOCK, out_slot = 65536 + 64;
   std::vector<unsigned char> in(in_cap), out(nb * out_slot);
   std::vector<size_t> osz(nb);
   bool ok = true;

@@ -25,6 +25,10 @@ CONFIGS = {
     # not a BASELINE config: long cDNA inserts (real R2C2 libraries hold 2-6 kb molecules; abPOA has no length limit,
     # bin/determine_consensus.py:30-47).  Insert drawn per read from the list; 3-5 repeats; reads of 10-32 kb
     "cfgL": dict(reads=20000, seed=6, insert=(3000, 6000), n_lo=3, n_hi=5, k0=108, k1=108, mdist=500),
+    # not BASELINE configs: the cfg2 shape with every error rate x 1.5 (6 / 3.75 / 5.25 % = 15 %: where raw ONT R2C2 reads live) and x 2.0 --
+    # the polish band's certificate fails more often there, the POA bands drift further (round 6: the bench line watches x 1.5)
+    "cfg2e15": dict(reads=100000, seed=12, insert=1216, n_lo=3, n_hi=3, k0=108, k1=108, mdist=500, err=1.5),
+    "cfg2e20": dict(reads=100000, seed=13, insert=1216, n_lo=3, n_hi=3, k0=108, k1=108, mdist=500, err=2.0),
 }
 
 _ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
@@ -59,7 +63,7 @@ def _mutate(rng, clean, sub=0.04, ins=0.025, dele=0.035):
     return seq.tobytes(), q.tobytes()
 
 
-def make_read(rng, splint, insert_len, n, k0, k1):
+def make_read(rng, splint, insert_len, n, k0, k1, err=1.0):
     """returns (seq str, qual str, strand '+'/'-', truth str in read orientation)"""
     ins = _ACGT[rng.integers(0, 4, insert_len)].tobytes().decode()
     clean = ins[len(ins) - k0:] + (splint + ins) * n + splint + ins[:k1]
@@ -68,7 +72,7 @@ def make_read(rng, splint, insert_len, n, k0, k1):
     strand = "+"
     if rng.random() < 0.5:
         clean, truth, strand = revcomp(clean), revcomp(truth), "-"
-    seq, qual = _mutate(rng, np.frombuffer(clean.encode(), dtype=np.uint8))
+    seq, qual = _mutate(rng, np.frombuffer(clean.encode(), dtype=np.uint8), sub=0.04 * err, ins=0.025 * err, dele=0.035 * err)
     return seq.decode(), qual.decode(), strand, truth
 
 
@@ -82,7 +86,7 @@ def generate(cfg="cfg2", n_reads=None, seed=None, splint=SPLINT1, start=0):
         rng = np.random.default_rng([sd, i])
         n = int(rng.integers(c["n_lo"], c["n_hi"] + 1))
         ins = c["insert"] if isinstance(c["insert"], int) else int(c["insert"][int(rng.integers(0, len(c["insert"])))])
-        seq, qual, strand, truth = make_read(rng, splint, ins, n, c["k0"], c["k1"])
+        seq, qual, strand, truth = make_read(rng, splint, ins, n, c["k0"], c["k1"], c.get("err", 1.0))
         yield ("r%08d" % i, seq, qual, strand, truth)
 
 

@@ -30,6 +30,11 @@ int c3o_poa_last_scores(int32_t* out, int cap) { int n = g_nscores < cap ? g_nsc
  * batch consist of, as the HIP kernel classifies them, and how far real cell values sit below their row's maximum */
 int64_t c3o_poa_rowstats[64];
 int c3o_poa_rowstats_on = 0;
+/* run-length statistics (tools/poa_run_lengths.py; round 6): [0..63] rows that lie in a run of k+1 consecutive fast rows (63 = 64 or
+ * more), [64..127] the same for runs of fast rows whose band moved by exactly one column at both ends (what a skewed multi-row
+ * step would have to predict), [128..191] fast rows whose band shift / width change was (dbeg, dend) = (1,1) / other, by kind */
+int64_t c3o_poa_runstats[192];
+static void run_close(int64_t* S, int len) { if (len > 0) S[len > 64 ? 63 : len - 1] += len; }
 
 typedef struct {
   int32_t *H, *E1, *E2; uint32_t* D;
@@ -104,6 +109,7 @@ static int poa_align(const c3o_graph* g, const uint8_t* q, int Q, const c3o_para
   m.rend = (int*)malloc(sizeof(int) * (size_t)n);
   m.roff = (int64_t*)malloc(sizeof(int64_t) * (size_t)n);
   int32_t* ht = (int32_t*)malloc(sizeof(int32_t) * (size_t)(Q + 2));
+  int run_fast = 0, run_diag = 0;
 
   for (int idx = 0; idx < n; ++idx) {
     int v = g->order[idx];
@@ -200,6 +206,12 @@ static int poa_align(const c3o_graph* g, const uint8_t* q, int Q, const c3o_para
         if (f6) S[56] += wd;
         if (f4) S[57] += wd; }
       if (nin == 1 && dmax == 1 && wd <= 64 && pwd <= 64 && sh < 64 && !(wd + sh <= 64 && (sh >= 1 || pwd <= 63))) S[54]++;     /* fast in round 3, not under the round-4 no-wrap rule */
+      { int64_t* R = c3o_poa_runstats;
+        const int isfast = nin == 1 && dmax == 1 && wd <= 64 && pwd <= 64 && sh < 64 && wd + sh <= 64 && (sh >= 1 || pwd <= 63);
+        const int isdiag = isfast && sh == 1 && end == m.rend[idx - 1] + 1;
+        if (isfast) { ++run_fast; R[128 + (isdiag ? 0 : 1)]++; if (!isdiag) { int db = sh, de = end - m.rend[idx - 1]; R[130 + (db == 1 ? 0 : db == 0 ? 1 : db == 2 ? 2 : 3) * 4 + (de == 1 ? 0 : de == 0 ? 1 : de == 2 ? 2 : 3)]++; } }
+        else { run_close(R, run_fast); run_fast = 0; }
+        if (isdiag) ++run_diag; else { run_close(R + 64, run_diag); run_diag = 0; } }
       if (nin == 1 && dmax == 1 && wd <= 64 && pwd <= 64 && sh < 64) { S[2]++; S[8 + (sh < 0 ? 0 : sh > 3 ? 4 : sh + 0)]++; }   /* fast; shift histogram 8..12 */
       else if (nin <= 4 && dmax < 4 && wd <= 128 && pwmax < 128) {
         S[3]++;
@@ -234,6 +246,7 @@ static int poa_align(const c3o_graph* g, const uint8_t* q, int Q, const c3o_para
       if (left + 1 < mpl[t]) mpl[t] = left + 1;
     }
   }
+  if (c3o_poa_rowstats_on) { run_close(c3o_poa_runstats, run_fast); run_close(c3o_poa_runstats + 64, run_diag); }
   *cells += m.ncell;
 
   /* end cell: best predecessor of the sink at column Q (first max in in-edge order) */

@@ -77,15 +77,16 @@ def test_traffic_and_valu_lookups_take_only_this_builds_counters(tmp_path):
     sha = "0123456789abcdef"
     pm = {"kernel_src_sha": sha, "kernels": {"k_poa": {"hbm_bytes_per_launch": 123.0}, "k_window": {"hbm_bytes_per_launch": 7.0}}}
     json.dump(pm, open(tmp_path / "r05_pmc_traffic_cfg2_100k.json", "w"))
-    t, src = bench.pmc_traffic_lookup(str(tmp_path), "cfg2", 100000, "ms_poa", sha)
+    t, src, tot = bench.pmc_traffic_lookup(str(tmp_path), "cfg2", 100000, "ms_poa", sha)
     assert t == 123.0 and "r05_pmc_traffic_cfg2_100k.json" in src and "this build" in src
-    t, src = bench.pmc_traffic_lookup(str(tmp_path), "cfg2", 100000, "ms_poa", "f" * 16)
-    assert t is None and src.startswith("none for this build") and sha in src
+    assert tot == 130.0                                                        # roofline.traffic_total: every kernel of the step (round 6)
+    t, src, tot = bench.pmc_traffic_lookup(str(tmp_path), "cfg2", 100000, "ms_poa", "f" * 16)
+    assert t is None and tot is None and src.startswith("none for this build") and sha in src
     pm.pop("kernel_src_sha")                                                   # a summary from before the hash existed
     json.dump(pm, open(tmp_path / "r05_pmc_traffic_cfg2_100k.json", "w"))
-    t, src = bench.pmc_traffic_lookup(str(tmp_path), "cfg2", 100000, "ms_poa", sha)
+    t, src, tot = bench.pmc_traffic_lookup(str(tmp_path), "cfg2", 100000, "ms_poa", sha)
     assert t is None and src.startswith("none for this build")
-    assert bench.pmc_traffic_lookup(str(tmp_path), "cfg4", 100000, "ms_poa", sha) == (None, None)      # no file for the workload
+    assert bench.pmc_traffic_lookup(str(tmp_path), "cfg4", 100000, "ms_poa", sha) == (None, None, None)      # no file for the workload
     # the newest tag wins: an r04 file of this build is not consulted when an r05 file (stale) exists
     json.dump({"kernel_src_sha": sha, "kernels": {"k_poa": {"hbm_bytes_per_launch": 5.0}}}, open(tmp_path / "r04_pmc_traffic_cfg2_100k.json", "w"))
     assert bench.pmc_traffic_lookup(str(tmp_path), "cfg2", 100000, "ms_poa", sha)[0] is None
@@ -93,6 +94,11 @@ def test_traffic_and_valu_lookups_take_only_this_builds_counters(tmp_path):
     json.dump(sq, open(tmp_path / "r05_sq_counters_cfg2.json", "w"))
     v = bench.valu_lookup(str(tmp_path), "cfg2", "ms_poa", sha)
     assert v["insts_per_cell"] == 3.5 and v["busy_frac"] == 0.65 and "this build" in v["source"]
+    assert v["cycles_per_inst"] == 2.9                                         # a summary without the per-kernel figure: the file's constant
+    sq["kernels"]["k_poa"]["cycles_per_inst"] = 3.31                           # round 6: priced from the kernel's own listing (tools/isa_cpi.py)
+    json.dump(sq, open(tmp_path / "r06_sq_counters_cfg2.json", "w"))
+    assert bench.valu_lookup(str(tmp_path), "cfg2", "ms_poa", sha)["cycles_per_inst"] == 3.31
+    os.remove(tmp_path / "r06_sq_counters_cfg2.json")
     v = bench.valu_lookup(str(tmp_path), "cfg2", "ms_poa", "e" * 16)
     assert v["insts_per_cell"] is None and v["busy_frac"] is None and v["source"].startswith("none for this build")
     assert bench.valu_lookup(str(tmp_path), "cfg3", "ms_poa", sha) == {"insts_per_cell": None, "busy_frac": None, "source": None}

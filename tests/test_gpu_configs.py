@@ -77,6 +77,14 @@ def test_cfgL_long_inserts_one_batch():
     assert ns.min() >= 2 and ns.max() <= 6
 
 
+@pytest.mark.parametrize("cfg,min_ok,min_ident", [("cfg2e15", 0.99, 0.91), ("cfg2e20", 0.97, 0.86)])
+def test_noisy_reads_15_and_20_percent_errors(cfg, min_ok, min_ident):
+    """round 6 (review item 2): the cfg2 shape with every error rate x 1.5 and x 2.0.  More band certificates of the polish fail there, more
+    POA rows leave the one-chunk fast path, more windows take k_window's full-size launch -- the paths the 10 % configs barely touch.
+    Whole batch against the oracle on a sample, sharding invariance, counted cells equal."""
+    _whole_vs_shards_vs_oracle(cfg, 4096, 96, min_ok, min_ident)
+
+
 # ---- cfg5: the streamed CLI -------------------------------------------------------------------------------------------
 
 def _write_inputs(tmp_path, recs, with_psl):

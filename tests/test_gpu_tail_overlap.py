@@ -96,3 +96,20 @@ def test_stragglers_among_zero_repeat_reads_and_stage_by_stage_runs():
     for i in range(len(recs)):
         assert int(res[i]["status"]) == ores[i].status and cons[i] == ocons[i], i
     assert t["ms_poa_tail"] == 0
+
+
+def test_polish_again_on_the_resident_batch_after_an_overlapped_last_pass():
+    """round 6 (advisor): after the overlapped last pass the handle used to keep the STRAGGLERS' draft statistics (longest draft, window
+    count); a later c3_batch_run(C3_STAGE_POLISH) on the same resident batch sized k_prep's window tables from a handful of reads and
+    most reads ended as LIMIT.  The handle now keeps the whole batch's figures: full run with stragglers, then the polish stage again."""
+    recs = list(synth.generate("cfg2", n_reads=96))
+    md = synth.CONFIGS["cfg2"]["mdist"]
+    ores, ocons = _oracle(recs, md)
+    res, cons, t = _run(recs, md, {"C3_DEBUG_POA_PUNT_MOD": "7"}, stages=[_lib.STAGES_ALL, _lib.STAGE_POLISH])
+    for i in range(len(recs)):
+        assert int(res[i]["status"]) == ores[i].status and cons[i] == ocons[i], i
+    # ... and when every straggler fails to produce a draft worth a window the figures of the others must survive as well: POA + polish
+    # in one call, then polish twice more
+    res, cons, t = _run(recs, md, {"C3_DEBUG_POA_PUNT_MOD": "2"}, stages=[_lib.STAGES_ALL, _lib.STAGE_POLISH, _lib.STAGE_POLISH])
+    for i in range(len(recs)):
+        assert int(res[i]["status"]) == ores[i].status and cons[i] == ocons[i], i

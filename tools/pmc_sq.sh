@@ -26,10 +26,20 @@ hsh = hashlib.sha1()
 for f_ in sorted(glob.glob("c3poa_amd/csrc/*.hip") + glob.glob("c3poa_amd/csrc/*.h")):
     hsh.update(os.path.basename(f_).encode() + b"\0" + open(f_, "rb").read())
 # mean issue cost of a vector wave-instruction: the two classes of tools/ubench/valu_cost.hip (2.3 cycles: add / sub / logic / 16-bit min-max;
-# 4.2 cycles: DPP, 32-bit min-max, compares, selects, lane reads), about two thirds / one third in the DP rows' ISA
+# 4.2 cycles: DPP, 32-bit min-max, compares, selects, lane reads) weighted by EACH KERNEL'S OWN instruction mix (tools/isa_cpi.py compiles the
+# sources here and classifies the listing; round 6 -- one constant for every kernel had k_conk at 106 % of its issue cycles); 2.9 where the
+# tool has no entry
 CPI = 2.9
+CPIK = {}
+try:
+    import subprocess, sys
+    sys.path.insert(0, "tools")
+    import isa_cpi
+    CPIK = {k: v["cycles_per_inst"] for k, v in isa_cpi.main()["kernels"].items()}
+except Exception as e_:
+    print("# tools/isa_cpi.py failed (%s): every kernel at %.1f cycles per instruction" % (e_, CPI))
 js = {"note": "tools/pmc_sq.sh $N $CFG: rocprofv3 --kernel-trace --pmc, SQ counters of the shipped build on tools/phase_prof.py", "cfg": "$CFG", "reads": $N,
-      "kernel_src_sha": hsh.hexdigest()[:16], "cycles_per_inst_assumed": CPI, "kernels": {}}
+      "kernel_src_sha": hsh.hexdigest()[:16], "cycles_per_inst_assumed": CPI, "cycles_per_inst_by_kernel": CPIK, "kernels": {}}
 val = defaultdict(dict); dur = {}
 for f in glob.glob("$R/p*/*results.db"):
     db = sqlite3.connect(f)
@@ -50,10 +60,12 @@ for n, d in sorted(val.items(), key=lambda t: -dur.get(t[0], 0)):
     kn = n.split("<")[0]
     if cyc and "SQ_INSTS_VALU" in d and kn not in js["kernels"]:
         ipc = d["SQ_INSTS_VALU"] / 1024.0 / cyc
+        wide = "true>" in n and kn == "k_poa"
+        cpi = CPIK.get("k_poa_wide" if wide else kn, CPI)
         js["kernels"][kn] = {"instance": n, "ms": dur[n] / 1e6, "insts_valu": d["SQ_INSTS_VALU"], "insts_salu": d.get("SQ_INSTS_SALU"), "kernel_cycles": cyc,
                              "cells": cells, "insts_per_cell": (d["SQ_INSTS_VALU"] / cells) if cells else None,
-                             "insts_per_simd_cycle": ipc, "busy_frac": ipc * CPI}
-        print("           vector issue: %.3f wave-instructions per SIMD cycle (%.2f GHz); x %.2f cycles per instruction = %.0f %% of the issue cycles" % (ipc, cyc / dur[n], CPI, 100 * ipc * CPI))
+                             "insts_per_simd_cycle": ipc, "cycles_per_inst": cpi, "busy_frac": ipc * cpi}
+        print("           vector issue: %.3f wave-instructions per SIMD cycle (%.2f GHz); x %.2f cycles per instruction (this kernel's listing) = %.0f %% of the issue cycles" % (ipc, cyc / dur[n], cpi, 100 * ipc * cpi))
 import json
 json.dump(js, open("$R/summary.json", "w"), indent=1)
 PY
