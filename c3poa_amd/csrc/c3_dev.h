@@ -60,6 +60,11 @@ __device__ __forceinline__ int wave_shl1(int v, int carry) {
   return __builtin_amdgcn_update_dpp(carry, v, 0x130, 0xf, 0xf, false);
 }
 
+// value of lane+1; lane 63 receives 0 (bound_ctrl: no register has to be preset)
+__device__ __forceinline__ int wave_shl1z(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true);
+}
+
 // three independent inclusive max-scans, interleaved step by step: a DPP instruction reading a register written by the
 // previous VALU instruction needs two wait states, which the other two chains fill
 __device__ __forceinline__ void wave_scan_max3(int& a, int& b, int& c) {

@@ -176,6 +176,12 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 #ifndef C3_NEAR
 #define C3_NEAR 1
 #endif
+#ifndef C3_STEADY
+#define C3_STEADY 1            /* steady rows (round 6); 0 = the round-5 row loop, instruction for instruction */
+#endif
+#ifndef C3_STEADY_FORK
+#define C3_STEADY_FORK 0       /* steady rows also for rows that a row further down reads (they write the ring at once) */
+#endif
 #ifndef C3_EXP_CALL_NARROW
 #define C3_EXP_CALL_NARROW 0   /* experiment: poa_align as a real call in the NARROW instances too */
 #endif
@@ -344,7 +350,7 @@ __device__ __forceinline__ int cv_9to16(int x9, int b8, int& bad) {
 // the first, a target outside the chunk is already final (one gather from hops[]), and the chains inside a chunk are
 // resolved by pointer doubling between lanes (ds_bpermute, at most six rounds).  Replaces log2(n) rounds of pointer jumping
 // over four node arrays in memory by four dependent memory levels per chunk.
-// descriptor A: x = node, y = ring slots (position mod PR) of the first four predecessors, 4 bits each, z = base | nin<<8 | far<<16 | (nin>4)<<17 | fast-row candidate<<18 | sink<<19, w = qr = Q - rem;
+// descriptor A: x = node, y = ring slots (position mod PR) of the first four predecessors, 4 bits each, z = base | nin<<8 | far<<16 | (nin>4)<<17 | fast-row candidate<<18 | sink<<19 | fork<<20, w = qr = Q - rem;
 // descriptor B: positions of the first four predecessors.  hops[] (by position) lives in col() (free until the MSA columns).
 __device__ void poa_sweep_desc(Ctx& c, int lane, int Q, bool qlds, const int PR) {
   const int n = c.n;
@@ -355,12 +361,14 @@ __device__ void poa_sweep_desc(Ctx& c, int lane, int Q, bool qlds, const int PR)
     const int v = live ? c.order()[idx] : SNK;
     const int nin = live ? c.n_in()[v] : 0, nout = live ? c.n_out()[v] : 0;
     int bw = INT32_MIN, bt = SNK;
-    unsigned far = 0;
+    unsigned far = 0, fork = 0;
     for (int k = 0; __builtin_amdgcn_ballot_w64(k < nout) != 0; ++k) {
       if (k < nout) {
         const int t = c.out_to()[EI(v, k)], ww = c.out_w()[EI(v, k)];
         if (ww > bw) { bw = ww; bt = t; }
-        if (t == SNK || c.index()[t] - idx > PR - 1) far = 1;
+        const int ti = t == SNK ? INT32_MAX : c.index()[t];
+        if (ti - idx > PR - 1) far = 1;
+        if (ti != idx + 1) fork = 1;                            // a reader of this row other than the row below (or the sink)
       }
     }
     unsigned p[4] = {0, 0, 0, 0};
@@ -380,7 +388,8 @@ __device__ void poa_sweep_desc(Ctx& c, int lane, int Q, bool qlds, const int PR)
       A.y = (p[0] % PR) | ((p[1] % PR) << 4) | ((p[2] % PR) << 8) | ((p[3] % PR) << 12);
       A.z = (unsigned)c.base()[v] | ((unsigned)min(nin, 255) << 8) | (far << 16) | ((unsigned)(nin > 4) << 17);
       // bit 18: candidate for the fast row (one predecessor, the row above; query in LDS); bit 19: the sink (no DP row)
-      A.z |= ((unsigned)(qlds && nin == 1 && (int)p[0] == idx - 1 && v != SRC && v != SNK) << 18) | ((unsigned)(v == SNK) << 19);
+      // bit 20: some row other than the next one reads this row's cells (the steady row keeps them out of the LDS ring otherwise)
+      A.z |= ((unsigned)(qlds && nin == 1 && (int)p[0] == idx - 1 && v != SRC && v != SNK) << 18) | ((unsigned)(v == SNK) << 19) | (fork << 20);
       A.w = (unsigned)(Q - (d - 1));                         // qr: the query column this node would sit on by distance to the sink
       uint4 B; B.x = p[0]; B.y = p[1]; B.z = p[2]; B.w = p[3];
       c.descA()[idx] = A; c.descB()[idx] = B;
@@ -462,6 +471,20 @@ __device__ __forceinline__ int poa_align(Ctx& c, const C3Params& P, int qb, int 
   unsigned long long row_t0 = __builtin_readcyclecounter();
 #endif
   int slot = PR - 1;                                                                   // ring slot of the row: position mod PR
+  // steady rows (round 6, below): the previous row's band in SCALAR registers, the query window of the lanes, what the ring still lacks
+  bool st_on = false, ring_stale = false;
+  int s_beg = 0, s_end = 0, s_left = 0, s_right = 0, s_ro = 0, s_idx0 = 0;
+  unsigned qw = 0;
+  // band records (begin, end, cell offset: what the traceback reads) of a run of steady rows, rows s_idx0 .. iend - 1, written when the run
+  // ends -- one lane per row: within a run the band moves one column per row and the width stays, so the last row's record gives them all
+  // (a lane-0 store per row cost three scalar-to-vector moves, the address arithmetic and an EXEC switch in every steady row)
+  auto steady_rowm = [&](int iend) {
+    const int R = iend - s_idx0, swd = s_end - s_beg + 1;
+    for (int t0 = 0; t0 < R; t0 += 64) {
+      const int t = t0 + lane;
+      if (t < R) { int* rm = c.rowm() + 3 * (iend - 1 - t); rm[0] = s_beg - t; rm[1] = s_end - t; rm[2] = s_ro - swd * (t + 1); }
+    }
+  };
   for (int ib = 0; ib < n; ib += 64) {
   uint4 dA = c.descA()[min(ib + lane, n - 1)], dB = c.descB()[min(ib + lane, n - 1)];
   asm volatile("" : "+v"(dA.x), "+v"(dA.y), "+v"(dA.z), "+v"(dA.w), "+v"(dB.x), "+v"(dB.y), "+v"(dB.z), "+v"(dB.w));   // wait here, not in the row loop
@@ -487,6 +510,84 @@ __device__ __forceinline__ int poa_align(Ctx& c, const C3Params& P, int qb, int 
     // row, must be idle when the band did not move)
     // (DIRECTION BYTE, all rows): bit0 E1 opened (0 = extended), bit1 E2 opened, bits2-3 Ht source (2 M, 1 E1, 0 E2),
     // bits4-5 H source (2 Ht, 1 F1, 0 F2), bit6 F1 extended, bit7 F2 extended.
+#if C3_STEADY
+    // ---- STEADY ROW (round 6): a fast row whose band is the previous row's moved ONE column to the right at both ends -- 83 % of the
+    // fast rows at cfg2 (66 % of all rows), 68 % at cfg4 (29 %): tools/poa_run_lengths.py.  What the fast row spends on the general case is
+    // then known in advance and the scalar unit only CHECKS it (a dozen scalar instructions instead of 27 vector ones): beg = s_beg + 1,
+    // end = s_end + 1, the same width, shift 1.  With shift 1 the cell above sits one lane to the right (a DPP move instead of ds_bpermute
+    // and its addresses) and the diagonal in the lane itself; the query bases of the lane's next 16 columns ride in one register (a shift
+    // per row, refilled every 16 rows, instead of an LDS lookup per row); the band records of a run are written when it ends
+    // (steady_rowm); and a row whose cells nobody but the next row reads (descriptor bit 20 clear) writes nothing to the LDS ring -- when
+    // the NEXT row turns out not to be a fast / steady row, the cells still in registers go there then (ring_stale, below).  Rows with a
+    // successor beyond the ring (far) keep the fast row.  The arithmetic of the cells is the fast row's, instruction for instruction.
+    if (!W32 && !WIDE && ((fl & ((1 << 16) | (1 << 18) | (1 << 19) | (C3_STEADY_FORK ? 0 : 1 << 20))) == (1 << 18)) && pv_ok) {
+      if (!st_on) { s_beg = wave_first(u_beg); s_end = wave_first(u_end); s_left = wave_first(u_left); s_right = wave_first(u_right); s_ro = wave_first(u_ncell); s_idx0 = idx; }
+      const int qr1 = qr - 1, wd = s_end - s_beg + 1;
+      if (min(s_left, qr1) == s_beg + w && s_end < Q && max(s_right, qr1) >= s_end - w && (unsigned)(wd - 1) < 63u && s_ro + 64 <= c.cells_cap) {
+        const int beg = s_beg + 1, end = s_end + 1, ro = s_ro;
+        // the lane's next 16 query bases (columns beg + lane - 1 ...): fetched on entering a run and wherever the band start crosses a
+        // multiple of 16 -- never more than 16 rows apart, no counter
+        if (!st_on || (s_beg & 15) == 0) {
+          const int cq = s_beg + lane;
+          const unsigned w0 = Lqpk[min(cq >> 4, PQW - 1)], w1 = Lqpk[min((cq >> 4) + 1, PQW - 1)];
+          qw = __builtin_amdgcn_alignbit(w1, w0, (unsigned)(cq & 15) * 2);
+        }
+        st_on = true;
+        const unsigned long long am = __ballot(lane < wd);                 // active lanes: ONE compare, every select below names this mask
+#define SEL(a, b) ({ int d_; asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d_) : "v"(b), "v"(a), "s"(am)); d_; })      /* act ? a : b */
+        const int qc = (int)(qw & 3u);
+        qw >>= 2;
+        // the cells above sit one lane to the right; the vertical candidates are formed in the lane that holds them and THEN moved: two DPP
+        // moves instead of three (lane 63 reads 0: it is never active -- wd <= 63 -- and every result of an inactive lane is replaced below)
+        const int E1t = wave_shl1z(maxu16(pH - (oe1_8 - 1), pE1 - e1_8));
+        const int E2t = wave_shl1z(maxu16(pH - (oe2_8 - 2), pE2 - e2_8));
+        const int M = pH + ((vb == qc) ? mt8 + 2 : mm8 + 2);
+        const int E1c = E1t & ~7, E2c = E2t & ~7;
+        const int k2 = maxu16(maxu16(M, E1c + 1), E2c);
+        const int ht = k2 & ~7;
+        const int c_neg2 = NEG2_16, c_neg = NEG16;
+        const int htm = SEL(ht, c_neg2);
+        int s1 = htm + le1_8, s2 = htm + le2_8, s3 = htm;
+        wave_scan_max3(s1, s2, s3);
+        const int px1 = wave_shr1(s1, NEG2_16), px2 = wave_shr1(s2, NEG2_16);
+        const int htl = wave_shr1(htm, NEG16);
+        const int f1 = px1 - lo1_8, f2 = px2 - lo2_8;
+        const int k3 = maxu16(maxu16(ht + 2, f1 + 1), f2);
+        const int h = k3 & ~7;
+        unsigned d = ((unsigned)E1t & 1u) | ((unsigned)E2t & 2u) | (((unsigned)k2 & 3u) << 2) | (((unsigned)k3 & 3u) << 4);
+        d |= (((unsigned)(htl - oe1_8 - f1)) >> 25) & 64u;
+        d |= (((unsigned)(htl - oe2_8 - f2)) >> 24) & 128u;
+        const int rb = __builtin_amdgcn_readlane(s3, 63);
+        const unsigned long long mxm = __ballot(htm == rb);
+        const int left = beg + __builtin_ctzll(mxm), right = beg + (63 - __builtin_clzll(mxm));
+        pH = maxu16(SEL(h, c_neg), FLOOR16); pE1 = SEL(E1c, c_neg); pE2 = SEL(E2c, c_neg);
+        if ((unsigned)(rb - RB_LO16) > (unsigned)c.rb_span) {         // rare: the base follows the row maximum (see the fast row)
+          const int m1 = rb - BIAS16, fl1 = FLOOR16 + max(m1, 0);
+          u_b8 += m1; punt |= (int)(rb < GLO16);
+          const int a_ = maxu16(h, fl1) - m1, b_ = maxu16(E1c, fl1) - m1, c_ = maxu16(E2c, fl1) - m1;
+          pH = SEL(a_, c_neg); pE1 = SEL(b_, c_neg); pE2 = SEL(c_, c_neg);
+        }
+#undef SEL
+        gacc = minu16(gacc, pH - (ZHI16 + 1));
+        c.D8()[(unsigned)(ro + lane)] = (uint8_t)d;
+        // (the row's band record: written for the whole run when it ends -- steady_rowm)
+        if ((fl >> 20) & 1) {                                             // a row further down reads this one: into the ring at once, as the fast row does
+          const int cb = slot * PWT + PADL + lane;
+          LH[cb] = (unsigned short)pH; LE1[cb] = (unsigned short)pE1; LE2[cb] = (unsigned short)pE2;
+#pragma unroll
+          for (int f = 1; f < NCHMAX; ++f) { LH[cb + 64 * f] = NEG16; LE1[cb + 64 * f] = NEG16; LE2[cb + 64 * f] = NEG16; }
+          if (lane == 0) { L.meta[slot] = make_int4(beg, end, left, right); L.base8[slot] = u_b8; }
+          ring_stale = false;
+        } else ring_stale = true;
+        s_beg = beg; s_end = end; s_left = left; s_right = right; s_ro = ro + wd;
+#ifdef C3_PHASE_PROF
+        { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[12] += t_ - row_t0; row_t0 = t_; ph_acc_[13] += 1; }
+#endif
+        continue;
+      }
+    }
+    if (st_on) { steady_rowm(idx); u_beg = s_beg; u_end = s_end; u_left = s_left; u_right = s_right; u_ncell = s_ro; st_on = false; }      // leaving the steady rows
+#endif
     if (!W32 && ((fl >> 18) & 1) && pv_ok) {
       UNI(u_beg); UNI(u_end); UNI(u_left); UNI(u_right); UNI(u_ncell);
       const bool nonempty = u_end >= u_beg;
@@ -562,12 +663,31 @@ __device__ __forceinline__ int poa_align(Ctx& c, const C3Params& P, int qb, int 
           u_nfar = fo + wave_first(wd);
         }
         u_beg = beg; u_end = end; u_left = left; u_right = right; u_ncell = ro + wd; u_b8 = nb8;
+#if C3_STEADY
+        ring_stale = false;                          // (this row is in the ring; the one before it has no other reader)
+#endif
 #ifdef C3_PHASE_PROF
-        { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[8] += t_ - row_t0; row_t0 = t_; }
+        { unsigned long long t_ = __builtin_readcyclecounter(); ph_acc_[8] += t_ - row_t0; row_t0 = t_; ph_acc_[14] += 1; }
 #endif
         continue;
       }
     }
+#if C3_STEADY
+    if (ring_stale) {
+      // the previous row was a steady row and this one reads the ring: its cells (still in registers) and band record go there now,
+      // exactly as the fast row's tail would have written them
+      const int ps = slot == 0 ? PR - 1 : slot - 1;
+      const int cb = ps * PWT + PADL + lane;
+      LH[cb] = (unsigned short)pH; LE1[cb] = (unsigned short)pE1; LE2[cb] = (unsigned short)pE2;
+#pragma unroll
+      for (int f = 1; f < NCHMAX; ++f) { LH[cb + 64 * f] = NEG16; LE1[cb + 64 * f] = NEG16; LE2[cb + 64 * f] = NEG16; }
+      if (lane == 0) { L.meta[ps] = make_int4(u_beg, u_end, u_left, u_right); L.base8[ps] = u_b8; }
+      ring_stale = false;
+#ifdef C3_PHASE_PROF
+      ph_acc_[15] += 1;
+#endif
+    }
+#endif
     const int v = __builtin_amdgcn_readlane(dA.x, li);
     const int nin = (fl >> 8) & 0xff;
     const bool ovf = (fl >> 17) & 1;
@@ -972,6 +1092,9 @@ __device__ __forceinline__ int poa_align(Ctx& c, const C3Params& P, int qb, int 
     pH = gH; pE1 = gE1; pE2 = gE2; pv_ok = inl && wd <= 64;
   }
   }
+#if C3_STEADY
+  if (st_on) { steady_rowm(n); u_ncell = s_ro; st_on = false; }              // (cannot happen: the rows before the sink have an edge to it and are not steady)
+#endif
   WSYNC();
   *cells += wave_first(u_ncell);
   PH_MARK(1)

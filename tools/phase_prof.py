@@ -40,4 +40,8 @@ for which, kn in ((0, "k_poa"), (1, "k_window")):
             print("   band traceback: %d blocks, load+sync %.0f cycles per block (%.1f%% of the wave time), %.1f steps per block, %.0f cycles per step (%.1f%%)" % (
                 out[12], out[13] / out[12], 100.0 * out[13] / tot, out[14] / out[12], out[15] / max(out[14], 1), 100.0 * out[15] / tot))
     if which == 0 and out[1]:
-        print("   DP rows by kind (cycles): fast %.1f%%, near %.1f%%, general %.1f%% of the row loop" % tuple(100.0 * out[i] / max(out[8] + out[10] + out[11], 1) for i in (8, 10, 11)))
+        rc = max(out[8] + out[10] + out[11] + out[12], 1)
+        print("   DP rows by kind (cycles): steady %.1f%%, fast %.1f%%, near %.1f%%, general %.1f%% of the row loop" % tuple(100.0 * out[i] / rc for i in (12, 8, 10, 11)))
+        if out[13] or out[14]:
+            print("   steady rows %d (%.0f cycles each), fast rows %d (%.0f cycles each), ring flushes after a steady run %d" % (
+                out[13], out[12] / max(out[13], 1), out[14], out[8] / max(out[14], 1), out[15]))
