@@ -178,6 +178,8 @@ struct c3_handle {
   // the LAST POA pass (a handful of reads whose bands blew up: a workgroup of eight waves each, >100 ms on four CUs) runs on a stream of
   // its own beside k_prep / k_window of every other read; the stragglers are polished by a small tail afterwards (run_tail)
   hipStream_t stream_mw = nullptr; hipEvent_t ev_mw[2] = {nullptr, nullptr}; DBuf d_counter_mw, d_work_main;
+  // k_window's full-size launch as a consumer beside the first launch (round 6): its stream, "inputs ready" / "consumer done"
+  hipStream_t stream_w2 = nullptr; hipEvent_t ev_w2[2] = {nullptr, nullptr}; int win_consumers = 0;
   std::vector<int> strag, work_main; bool tail_pending = false;
   int n_poa_redo = 0;        // reads of the last run that needed the full-size second POA pass
   int n_poa_redo16 = 0;      // ... of them: because a score left the 16-bit cells
@@ -253,6 +255,8 @@ extern "C" int c3_create(const c3_config* cfg, c3_handle** out) {
   if ((e = hipStreamCreate(&h->stream_dn)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   if ((e = hipStreamCreate(&h->stream_mw)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   for (int i = 0; i < 2; ++i) if ((e = hipEventCreate(&h->ev_mw[i])) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  if ((e = hipStreamCreate(&h->stream_w2)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
+  for (int i = 0; i < 2; ++i) if ((e = hipEventCreateWithFlags(&h->ev_w2[i], hipEventDisableTiming)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   if ((e = hipEventCreateWithFlags(&h->ev_dn, hipEventDisableTiming)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   if ((e = hipHostMalloc((void**)&h->h_tot, 64, hipHostMallocDefault)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   for (int i = 0; i < 2; ++i) if ((e = hipEventCreate(&h->ev_up[i])) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
@@ -269,6 +273,8 @@ extern "C" void c3_destroy(c3_handle* h) {
   if (h->stream_dn) { (void)hipStreamSynchronize(h->stream_dn); (void)hipStreamDestroy(h->stream_dn); }
   if (h->stream_mw) { (void)hipStreamSynchronize(h->stream_mw); (void)hipStreamDestroy(h->stream_mw); }
   for (int i = 0; i < 2; ++i) if (h->ev_mw[i]) (void)hipEventDestroy(h->ev_mw[i]);
+  if (h->stream_w2) { (void)hipStreamSynchronize(h->stream_w2); (void)hipStreamDestroy(h->stream_w2); }
+  for (int i = 0; i < 2; ++i) if (h->ev_w2[i]) (void)hipEventDestroy(h->ev_w2[i]);
   h->d_counter_mw.release(); h->d_work_main.release();
   if (h->ev_dn) (void)hipEventDestroy(h->ev_dn);
   if (h->h_tot) (void)hipHostFree(h->h_tot);
@@ -874,18 +880,40 @@ static int run_polish(c3_handle* h, const std::vector<int>& work, const int* d_w
     a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
     if (const char* e = getenv("C3_DEBUG_BAND")) a.band_mode = !strcmp(e, "off") ? 1 : !strcmp(e, "fail") ? 2 : !strcmp(e, "verify") ? 3 : 0;    // test hook (tests/test_gpu_band.py)
     a.ovf_list = h->d_wovf.as<int>();
-    c3k_launch_window(&a, slots, h->stream);
-    HIPCHK(hipGetLastError());
-    if (getenv("C3_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(h->stream)); DBG("window: first launch done\n"); }
-    {
-      a.ibase = h->s_win_i2.as<int>(); a.ebase = h->s_win_nk2.as<int>(); a.base = h->s_win_b2.as<uint8_t>(); a.score = h->s_win_sc2.as<long long>();
-      a.rdesc = h->s_win_desc2.as<uint4>(); a.Ncap = Ncap2; a.Lcap = std::min(a.Lcap, Ncap2);
-      a.H = h->s_win_h2.as<int32_t>(); a.D = h->s_win_d2.as<uint16_t>(); a.hcap = hcap2;
-      a.wlist = h->d_wovf.as<int>(); a.n_win_dev = h->d_counter.as<int>() + W_CNT_OVF; a.ovf_list = nullptr;
-      c3k_launch_window(&a, slots2, h->stream);
+    // Three launches (round 6).  (1) on stream_w2, FIRST, so that its few waves are resident before the first launch fills the device: the
+    // full-size kernel as a consumer of the overflow list (every entry -1, the flag 0), a few waves, each of which costs one SIMD one
+    // of its six first-launch waves (twice the number of windows the previous run handed over, 16..256: enough to take every window at once
+    // when batches resemble each other, cheap when there are none).  (2) the first launch; behind it, on its stream, the flag.  (3) the
+    // full-size kernel once more, in list + count mode, for whatever the consumers left (they stop taking tickets at the flag) -- when nothing
+    // is left, its waves take one ticket each and exit.  C3_NO_WIN_CONSUMER=1: launches (2) and (3) only, the order of round 5
+    WinArgs a2 = a;
+    a2.ibase = h->s_win_i2.as<int>(); a2.ebase = h->s_win_nk2.as<int>(); a2.base = h->s_win_b2.as<uint8_t>(); a2.score = h->s_win_sc2.as<long long>();
+    a2.rdesc = h->s_win_desc2.as<uint4>(); a2.Ncap = Ncap2; a2.Lcap = std::min(a.Lcap, Ncap2);
+    a2.H = h->s_win_h2.as<int32_t>(); a2.D = h->s_win_d2.as<uint16_t>(); a2.hcap = hcap2;
+    a2.wlist = h->d_wovf.as<int>(); a2.n_win_dev = h->d_counter.as<int>() + W_CNT_OVF; a2.ovf_list = nullptr; a2.done_flag = nullptr;
+    const bool consumer = !getenv("C3_NO_WIN_CONSUMER") && !getenv("C3_DEBUG_SYNC");
+    HIPCHK(hipMemsetAsync(h->d_wovf.p, 0xff, sizeof(int) * (size_t)n_win, h->stream));
+    if (consumer) {
+      int nc = h->win_consumers > 0 ? h->win_consumers : 32;
+      if (const char* e = getenv("C3_DEBUG_WIN_CONSUMERS")) nc = atoi(e);
+      nc = std::max(1, std::min(std::min(nc, 256), slots2));
+      WinArgs ac = a2; ac.done_flag = h->d_counter.as<int>() + W_CNT_DONE;
+      HIPCHK(hipEventRecord(h->ev_w2[0], h->stream));
+      HIPCHK(hipStreamWaitEvent(h->stream_w2, h->ev_w2[0], 0));
+      c3k_launch_window(&ac, nc, h->stream_w2);
       HIPCHK(hipGetLastError());
-      if (getenv("C3_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(h->stream)); DBG("window: full-size launch done\n"); }
+      HIPCHK(hipEventRecord(h->ev_w2[1], h->stream_w2));
     }
+    c3k_launch_window(&a, slots, h->stream);
+    { const hipError_t le = hipGetLastError();
+      // (whatever happened to the first launch: the flag goes out, or the consumers wait for their whole bounded spin)
+      (void)hipMemsetAsync(h->d_counter.as<int>() + W_CNT_DONE, 0x01, sizeof(int), h->stream);
+      if (consumer) (void)hipStreamWaitEvent(h->stream, h->ev_w2[1], 0);
+      HIPCHK(le); }
+    if (getenv("C3_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(h->stream)); DBG("window: first launch done\n"); }
+    c3k_launch_window(&a2, slots2, h->stream);
+    HIPCHK(hipGetLastError());
+    if (getenv("C3_DEBUG_SYNC")) { HIPCHK(hipStreamSynchronize(h->stream)); DBG("window: full-size launch done\n"); }
     HIPCHK(hipMemcpyAsync(h->phase_win, h->d_counter.as<char>() + 64, 128, hipMemcpyDeviceToHost, h->stream));
   }
   HIPCHK(hipEventRecord(h->ev[8], h->stream));
@@ -901,7 +929,7 @@ static int run_polish(c3_handle* h, const std::vector<int>& work, const int* d_w
   HIPCHK(hipMemcpyAsync(cnt_all, h->d_counter.p, 256, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   memcpy(cnt, cnt_all, 64);
-  if (n_win > 0) h->tm.n_win_redo += cnt_all[W_CNT_OVF];
+  if (n_win > 0) { h->tm.n_win_redo += cnt_all[W_CNT_OVF]; h->win_consumers = std::max(16, std::min(256, 2 * cnt_all[W_CNT_OVF])); }
   if (n_win > 0) DBG("window: second launch %d; given up: backbone %d scratch %d nodes %d consensus %d\n", cnt_all[W_CNT_OVF], cnt_all[W_CNT_WHY], cnt_all[W_CNT_WHY + 1], cnt_all[W_CNT_WHY + 2], cnt_all[W_CNT_WHY + 3]);
   if (n_win > 0) { h->tm.cells_polish += *(long long*)(cnt + 2); h->tm.cells_polish_computed += *(long long*)(cnt + 4); h->tm.n_band_layers += cnt[6]; h->tm.n_band_fallback += cnt[7]; h->tm.n_band_mismatch += cnt[8]; if (cnt[8]) fprintf(stderr, "c3poa: band verify mismatch in window %d layer %d (R = %d): last differing base q = %d, band row %d, full row %d, row of q+1 = %d\n", cnt[9], cnt[10], cnt[11], cnt[12], cnt[13], cnt[14], cnt[15]); }
   { float a_, b_, c_;

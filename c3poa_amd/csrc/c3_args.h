@@ -46,12 +46,19 @@ struct WinArgs {
   // takes its windows from `wlist`, their number from device memory (`n_win_dev`) and its queue from counter[W_CNT_Q2]
   // (k_window<true>: the first launch's code carries none of this)
   const int* wlist; const int* n_win_dev; int* ovf_list;
+  // round 6: done_flag != nullptr makes the second launch a CONSUMER that runs beside the first one on a stream of its own: a few resident waves
+  // claim an entry of the list whenever it holds one they have not taken (CAS on counter[W_CNT_Q2] against counter[W_CNT_OVF]), sleep otherwise,
+  // and stop when the flag is set (by the host, on the first launch's stream, behind that launch) and the list is empty.  A third, ordinary
+  // launch (done_flag = nullptr) mops up what they left
+  const int* done_flag;
   // output of the second launch: entry q of its queue writes wout2 + q * wout2_cap (a window consensus can be as long as the graph has
   // nodes; the first launch's slots hold 3 windows + 64 and hand longer ones over); WinRec::pad_ = q + 1 tells k_stitch where to look
   uint8_t* wout2; int wout2_cap, wout2_n;
 };
 #define W_CNT_OVF 48                      /* d_counter ints: [0] queue of the first launch, [48] overflow count, [49] queue of the second */
 #define W_CNT_Q2 49
+#define W_CNT_START 55                    /* [55] raised by every wave of the first launch: the consumer beside it only waits for a launch that runs */
+#define W_CNT_DONE 54                     /* [54] set by the host behind the first launch: its overflow list is complete */
 #define W_CNT_WHY 50                      /* [50..53] windows given up: backbone longer than the output slot, DP scratch, graph nodes, consensus length */
 struct StitchArgs {
   C3Batch b; C3Info* info; const int* work; int n_work; const WinRec* wrec; const int* win_base; const uint8_t* wout; int wout_cap; char* cons;

@@ -1096,6 +1096,9 @@ __device__ __forceinline__ int win_consensus(WCtx& c, int* s_score, unsigned sho
 // row loops (76 ms).
 // Round 5: the first launch at SIX waves per SIMD (80 VGPRs; five LDS granules of 1 280 bytes): 30.9 -> 28.4 ms (cfg2), 59.1 -> 54.4 (cfg4),
 // 33.9 -> 31.1 (cfg3).  Round 4 had measured "6 waves: nothing" -- with 6 656 bytes of LDS, i.e. six granules and 21 resident waves.
+#ifndef C3_BAND_THIN
+#define C3_BAND_THIN 48        /* certificate margin (score units) below which the next layer of the window starts one band wider */
+#endif
 #ifndef C3_WIN_WAVES
 #define C3_WIN_WAVES 6
 #endif
@@ -1121,11 +1124,37 @@ __global__ __launch_bounds__(64, SECOND ? C3_WIN_WAVES2 : C3_WIN_WAVES) void k_w
   unsigned long long* d0bits = mabits + MW; unsigned long long* d1bits = d0bits + MW;         // band shift bits of every DP row (banded layers)
   const int lds_ints = (int)(win_lds_bytes(a.Lcap, a.Ncap, !SECOND) / 4);    // = the launch's dynamic LDS
   PH_DECL
+  if (!SECOND && lane == 0) a.counter[W_CNT_START] = 1;       // (for the consumer launch beside this one: see below)
 
   for (;;) {
     int wi = 0, qi = 0;
     if (lane == 0) {
-      if (SECOND) {                                 // the windows the first launch could not hold: list and count in device memory
+      if (SECOND && a.done_flag) {
+        // consumer beside the first launch (round 6): a window that overflows there used to wait for that launch to drain and then ran ALONE on
+        // an idle device -- 1.5-8 ms of single-wave latency behind every batch (2 ms of cfg2's 81, 16 of cfg4's 591, more on noisy reads).  Now
+        // it is picked up while the first launch still runs: an entry is claimed (CAS on the queue head) only when the list holds one, so a
+        // consumer that gives up -- the flag "no further entry will come" is set by the host behind the first launch; the wait is bounded all
+        // the same: a host that never sets it costs seconds, not a hung device -- leaves nothing half taken for the launch that mops up
+        wi = -1;
+        // ... and first of all it must see the first launch RUNNING (every wave of it raises counter[W_CNT_START]): when the two kernels do not
+        // overlap -- the first k_window launch of a process waits for the queue's scratch to be (re)allocated, which waits for this kernel;
+        // counter passes of a profiler serialise dispatches -- half a millisecond is all this launch may cost
+        bool started = false;
+        for (int it = 0; it < 256 && !(started = *(const volatile int*)(a.counter + W_CNT_START) != 0); ++it) __builtin_amdgcn_s_sleep(16);
+        for (int it = 0; started && it < (1 << 20); ++it) {
+          const int done = *(const volatile int*)a.done_flag;          // (read BEFORE the count: with the flag set the count is final)
+          const int nl_ = *(const volatile int*)a.n_win_dev, q = *(const volatile int*)(a.counter + W_CNT_Q2);
+          if (q < nl_) {
+            if (atomicCAS(a.counter + W_CNT_Q2, q, q + 1) != q) continue;
+            qi = q;
+            // (the producer takes its index first and writes the entry right after: a moment, but not none)
+            for (int it2 = 0; it2 < (1 << 20) && (wi = *(const volatile int*)(a.wlist + q)) < 0; ++it2) __builtin_amdgcn_s_sleep(2);
+            break;
+          }
+          if (done) break;
+          __builtin_amdgcn_s_sleep(64);
+        }
+      } else if (SECOND) {                          // the windows the first launch could not hold: list and count in device memory
         qi = wi = atomicAdd(a.counter + W_CNT_Q2, 1);
         wi = wi < *(const volatile int*)a.n_win_dev ? a.wlist[wi] : -1;
       } else {
@@ -1148,6 +1177,13 @@ __global__ __launch_bounds__(64, SECOND ? C3_WIN_WAVES2 : C3_WIN_WAVES) void k_w
     const WLayer* lay = a.wlay + (size_t)wi * a.NLcap;
     long long cells = 0, cells_done = 0;          // cells of the full matrices (what the oracle counts) / cells actually computed
     int olen = 0, polished = 0, fail = 0, n_band = 0, n_fallback = 0;
+    // band width the NEXT layer of this window starts with (cells per lane; the inflation rule of win_rows_dispatch is a floor under it).
+    // The layers of a window come from one read and share its error rate, and that -- not the graph -- is what the certificate's margin
+    // depends on: an optimal path scores ~2.25 per column at 10 % errors and ~1.9 at 15 %, the bound of a path that leaves the band assumes 3
+    // for everything still to come, so noisier reads need the wider band's deeper edge cells.  At 15 % errors 27 % of the layers failed the
+    // 128-column band and ALL of them passed at 192 (tools/experiments/band_stats.py): a layer that fails, or passes with a thin margin, sends
+    // the layers after it straight to the width it needed.  A hint only: every accepted band reproduces the full matrix.
+    int cb_hint = 1;
     if (nl + 1 < 3) {
       if (blen > ocap) { fail = SECOND ? 1 : 2; if (SECOND && lane == 0) atomicAdd(a.counter + W_CNT_WHY, 1); }
       else { for (int i = lane; i < blen; i += 64) out[i] = bb[i]; olen = blen; }
@@ -1278,7 +1314,7 @@ __global__ __launch_bounds__(64, SECOND ? C3_WIN_WAVES2 : C3_WIN_WAVES) void k_w
         unsigned long long tbp_[4] = {0, 0, 0, 0};
         bool verify = false;
         for (int vpass = 0; vpass < 2 && !fail; ++vpass) {
-        int cpl = 0, RS = 0, cb = a.band_mode != 1 && vpass == 0, gbs = INT32_MIN, gbr = 0;
+        int cpl = 0, RS = 0, cb = (a.band_mode != 1 && vpass == 0) ? (a.band_mode == 0 ? cb_hint : 1) : 0, gbs = INT32_MIN, gbr = 0;
         for (int attempt = 0; attempt < 4; ++attempt) {
           unsigned long long dbg_[6] = {0, 0, 0, 0, 0, 0};
           int nblocks = 0;
@@ -1298,7 +1334,11 @@ __global__ __launch_bounds__(64, SECOND ? C3_WIN_WAVES2 : C3_WIN_WAVES) void k_w
 #ifdef C3_EXP_NOCERT
             if (cb) { ++n_band; break; }
 #endif
-            if (gbs != INT32_MIN && bound < gbs && a.band_mode != 2) { ++n_band; break; }
+            if (gbs != INT32_MIN && bound < gbs && a.band_mode != 2) {
+              ++n_band;
+              if (a.band_mode == 0 && C3_BAND_THIN >= 0) cb_hint = (gbs - bound < C3_BAND_THIN && cb < 4) ? cb + 1 : cb;      // accepted by a thin margin: the next layer one wider
+              break;
+            }
           } else {
             int bs = INT32_MIN, br = INT32_MAX / 2;
             for (int r = 1 + lane; r <= R; r += 64) { const int sc = c.hend()[r]; if (sc > bs) { bs = sc; br = r; } }
@@ -1309,6 +1349,7 @@ __global__ __launch_bounds__(64, SECOND ? C3_WIN_WAVES2 : C3_WIN_WAVES) void k_w
           // a failed certificate: one more try with the next wider band (half again / twice the margin for the bounds, still well
           // below the full matrix), then the full matrix
           ++n_fallback; cb = (cb < 4 && a.band_mode == 0) ? cb + 1 : 0;
+          if (a.band_mode == 0 && C3_BAND_THIN >= 0) cb_hint = cb ? cb : 4;
         }
         if (fail) break;
         cells += (long long)(R + 1) * (Q + 1);

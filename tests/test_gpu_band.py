@@ -117,6 +117,38 @@ def test_tiny_first_launch_scratch_sends_every_window_to_the_second_launch(monke
         assert t1[k] == t0[k], k
 
 
+@pytest.mark.parametrize("consumers", ["1", "7", "256", "off"])
+def test_full_size_launch_as_a_consumer_beside_the_first_one(monkeypatch, consumers):
+    """round 6: k_window's full-size launch runs BESIDE the first launch (a few resident waves on a stream of their own claim the windows
+    the first launch hands over while it is still running; a third launch mops up).  With the tiny first-launch scratch every window takes
+    that road: one consumer wave, a few, many, or none at all (C3_NO_WIN_CONSUMER: the serial order of round 5) -- the same bytes, the same
+    counters, and a second batch on the same handle (the consumer count follows the previous batch's overflow)"""
+    recs = list(synth.generate("cfg2e15", n_reads=64)) + list(synth.generate("cfg3", n_reads=32, start=700))
+    want, wcons, t0 = _run(recs, 500, None)
+    ores, ocons = O.process_batch(synth.SPLINT1, [(r[1], r[2]) for r in recs], [r[3] for r in recs], threads=8)
+    assert wcons == ocons
+    monkeypatch.setenv("C3_DEBUG_HCAP_DIV", "100000")
+    if consumers == "off":
+        monkeypatch.setenv("C3_NO_WIN_CONSUMER", "1")
+    else:
+        monkeypatch.setenv("C3_DEBUG_WIN_CONSUMERS", consumers)
+    got, gcons, t1 = _run(recs, 500, None)
+    assert gcons == wcons and np.array_equal(got["status"], want["status"]) and np.array_equal(got["cons_len"], want["cons_len"])
+    assert t1["n_win_redo"] >= 0.9 * t1["n_windows"] > 0
+    for k in ("cells_polish", "cells_polish_computed", "n_band_layers", "n_band_fallback", "n_windows"):
+        assert t1[k] == t0[k], k
+    # two batches through one handle
+    monkeypatch.delenv("C3_DEBUG_WIN_CONSUMERS", raising=False)
+    from c3poa_amd import _lib
+    h = _lib.Handle(mdistcutoff=500)
+    h.set_splints([synth.SPLINT1])
+    for _ in range(2):
+        h.upload([r[1] for r in recs], [r[2] for r in recs], [r[3] for r in recs])
+        h.run()
+        assert h.results()[1] == wcons
+    h.close()
+
+
 def test_results_do_not_depend_on_what_fresh_device_memory_holds(monkeypatch):
     """every device buffer poisoned at allocation (C3_DEBUG_POISON): nothing may read a scratch cell it did not write -- with the
     usual scratch and with the tiny first-launch scratch that sends the windows through the abort + second-launch path"""

@@ -5,6 +5,8 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 N=${1:-32768}; CFG=${2:-cfg2}; R=gpurun_out/pmcmem_$CFG; rm -rf $R; mkdir -p $R
 export C3_REPS=1
+# (counter passes serialise kernel dispatch: k_window's consumer beside the first launch (round 6) would only wait out its bounded spin)
+export C3_NO_WIN_CONSUMER=1
 GROUPS_=(
  "TA_TA_BUSY_sum TA_BUSY_avr GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"
  "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TOTAL_ACCESSES_sum"

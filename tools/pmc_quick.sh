@@ -3,6 +3,8 @@
 cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 N=${1:-32768}; R=${2:-gpurun_out/pmcq}; rm -rf $R; mkdir -p $R
 export C3_REPS=1
+# (counter passes serialise kernel dispatch: k_window's consumer beside the first launch (round 6) would only wait out its bounded spin)
+export C3_NO_WIN_CONSUMER=1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 200 rocprofv3 --kernel-trace --pmc $c -d $R/$c -o b -- python3 tools/phase_prof.py $N > $R/$c.log 2>&1
 done

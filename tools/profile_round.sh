@@ -12,7 +12,10 @@ R=gpurun_out/${TAG}_${CFG}; rm -rf $R; mkdir -p $R
 ARGS="--cfg $CFG --steps 1 --warmup 0 --no-cpu --other-configs none $*"
 echo "python3 bench.py $ARGS" > $R/command.txt
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/stats -o s -- python3 bench.py $ARGS > $R/bench_stats.json 2> $R/stats.err
+# (counter passes serialise kernel dispatch: k_window's consumer beside the first launch (round 6) would only wait out its bounded spin)
+export C3_NO_WIN_CONSUMER=1
 timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $R/fetch -o b -- python3 bench.py $ARGS > $R/bench_fetch.json 2> $R/fetch.err
 timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $R/write -o b -- python3 bench.py $ARGS > $R/bench_write.json 2> $R/write.err
+unset C3_NO_WIN_CONSUMER
 python3 bench.py --cfg $CFG --steps 3 --warmup 2 $* > $R/bench.json 2> $R/bench.err
 ls -la $R $R/stats | head -30
