@@ -178,8 +178,11 @@ struct c3_handle {
   // the LAST POA pass (a handful of reads whose bands blew up: a workgroup of eight waves each, >100 ms on four CUs) runs on a stream of
   // its own beside k_prep / k_window of every other read; the stragglers are polished by a small tail afterwards (run_tail)
   hipStream_t stream_mw = nullptr; hipEvent_t ev_mw[2] = {nullptr, nullptr}; DBuf d_counter_mw, d_work_main;
-  // k_window's full-size launch as a consumer beside the first launch (round 6): its stream, "inputs ready" / "consumer done"
-  hipStream_t stream_w2 = nullptr; hipEvent_t ev_w2[2] = {nullptr, nullptr}; int win_consumers = 0;
+  // k_window's full-size launch as a consumer beside the first launch (round 6): "inputs ready" / "consumer done".  It runs on stream_mw: a
+  // fifth stream would share one of the runtime's four hardware queues with another stream of this handle, and kernels that share a queue
+  // run one after the other (measured: with a stream of its own the consumer ended up on the main stream's queue once stream_mw had taken
+  // the fourth, and the last POA pass of cfgL stopped overlapping the polish: +130 ms).  While that pass is in flight there is no consumer
+  hipEvent_t ev_w2[2] = {nullptr, nullptr}; int win_consumers = 0;
   std::vector<int> strag, work_main; bool tail_pending = false;
   int n_poa_redo = 0;        // reads of the last run that needed the full-size second POA pass
   int n_poa_redo16 = 0;      // ... of them: because a score left the 16-bit cells
@@ -255,7 +258,6 @@ extern "C" int c3_create(const c3_config* cfg, c3_handle** out) {
   if ((e = hipStreamCreate(&h->stream_dn)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   if ((e = hipStreamCreate(&h->stream_mw)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   for (int i = 0; i < 2; ++i) if ((e = hipEventCreate(&h->ev_mw[i])) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
-  if ((e = hipStreamCreate(&h->stream_w2)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   for (int i = 0; i < 2; ++i) if ((e = hipEventCreateWithFlags(&h->ev_w2[i], hipEventDisableTiming)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   if ((e = hipEventCreateWithFlags(&h->ev_dn, hipEventDisableTiming)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
   if ((e = hipHostMalloc((void**)&h->h_tot, 64, hipHostMallocDefault)) != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return C3_E_HIP; }
@@ -273,7 +275,6 @@ extern "C" void c3_destroy(c3_handle* h) {
   if (h->stream_dn) { (void)hipStreamSynchronize(h->stream_dn); (void)hipStreamDestroy(h->stream_dn); }
   if (h->stream_mw) { (void)hipStreamSynchronize(h->stream_mw); (void)hipStreamDestroy(h->stream_mw); }
   for (int i = 0; i < 2; ++i) if (h->ev_mw[i]) (void)hipEventDestroy(h->ev_mw[i]);
-  if (h->stream_w2) { (void)hipStreamSynchronize(h->stream_w2); (void)hipStreamDestroy(h->stream_w2); }
   for (int i = 0; i < 2; ++i) if (h->ev_w2[i]) (void)hipEventDestroy(h->ev_w2[i]);
   h->d_counter_mw.release(); h->d_work_main.release();
   if (h->ev_dn) (void)hipEventDestroy(h->ev_dn);
@@ -880,7 +881,7 @@ static int run_polish(c3_handle* h, const std::vector<int>& work, const int* d_w
     a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
     if (const char* e = getenv("C3_DEBUG_BAND")) a.band_mode = !strcmp(e, "off") ? 1 : !strcmp(e, "fail") ? 2 : !strcmp(e, "verify") ? 3 : 0;    // test hook (tests/test_gpu_band.py)
     a.ovf_list = h->d_wovf.as<int>();
-    // Three launches (round 6).  (1) on stream_w2, FIRST, so that its few waves are resident before the first launch fills the device: the
+    // Three launches (round 6).  (1) on stream_mw, FIRST, so that its few waves are resident before the first launch fills the device: the
     // full-size kernel as a consumer of the overflow list (every entry -1, the flag 0), a few waves, each of which costs one SIMD one
     // of its six first-launch waves (twice the number of windows the previous run handed over, 16..256: enough to take every window at once
     // when batches resemble each other, cheap when there are none).  (2) the first launch; behind it, on its stream, the flag.  (3) the
@@ -891,7 +892,7 @@ static int run_polish(c3_handle* h, const std::vector<int>& work, const int* d_w
     a2.rdesc = h->s_win_desc2.as<uint4>(); a2.Ncap = Ncap2; a2.Lcap = std::min(a.Lcap, Ncap2);
     a2.H = h->s_win_h2.as<int32_t>(); a2.D = h->s_win_d2.as<uint16_t>(); a2.hcap = hcap2;
     a2.wlist = h->d_wovf.as<int>(); a2.n_win_dev = h->d_counter.as<int>() + W_CNT_OVF; a2.ovf_list = nullptr; a2.done_flag = nullptr;
-    const bool consumer = !getenv("C3_NO_WIN_CONSUMER") && !getenv("C3_DEBUG_SYNC");
+    const bool consumer = !getenv("C3_NO_WIN_CONSUMER") && !getenv("C3_DEBUG_SYNC") && !h->tail_pending;
     HIPCHK(hipMemsetAsync(h->d_wovf.p, 0xff, sizeof(int) * (size_t)n_win, h->stream));
     if (consumer) {
       int nc = h->win_consumers > 0 ? h->win_consumers : 32;
@@ -899,10 +900,10 @@ static int run_polish(c3_handle* h, const std::vector<int>& work, const int* d_w
       nc = std::max(1, std::min(std::min(nc, 256), slots2));
       WinArgs ac = a2; ac.done_flag = h->d_counter.as<int>() + W_CNT_DONE;
       HIPCHK(hipEventRecord(h->ev_w2[0], h->stream));
-      HIPCHK(hipStreamWaitEvent(h->stream_w2, h->ev_w2[0], 0));
-      c3k_launch_window(&ac, nc, h->stream_w2);
+      HIPCHK(hipStreamWaitEvent(h->stream_mw, h->ev_w2[0], 0));
+      c3k_launch_window(&ac, nc, h->stream_mw);
       HIPCHK(hipGetLastError());
-      HIPCHK(hipEventRecord(h->ev_w2[1], h->stream_w2));
+      HIPCHK(hipEventRecord(h->ev_w2[1], h->stream_mw));
     }
     c3k_launch_window(&a, slots, h->stream);
     { const hipError_t le = hipGetLastError();
