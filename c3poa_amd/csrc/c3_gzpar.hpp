@@ -1,0 +1,364 @@
+// c3_gzpar.hpp -- ONE plain gzip stream inflated by several threads (host only, no GPU code; round 6).
+//
+// Why: the command line reads `.gz` input (C3POa.py:201,239), ONT data ships as plain gzip -- one deflate stream, not BGZF -- and one
+// thread inflates FASTQ at ~0.5 GB/s with the decoder of c3_inflate.hpp: ~50 k reads/s, a ninth of ONE GPU (profiles/r05_cli_500k_gz_*).
+// A deflate stream cannot be entered in the middle in general: Huffman codes are not self-synchronising at the bit level and a match
+// may copy from the 32 KiB before it.  The two-pass scheme used here is the published one (Kerbiriou & Chikhi 2019, "pugz"; rapidgzip):
+//
+//   1. the compressed file is cut into chunks of `chunk` bytes; in every chunk but the first a thread looks for the first bit offset
+//      that holds a DYNAMIC block header whose three Huffman codes are complete and whose block decodes to its end-of-block symbol
+//      with another well-formed block header behind it (probe);
+//   2. every thread decodes from its offset with an UNKNOWN window: symbols are 16 bits wide, a literal is its byte, a copy from
+//      before the chunk yields the marker 0x8000 | k for byte k of the 32 KiB before the chunk (copies of markers copy the marker),
+//      and it stops at the block boundary where the next chunk begins;
+//   3. the chunks are chained in order: the chunk before must have stopped EXACTLY where this one started (an offset that is not a
+//      block boundary of the real stream -- a false positive of step 1 -- is found out here, structurally: its chunk is dropped and
+//      the chunk before decodes on through it), its last 32 KiB, resolved, are this chunk's window;
+//   4. every thread replaces the markers of its chunk, narrows the symbols to bytes and takes the CRC-32 of every stretch of a gzip
+//      member in it; the stretches are combined (crc32_combine) and checked against every member's trailer, as is its length.
+//
+// Members may be concatenated (one stream, as for gzread); bytes behind the last member that are no gzip header end the input.
+// The code is this repository's own; zlib supplies crc32 / crc32_combine only.
+#pragma once
+#include "c3_inflate.hpp"
+#include <zlib.h>
+#include <algorithm>
+#include <atomic>
+#include <functional>
+#include <thread>
+#include <vector>
+
+namespace c3inf {
+
+struct MemberEnd { size_t off; uint32_t crc, isize; };      // a gzip member ends after `off` symbols of the chunk; its trailer's fields
+
+// deflate data of the gzip member whose header starts at p (n bytes available); nullptr when p is no gzip header
+static inline const uint8_t* gz_member_data(const uint8_t* p, size_t n) {
+  if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xe0)) return nullptr;
+  const int flg = p[3]; size_t q = 10;
+  if (flg & 4) { if (q + 2 > n) return nullptr; q += 2 + ((size_t)p[q] | ((size_t)p[q + 1] << 8)); }
+  if (flg & 8) { while (q < n && p[q]) ++q; ++q; }
+  if (flg & 16) { while (q < n && p[q]) ++q; ++q; }
+  if (flg & 2) q += 2;
+  if (q + 8 > n) return nullptr;
+  return p + q;
+}
+
+// growable array of 16-bit symbols WITHOUT value-initialisation (std::vector::resize would fill megabytes with zeros per probe)
+struct SymBuf {
+  uint16_t* p = nullptr; size_t cap = 0, len = 0;
+  SymBuf() {}
+  SymBuf(const SymBuf&) = delete; SymBuf& operator=(const SymBuf&) = delete;
+  SymBuf(SymBuf&& o) noexcept : p(o.p), cap(o.cap), len(o.len) { o.p = nullptr; o.cap = o.len = 0; }
+  SymBuf& operator=(SymBuf&& o) noexcept { if (this != &o) { free(p); p = o.p; cap = o.cap; len = o.len; o.p = nullptr; o.cap = o.len = 0; } return *this; }
+  ~SymBuf() { free(p); }
+  void release() { free(p); p = nullptr; cap = len = 0; }
+  bool reserve(size_t need) {
+    if (need <= cap) return true;
+    size_t nc = cap ? cap : (size_t)1 << 16;
+    while (nc < need) nc *= 2;
+    uint16_t* q = (uint16_t*)realloc(p, nc * sizeof(uint16_t));
+    if (!q) return false;
+    p = q; cap = nc; return true;
+  }
+};
+
+struct Dec16 {
+  Inflater z;
+  const uint8_t* base = nullptr; const uint8_t* fend = nullptr;
+
+  void seek(size_t bit) {
+    z.reset(base + (bit >> 3), fend);
+    z.refill_safe();
+    const unsigned drop = (unsigned)(bit & 7);
+    z.bitbuf >>= drop; z.bitcnt -= drop;
+  }
+  size_t bitpos() const { return (size_t)(z.in - base) * 8 - z.bitcnt; }
+
+  // Decode blocks from the current position into out (symbols appended; `known` = the decoder starts at the first block of a member, so
+  // nothing may be copied from before out[0]).  Stops at the first block boundary at or beyond stop_bit that lies behind the start
+  // (returns 0), at the end of the last member (1), or on an error / more than max_syms symbols (-1).  *end_bit = where it stopped.
+  int run(SymBuf& out, size_t stop_bit, size_t* end_bit, bool known, std::vector<MemberEnd>& ends, size_t max_syms) {
+    const size_t start_bit = bitpos();
+    size_t pos = out.len;
+    if (!out.reserve(pos + 65536)) return -1;
+    uint16_t* o = out.p; size_t capv = out.cap;
+    size_t mstart = 0;                       // first symbol of the member being decoded (0: the chunk began inside it, or with it when `known`)
+    bool reach = !known;                     // copies may reach up to 32 KiB before out[0]
+    const uint32_t LM = (1u << LIT_BITS) - 1;
+    auto fail = [&]() { out.len = pos; return -1; };
+    for (;;) {
+      const size_t bp = bitpos();
+      if (bp >= stop_bit && bp > start_bit) { *end_bit = bp; out.len = pos; return 0; }
+      if (!z.read_block_header()) return fail();
+      if (z.btype == 0) {
+        size_t n = z.stored_left;
+        if (n > (size_t)(fend - z.in)) return fail();
+        if (pos + n + 600 > capv) { if (pos + n + 600 > max_syms || !out.reserve(pos + n + 600)) return fail(); o = out.p; capv = out.cap; }
+        for (size_t i = 0; i < n; ++i) o[pos + i] = z.in[i];
+        z.in += n; pos += n; z.stored_left = 0;
+      } else {
+        for (;;) {
+          if (pos + 600 > capv) { if (capv * 2 > max_syms || !out.reserve(capv * 2)) return fail(); o = out.p; capv = out.cap; }
+          const bool fast = (size_t)(fend - z.in) >= 16;
+          if (fast) z.refill_fast(); else z.refill_safe();
+          uint32_t e = z.lit[z.bitbuf & LM];
+          if (fast) {
+            // up to three literal lookups (one or two bytes each, at most 11 bits each) out of one refill, as in Inflater::run
+#define C3INF_LIT16() { z.bitbuf >>= e_len(e); z.bitcnt -= e_len(e); const uint32_t v_ = e_val(e), two_ = e_extra(e); o[pos] = (uint16_t)(v_ & 0xff); o[pos + 1] = (uint16_t)(v_ >> 8); pos += 1 + two_; e = z.lit[z.bitbuf & LM]; }
+            if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) {
+              C3INF_LIT16()
+              if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) {
+                C3INF_LIT16()
+                if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) C3INF_LIT16()
+              }
+            }
+#undef C3INF_LIT16
+            if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) continue;
+          }
+          if ((e & (K_MASK | K_VALID)) == (K_SUB | K_VALID)) {
+            if (z.bitcnt < (unsigned)LIT_BITS) return fail();
+            e = z.lit[e_val(e) + ((z.bitbuf >> LIT_BITS) & ((1u << e_extra(e)) - 1))]; z.bitbuf >>= LIT_BITS; z.bitcnt -= LIT_BITS;
+          }
+          if (!(e & K_VALID) || e_len(e) > z.bitcnt) return fail();
+          z.bitbuf >>= e_len(e); z.bitcnt -= e_len(e);
+          const uint32_t kind = e & K_MASK;
+          if (kind == K_LIT) { o[pos++] = (uint16_t)(e_val(e) & 0xff); if (e_extra(e)) o[pos++] = (uint16_t)(e_val(e) >> 8); continue; }
+          if (kind == K_EOB) break;
+          unsigned len = e_val(e), xb = e_extra(e);
+          if (xb) { if (z.bitcnt < xb) return fail(); len += (unsigned)(z.bitbuf & ((1u << xb) - 1)); z.bitbuf >>= xb; z.bitcnt -= xb; }
+          if (fast) z.refill_fast(); else z.refill_safe();
+          uint32_t d = z.dist[z.bitbuf & ((1u << DIST_BITS) - 1)];
+          if ((d & (K_MASK | K_VALID)) == (K_SUB | K_VALID)) {
+            if (z.bitcnt < (unsigned)DIST_BITS) return fail();
+            d = z.dist[e_val(d) + ((z.bitbuf >> DIST_BITS) & ((1u << e_extra(d)) - 1))]; z.bitbuf >>= DIST_BITS; z.bitcnt -= DIST_BITS;
+          }
+          if ((d & (K_MASK | K_VALID)) != (K_LEN | K_VALID) || e_len(d) > z.bitcnt) return fail();
+          z.bitbuf >>= e_len(d); z.bitcnt -= e_len(d);
+          unsigned dd = e_val(d), db = e_extra(d);
+          if (db) { if (z.bitcnt < db) { z.refill_safe(); if (z.bitcnt < db) return fail(); } dd += (unsigned)(z.bitbuf & ((1u << db) - 1)); z.bitbuf >>= db; z.bitcnt -= db; }
+          if ((size_t)dd <= pos - mstart) {
+            uint16_t* dst = o + pos; const uint16_t* src = dst - dd; uint16_t* const end = dst + len;
+            if (dd >= 4) { do { uint64_t w; memcpy(&w, src, 8); memcpy(dst, &w, 8); src += 4; dst += 4; } while (dst < end); }      // (room: 600 symbols were ensured)
+            else { do { *dst++ = *src++; } while (dst < end); }
+          } else {
+            // from before the chunk: markers for the part that lies there
+            if (mstart != 0 || !reach || (size_t)dd - pos > 32768) return fail();
+            const long long p0 = (long long)pos - (long long)dd;
+            for (unsigned i = 0; i < len; ++i) { const long long p = p0 + i; o[pos + i] = p >= 0 ? o[p] : (uint16_t)(0x8000u | (unsigned)(32768 + p)); }
+          }
+          pos += len;
+        }
+      }
+      if (z.final_block) {
+        // the member's trailer; another member may follow (one stream, as for gzread)
+        const unsigned dropb = z.bitcnt & 7; z.bitbuf >>= dropb; z.bitcnt -= dropb;
+        const uint8_t* t = z.in - (z.bitcnt >> 3);
+        if (t + 8 > fend) return fail();
+        const uint32_t crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+        const uint32_t isz = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+        ends.push_back({pos, crc, isz});
+        const uint8_t* nx = t + 8;
+        const uint8_t* data = nx < fend ? gz_member_data(nx, (size_t)(fend - nx)) : nullptr;
+        if (!data) { *end_bit = (size_t)(nx - base) * 8; out.len = pos; return 1; }      // (trailing bytes that are no member end the input, as zlib does)
+        seek((size_t)(data - base) * 8);
+        mstart = pos; reach = false;
+        if (mstart == 0) { reach = false; known = true; }
+      }
+    }
+  }
+
+  // first bit offset in [from, to) that opens a dynamic block which decodes to its end with a well-formed block header behind it;
+  // (size_t)-1 when there is none.  tmp: scratch
+  size_t find_block(size_t from, size_t to, SymBuf& tmp, std::vector<MemberEnd>& tends) {
+    const size_t nbits = (size_t)(fend - base) * 8;
+    if (to > nbits) to = nbits;
+    for (size_t bit = from; bit + 64 < nbits && bit < to; ++bit) {
+      // BFINAL = 0, BTYPE = 2 (bits 1-2 = 10b, LSB first): the low three bits read 100b; HLIT <= 29; HDIST <= 29
+      const size_t by = bit >> 3; const unsigned sh = (unsigned)(bit & 7);
+      uint32_t w; memcpy(&w, base + by, 4);
+      w >>= sh;
+      if ((w & 7u) != 4u || ((w >> 3) & 31u) > 29u || ((w >> 8) & 31u) > 29u) continue;
+      // the header proper: the three codes must be complete (most candidates end at the 19 code-length code lengths)
+      seek(bit);
+      if (!z.read_block_header()) continue;
+      // ... the block must decode to its end-of-block symbol, and a well-formed header must follow
+      seek(bit);
+      tmp.len = 0; tends.clear();
+      size_t eb = 0;
+      const int rc = run(tmp, bit + 1, &eb, false, tends, (size_t)1 << 24);       // exactly one block (stops at the next boundary)
+      if (rc < 0) continue;
+      if (rc == 0) { seek(eb); if (!z.read_block_header()) continue; }
+      return bit;
+    }
+    return (size_t)-1;
+  }
+};
+
+// One chunk of a round
+struct ParChunk {
+  size_t start = (size_t)-1, end = 0;      // bit offsets (start: -1 = no block start found: the chunk before decodes through)
+  bool known = false;                      // starts at the first block of a member
+  int rc = 0;                              // result of the decode: 0 stopped at a boundary, 1 end of the input, -1 error
+  SymBuf sym;
+  std::vector<MemberEnd> ends;
+  std::vector<uint8_t> window;             // the 32 KiB before the chunk (resolved), oldest first, 32768 bytes (front padded)
+  std::vector<char> out;                   // final bytes
+  std::vector<uint32_t> seg_crc; std::vector<size_t> seg_len;     // CRC-32 of every stretch between member ends (ends.size() + 1 stretches)
+};
+
+// The whole parallel decoder over a mapped file.  next_round() produces the next stretch of output bytes (in order) into `chunks` --
+// false at the end of the input or on an error (bad = true).
+struct GzPar {
+  const uint8_t* map = nullptr; size_t size = 0;
+  int T = 4; size_t chunk = (size_t)1 << 20;
+  size_t next_bit = 0; bool next_known = true; bool started = false, done = false, bad = false;
+  std::vector<uint8_t> window;             // last 32 KiB of everything produced so far (front padded with zeros)
+  uint32_t run_crc = 0; uint64_t run_len = 0;     // the member that is still open: CRC-32 and length so far
+  int members = 0;
+  std::function<void(std::function<void()>)> with_slot;       // runs a worker body under the process-wide core limiter (c3_io.cpp: CpuSlot)
+  std::vector<ParChunk> chunks;
+
+  bool open() {
+    const uint8_t* d = gz_member_data(map, size);
+    if (!d) return false;
+    next_bit = (size_t)(d - map) * 8; next_known = true; started = true;
+    window.assign(32768, 0);
+    run_crc = (uint32_t)crc32(0L, Z_NULL, 0); run_len = 0;
+    return true;
+  }
+
+  template <class F> void parallel(int n, F body) {
+    std::vector<std::thread> th;
+    auto wrapped = [&](int j) { if (with_slot) with_slot([&]() { body(j); }); else body(j); };
+    for (int j = 1; j < n; ++j) th.emplace_back(wrapped, j);
+    if (n > 0) wrapped(0);
+    for (auto& t : th) t.join();
+  }
+
+  bool next_round() {
+    if (done || bad) return false;
+    const size_t nbits = size * 8;
+    const size_t b0 = next_bit >> 3;
+    int n = T;
+    chunks.clear(); chunks.resize((size_t)n);
+    chunks[0].start = next_bit; chunks[0].known = next_known;
+#ifdef C3_GZPAR_PROF
+    const double T0 = now_();
+#endif
+    // ---- 1. block starts of the chunks 1 .. n-1, and of the chunk the NEXT round begins with
+    std::vector<size_t> starts((size_t)n + 1, (size_t)-1);
+    starts[0] = next_bit;
+    parallel(n, [&](int j) {
+      const size_t from = (b0 + (size_t)(j + 1) * chunk) * 8;
+      if (from >= nbits) return;
+      Dec16 d; d.base = map; d.fend = map + size;
+      SymBuf tmp; std::vector<MemberEnd> te;
+      // (the last one -- where the next round starts -- searches on until it finds one: a round must end at a block boundary)
+      const size_t to = j + 1 < n ? from + chunk * 8 : nbits;
+      starts[(size_t)j + 1] = d.find_block(from, to, tmp, te);
+    });
+    for (int j = 1; j < n; ++j) chunks[(size_t)j].start = starts[(size_t)j];
+    const size_t round_end = starts[(size_t)n];            // (size_t)-1: this round runs to the end of the input
+#ifdef C3_GZPAR_PROF
+    const double T1 = now_();
+#endif
+    // ---- 2. decode every chunk that has a start up to the start of the next one that has
+    auto target_of = [&](int j) { for (int k = j + 1; k < n; ++k) if (chunks[(size_t)k].start != (size_t)-1) return chunks[(size_t)k].start; return round_end; };
+    parallel(n, [&](int j) {
+      ParChunk& c = chunks[(size_t)j];
+      if (c.start == (size_t)-1) return;
+      Dec16 d; d.base = map; d.fend = map + size;
+      d.seek(c.start);
+      c.sym.reserve(chunk * 4);
+      c.rc = d.run(c.sym, target_of(j), &c.end, c.known, c.ends, (size_t)1 << 30);
+    });
+#ifdef C3_GZPAR_PROF
+    const double T2 = now_();
+#endif
+    // ---- 3. the chain: every chunk must begin where the one before stopped.  One that does not was no block boundary of the real stream
+    // (a false positive of step 1): it is dropped and the chunk before decodes on through it (serially: this is the rare path)
+    size_t rend = round_end;
+    int cur = 0;
+    for (;;) {
+      ParChunk& p = chunks[(size_t)cur];
+      if (p.rc < 0) { bad = true; return false; }
+      if (p.rc == 1) { for (int k = cur + 1; k < n; ++k) chunks[(size_t)k].start = (size_t)-1; break; }      // the input ended inside p
+      int nx = -1;
+      for (int k = cur + 1; k < n; ++k) if (chunks[(size_t)k].start != (size_t)-1) { nx = k; break; }
+      const size_t want = nx >= 0 ? chunks[(size_t)nx].start : rend;
+      if (want == (size_t)-1 || p.end < want) { bad = true; return false; }          // (cannot happen: p stops at the first boundary at or beyond its target)
+      if (p.end == want) { if (nx < 0) break; cur = nx; continue; }
+      if (nx < 0) { rend = p.end; break; }                                           // the next round's start was the false positive: it begins where p stopped
+      chunks[(size_t)nx].start = (size_t)-1; chunks[(size_t)nx].sym.release(); chunks[(size_t)nx].ends.clear();
+      size_t tgt = rend;
+      for (int k = nx + 1; k < n; ++k) if (chunks[(size_t)k].start != (size_t)-1) { tgt = chunks[(size_t)k].start; break; }
+      if (tgt == (size_t)-1 || p.end < tgt) {
+        Dec16 d; d.base = map; d.fend = map + size;
+        d.seek(p.end);
+        p.rc = d.run(p.sym, tgt, &p.end, p.known, p.ends, (size_t)1 << 30);
+      }
+    }
+    {
+      const ParChunk& p = chunks[(size_t)cur];
+      if (p.rc == 1) done = true;
+      else { next_bit = p.end; next_known = false; }
+    }
+#ifdef C3_GZPAR_PROF
+    const double T3 = now_();
+#endif
+    // ---- 4. windows, in order (only the last 32 KiB of every chunk are resolved here), then markers -> bytes and CRCs in parallel
+    std::vector<uint8_t> w = window;
+    for (int j = 0; j < n; ++j) {
+      ParChunk& c = chunks[(size_t)j];
+      if (c.start == (size_t)-1) continue;
+      c.window = w;
+      const size_t m = c.sym.len;
+      const size_t keep = std::min<size_t>(m, 32768);
+      std::vector<uint8_t> nw(32768, 0);
+      if (keep < 32768) memcpy(nw.data(), w.data() + keep, 32768 - keep);
+      for (size_t i = 0; i < keep; ++i) { const uint16_t s = c.sym.p[m - keep + i]; nw[32768 - keep + i] = s < 256 ? (uint8_t)s : w[s & 0x7fffu]; }
+      w.swap(nw);
+    }
+    window = w;
+    parallel(n, [&](int j) {
+      ParChunk& c = chunks[(size_t)j];
+      if (c.start == (size_t)-1) return;
+      const size_t m = c.sym.len;
+      c.out.resize(m);
+      const uint16_t* s = c.sym.p; const uint8_t* wv = c.window.data(); char* o = c.out.data();
+      for (size_t i = 0; i < m; ++i) { const uint16_t v = s[i]; o[i] = (char)(v < 256 ? (uint8_t)v : wv[v & 0x7fffu]); }
+      c.sym.release();
+      size_t at = 0;
+      for (size_t k = 0; k <= c.ends.size(); ++k) {
+        const size_t to = k < c.ends.size() ? c.ends[k].off : m;
+        uint32_t cr = (uint32_t)crc32(0L, Z_NULL, 0);
+        for (size_t p = at; p < to;) { const size_t q = std::min<size_t>(to - p, (size_t)1 << 30); cr = (uint32_t)crc32(cr, (const unsigned char*)o + p, (unsigned)q); p += q; }
+        c.seg_crc.push_back(cr); c.seg_len.push_back(to - at);
+        at = to;
+      }
+    });
+#ifdef C3_GZPAR_PROF
+    const double T4 = now_();
+#endif
+    // ---- 5. every member that ended in this round: CRC-32 and length against its trailer
+    for (int j = 0; j < n; ++j) {
+      ParChunk& c = chunks[(size_t)j];
+      if (c.start == (size_t)-1) continue;
+      for (size_t k = 0; k <= c.ends.size(); ++k) {
+        run_crc = (uint32_t)crc32_combine(run_crc, c.seg_crc[k], (z_off_t)c.seg_len[k]); run_len += c.seg_len[k];
+        if (k < c.ends.size()) {
+          if (run_crc != c.ends[k].crc || (uint32_t)run_len != c.ends[k].isize) { bad = true; return false; }
+          run_crc = (uint32_t)crc32(0L, Z_NULL, 0); run_len = 0; ++members;
+        }
+      }
+    }
+#ifdef C3_GZPAR_PROF
+    fprintf(stderr, "  find %.4f decode %.4f chain %.4f convert %.4f verify %.4f\n", T1 - T0, T2 - T1, T3 - T2, T4 - T3, now_() - T4);
+#endif
+    if (done && run_len != 0) { bad = true; return false; }      // the input ended inside a member
+    return true;
+  }
+};
+
+}  // namespace c3inf

@@ -32,6 +32,7 @@
 
 #include "../../include/c3poa.h"
 #include "c3_inflate.hpp"
+#include "c3_gzpar.hpp"
 #include <sys/mman.h>
 
 namespace {
@@ -157,8 +158,18 @@ struct GzFast {
   bool done = false, bad = false, stop = false, started = false;
 };
 
+// plain gzip input inflated by several threads (c3_gzpar.hpp, round 6): a producer thread runs the rounds of the parallel decoder one ahead
+// of the parser, which copies the finished chunks out in order
+struct GzParReader {
+  int fd = -1; const uint8_t* map = nullptr; size_t size = 0;
+  c3inf::GzPar par;
+  std::thread th; std::mutex mu; std::condition_variable cv;
+  std::vector<std::vector<char>> ready[2]; bool full[2] = {false, false}; int prod = 0, cons = 0; size_t ci = 0, cpos = 0;
+  bool done = false, bad = false, stop = false, started = false;
+};
+
 struct c3_reader {
-  FILE* fp = nullptr; gzFile gz = nullptr; Bgzf* bz = nullptr; GzFast* gzf = nullptr;
+  FILE* fp = nullptr; gzFile gz = nullptr; Bgzf* bz = nullptr; GzFast* gzf = nullptr; GzParReader* gzp = nullptr;
   std::vector<char> buf; size_t beg = 0, end = 0; bool eof = false; bool gz_bad = false;
   std::vector<BatchSet> sets; int cur = -1;
   std::string err;
@@ -305,6 +316,54 @@ void gzfast_close(GzFast* g) {
   delete g;
 }
 
+void gzpar_thread(GzParReader* g) {
+  for (;;) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [g] { return g->stop || !g->full[g->prod]; });
+    if (g->stop) return;
+    lk.unlock();
+    const bool ok = g->par.next_round();
+    std::vector<std::vector<char>>& dst = g->ready[g->prod];
+    dst.clear();
+    if (ok) for (c3inf::ParChunk& c : g->par.chunks) if (c.start != (size_t)-1 && !c.out.empty()) dst.emplace_back(std::move(c.out));
+    lk.lock();
+    if (g->par.bad) { g->bad = true; g->done = true; g->cv.notify_all(); return; }
+    if (!dst.empty()) { g->full[g->prod] = true; g->prod ^= 1; }
+    if (!ok || g->par.done) { g->done = true; g->cv.notify_all(); return; }
+    g->cv.notify_all();
+  }
+}
+long gzpar_read(GzParReader* g, char* dst, size_t room) {
+  if (!g->started) {
+    g->started = true;
+    g->par.with_slot = [](std::function<void()> f) { CpuSlot s_; f(); };
+    if (!g->par.open()) { g->bad = true; return -1; }
+    g->th = std::thread(gzpar_thread, g);
+  }
+  for (;;) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [g] { return g->full[g->cons] || g->done; });
+    if (g->bad) return -1;                                          // (a damaged stream: nothing of the failing round is handed out)
+    if (!g->full[g->cons]) return 0;
+    lk.unlock();
+    std::vector<std::vector<char>>& cs = g->ready[g->cons];
+    if (g->ci < cs.size()) {
+      std::vector<char>& c = cs[g->ci];
+      const size_t k = std::min(room, c.size() - g->cpos);
+      memcpy(dst, c.data() + g->cpos, k); g->cpos += k;
+      if (g->cpos == c.size()) { std::vector<char>().swap(c); ++g->ci; g->cpos = 0; }
+      if (k) return (long)k;
+    }
+    if (g->ci >= cs.size()) { lk.lock(); g->full[g->cons] = false; g->cons ^= 1; g->ci = 0; g->cpos = 0; g->cv.notify_all(); }
+  }
+}
+void gzpar_close(GzParReader* g) {
+  if (g->started && g->th.joinable()) { { std::lock_guard<std::mutex> lk(g->mu); g->stop = true; } g->cv.notify_all(); g->th.join(); }
+  if (g->map) munmap((void*)g->map, g->size);
+  if (g->fd >= 0) close(g->fd);
+  delete g;
+}
+
 // next stretch of the file: up to `max_members` members read, located by their headers, inflated by b->threads threads
 bool bgzf_next_stretch(Bgzf* bz, BgzfStretch* b, size_t max_members = 512) {
   b->comp.clear(); b->coff.clear(); b->csz.clear(); b->doff.clear();
@@ -444,11 +503,12 @@ bool refill(c3_reader* r) {
   if (r->end == r->buf.size()) r->buf.resize(r->buf.size() * 2);
   size_t room = r->buf.size() - r->end;
   long got = r->bz ? bgzf_read(r->bz, r->buf.data() + r->end, room)
+           : r->gzp ? gzpar_read(r->gzp, r->buf.data() + r->end, room)
            : r->gzf ? gzfast_read(r->gzf, r->buf.data() + r->end, room)
            : r->gz ? (long)gzread(r->gz, r->buf.data() + r->end, (unsigned)std::min<size_t>(room, 1u << 30))
                    : (long)fread(r->buf.data() + r->end, 1, room, r->fp);
   if (got < 0 && r->bz) r->err = "BGZF input: a member is damaged (size, inflate or CRC)";
-  if (got < 0 && !r->bz && (r->gz || r->gzf)) r->gz_bad = true;                  // (reported by c3_reader_next: never a silently shorter file)
+  if (got < 0 && !r->bz && (r->gz || r->gzf || r->gzp)) r->gz_bad = true;                  // (reported by c3_reader_next: never a silently shorter file)
   if (got <= 0) { r->eof = true; return false; }
   r->end += (size_t)got;
   return true;
@@ -531,16 +591,27 @@ extern "C" int c3_reader_open(const char* path, int n_sets, c3_reader** out) {
           void* mp = mmap(nullptr, (size_t)sb.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
           if (mp != MAP_FAILED) {
             (void)madvise(mp, (size_t)sb.st_size, MADV_SEQUENTIAL);
-            r->gzf = new GzFast(); r->gzf->fd = fd; r->gzf->map = (const uint8_t*)mp; r->gzf->size = (size_t)sb.st_size;
+            // several threads on the one stream (c3_gzpar.hpp) when the file is large enough to cut up and there are cores for it;
+            // C3_GZ_SERIAL=1 / C3_GZ_THREADS=1: the single inflating thread of round 5
+            const char* et = getenv("C3_GZ_THREADS");
+            const int T = et ? std::max(1, atoi(et)) : std::min(16, host_cores());
+            const char* ec = getenv("C3_GZ_CHUNK");
+            const size_t chunk = ec ? (size_t)std::max(1024, atoi(ec)) : (size_t)1 << 20;
+            if (T > 1 && !getenv("C3_GZ_SERIAL") && (size_t)sb.st_size >= 2 * chunk) {
+              r->gzp = new GzParReader(); r->gzp->fd = fd; r->gzp->map = (const uint8_t*)mp; r->gzp->size = (size_t)sb.st_size;
+              r->gzp->par.map = r->gzp->map; r->gzp->par.size = r->gzp->size; r->gzp->par.T = T; r->gzp->par.chunk = chunk;
+            } else {
+              r->gzf = new GzFast(); r->gzf->fd = fd; r->gzf->map = (const uint8_t*)mp; r->gzf->size = (size_t)sb.st_size;
+            }
           }
         }
-        if (!r->gzf && fd >= 0) close(fd);
+        if (!r->gzf && !r->gzp && fd >= 0) close(fd);
       }
-      if (!r->gzf) { r->gz = gzopen(path, "rb"); if (r->gz) gzbuffer(r->gz, 1 << 20); }
+      if (!r->gzf && !r->gzp) { r->gz = gzopen(path, "rb"); if (r->gz) gzbuffer(r->gz, 1 << 20); }
     }
   }
   else r->fp = fopen(path, "rb");
-  if (!r->gz && !r->fp && !r->bz && !r->gzf) { delete r; return C3_E_ARG; }
+  if (!r->gz && !r->fp && !r->bz && !r->gzf && !r->gzp) { delete r; return C3_E_ARG; }
   { FILE* f = fopen(path, "rb"); if (f) { fseek(f, 0, SEEK_END); long z = ftell(f); r->file_bytes = z > 0 ? (size_t)z : 0; fclose(f); } }
   r->buf.resize((size_t)16 << 20);
   r->sets.resize((size_t)std::max(1, n_sets));
@@ -690,10 +761,29 @@ extern "C" long c3_debug_inflate(const unsigned char* in, size_t n, unsigned cha
   }
 }
 
+// test hook (tests/test_inflate.py): a whole gzip FILE image `in` through the parallel decoder (threads, chunk bytes); the size, -1 on a
+// damaged stream, -2 when cap is too small, -3 when `in` is no gzip member
+extern "C" long c3_debug_gunzip_par(const unsigned char* in, size_t n, int threads, size_t chunk, unsigned char* out, size_t cap) {
+  c3inf::GzPar par; par.map = in; par.size = n; par.T = std::max(1, threads); par.chunk = std::max<size_t>(chunk, 64);
+  if (!par.open()) return -3;
+  size_t total = 0;
+  for (;;) {
+    const bool ok = par.next_round();
+    if (par.bad) return -1;
+    if (ok) for (c3inf::ParChunk& c : par.chunks) if (c.start != (size_t)-1) {
+      if (total + c.out.size() > cap) return -2;
+      memcpy(out + total, c.out.data(), c.out.size()); total += c.out.size();
+    }
+    if (!ok || par.done) break;
+  }
+  return (long)total;
+}
+
 extern "C" void c3_reader_close(c3_reader* r) {
   if (!r) return;
   if (r->gz) gzclose(r->gz);
   if (r->gzf) gzfast_close(r->gzf);
+  if (r->gzp) gzpar_close(r->gzp);
   if (r->fp) fclose(r->fp);
   if (r->bz) { if (r->bz->pre_on) r->bz->pre.join(); if (r->bz->fp) fclose(r->bz->fp); delete r->bz; }
   delete r;
@@ -750,7 +840,7 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
   if (!r->names_only && r->hint_bases) {
     // later sets are allocated once, with the size the previous groups needed (growth by copying only for the first)
     size_t want = r->hint_bases + r->hint_bases / 8 + 4096;
-    if (!r->gz && !r->gzf && !r->bz && r->file_bytes) {       // ... but never more than this reader can still deliver (a set taken for the tail of a range)
+    if (!r->gz && !r->gzf && !r->gzp && !r->bz && r->file_bytes) {       // ... but never more than this reader can still deliver (a set taken for the tail of a range)
       const int64_t stop = r->range_end >= 0 ? std::min<int64_t>(r->range_end + 65536, (int64_t)r->file_bytes) : (int64_t)r->file_bytes;
       const int64_t here = r->buf_off + (int64_t)r->beg;
       want = std::min(want, (size_t)std::max<int64_t>(0, stop - here) / 2 + 65536);
@@ -805,11 +895,11 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
       // file / byte range (the other half are qualities), and only as many buffer sets as those bytes can fill are page-locked
       // now (a 100-read input used to pin ten buffers of max_reads reads each)
       size_t deliver = (size_t)-1;
-      if (!r->gz && !r->gzf && !r->bz && r->file_bytes) {
+      if (!r->gz && !r->gzf && !r->gzp && !r->bz && r->file_bytes) {
         const int64_t stop = r->range_end >= 0 ? std::min<int64_t>(r->range_end + (int64_t)(4 * sl + 4096), (int64_t)r->file_bytes) : (int64_t)r->file_bytes;
         const int64_t here = r->buf_off + (int64_t)r->beg;
         deliver = (size_t)std::max<int64_t>(0, stop - here) / 2 + sb + sl + 4096;
-      } else if ((r->gz || r->gzf || r->bz) && r->file_bytes) deliver = r->file_bytes * 16 + sb + sl + 4096;        // (compressed size: a generous bound)
+      } else if ((r->gz || r->gzf || r->gzp || r->bz) && r->file_bytes) deliver = r->file_bytes * 16 + sb + sl + 4096;        // (compressed size: a generous bound)
       want = std::min(want, std::max(deliver, sb + sl + 4096));
       // Page-locking costs ~0.15 s per GB and as much again to undo, i.e. about what THREE copies of the buffer from pageable memory lose
       // against DMA: it pays when a buffer set is refilled several times, not when the whole input of this reader passes through its sets

@@ -156,3 +156,90 @@ def test_the_deepest_huffman_trees():
             for chunk in (0, 50000):
                 n, got = _inflate(raw, len(data), chunk)
                 assert n == len(data) and got == data, (nsym, strategy, chunk, n)
+
+
+# ---- round 6: ONE gzip stream inflated by several threads (c3poa_amd/csrc/c3_gzpar.hpp) -----------------------------------------------
+def _gunzip_par(gz, threads, chunk, cap):
+    lib = _lib.load()
+    lib.c3_debug_gunzip_par.restype = C.c_long
+    lib.c3_debug_gunzip_par.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_size_t, C.c_char_p, C.c_size_t]
+    out = C.create_string_buffer(cap + 1)
+    n = lib.c3_debug_gunzip_par(gz, len(gz), threads, chunk, out, cap)
+    return n, out.raw[:max(n, 0)]
+
+
+def _gz(data, level=6, flush_every=0):
+    if not flush_every:
+        return gzip.compress(data, compresslevel=level)
+    co = zlib.compressobj(level, zlib.DEFLATED, 31)
+    out = b""
+    for i in range(0, len(data), flush_every):          # pigz-like: sync / full flushes (empty stored blocks, the window dropped)
+        out += co.compress(data[i:i + flush_every]) + co.flush(zlib.Z_FULL_FLUSH if (i // flush_every) % 2 else zlib.Z_SYNC_FLUSH)
+    return out + co.flush()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_one_gzip_stream_by_several_threads_matches_zlib(seed):
+    """every payload x level x (threads, chunk): chunks from a few KB (every chunk seam inside a few blocks: markers across many seams,
+    chunks without any block start, block starts found in the middle of members) to larger than the file (one chunk)"""
+    for data in _payloads(seed):
+        for level in (1, 6, 9, 0):
+            gz = _gz(data, level)
+            for threads, chunk in ((4, 3000), (3, 20000), (8, 70000), (2, 1 << 22)):
+                n, out = _gunzip_par(gz, threads, chunk, len(data))
+                assert n == len(data) and out == data, (seed, level, threads, chunk, n, len(data))
+        gz = _gz(data, 6, flush_every=50000)
+        n, out = _gunzip_par(gz, 4, 9000, len(data))
+        assert n == len(data) and out == data
+
+
+def test_parallel_gunzip_members_trailing_bytes_and_damage():
+    data = next(iter(_payloads(5)))
+    third = len(data) // 3
+    mm = _gz(data[:third], 6) + _gz(b"", 6) + _gz(data[third:2 * third], 1) + _gz(data[2 * third:], 9)      # concatenated members (one stream, as for gzread), an empty one among them
+    for threads, chunk in ((4, 5000), (8, 40000), (2, 1 << 22)):
+        n, out = _gunzip_par(mm, threads, chunk, len(data))
+        assert n == len(data) and out == data
+    n, out = _gunzip_par(mm + b"not a gzip member", 4, 5000, len(data))                                       # trailing bytes end the input (zlib: ignored)
+    assert n == len(data) and out == data
+    assert _gunzip_par(b"plain text, no gzip", 4, 5000, 100)[0] == -3
+    gz = _gz(data, 6)
+    rng = random.Random(9)
+    caught = 0
+    for _ in range(60):                                                                                       # one flipped bit anywhere: an error, or (a flip inside the header's name / time fields) the same bytes
+        d = bytearray(gz)
+        k = rng.randrange(len(d))
+        d[k] ^= 1 << rng.randrange(8)
+        n, out = _gunzip_par(bytes(d), 4, 6000, len(data) + 70000)
+        assert n < 0 or out == data, k
+        caught += n < 0
+    assert caught >= 50
+    for cut in (10, 1000, len(gz) // 2):                                                                      # a truncated file is an error, never a shorter stream
+        assert _gunzip_par(gz[:-cut], 4, 6000, len(data))[0] == -1
+
+
+def test_plain_gz_file_through_the_reader_with_several_inflating_threads(tmp_path, monkeypatch):
+    """the reader picks the parallel decoder for a plain .gz of at least two chunks (C3_GZ_CHUNK shrinks them for the test); the records
+    equal those of the uncompressed file, for one thread (the serial decoder), three and eight; a damaged file is an error"""
+    rng = random.Random(4)
+    recs = []
+    for i in range(1500):
+        n = rng.randint(200, 6000)
+        recs.append(("r%d some description" % i, "".join(rng.choice("ACGT") for _ in range(n)), "".join(chr(rng.randint(35, 70)) for _ in range(n))))
+    text = "".join("@%s\n%s\n+\n%s\n" % r for r in recs).encode()
+    plain = tmp_path / "a.fastq"
+    plain.write_bytes(text)
+    want = _read_all(str(plain))
+    gzp = tmp_path / "a.fastq.gz"
+    gzp.write_bytes(gzip.compress(text, 6))
+    monkeypatch.setenv("C3_GZ_CHUNK", "40000")
+    for th in ("1", "3", "8"):
+        monkeypatch.setenv("C3_GZ_THREADS", th)
+        assert _read_all(str(gzp)) == want
+    d = bytearray(gzp.read_bytes())
+    d[len(d) // 2] ^= 0x10
+    bad = tmp_path / "bad.fastq.gz"
+    bad.write_bytes(bytes(d))
+    monkeypatch.setenv("C3_GZ_THREADS", "4")
+    with pytest.raises(Exception):
+        _read_all(str(bad))

@@ -1,0 +1,20 @@
+# round 6: plain gzip input by several threads -- decoder throughput and the CLI on a .gz file (run on the GPU box: its 16-core quota)
+cd "$GRAFT_REPO_ROOT"
+N=${N:-200000}
+python - <<PY
+import gzip, os, sys, time, subprocess
+sys.path.insert(0, ".")
+from c3poa_amd import synth
+import bench
+t = time.time()
+recs = bench.make_reads("cfg2", $N, 0, 16)
+with open("/tmp/in.fastq", "wb") as f:
+    for i, r in enumerate(recs):
+        f.write(("@r%08d\n%s\n+\n%s\n" % (i, r[0], r[1])).encode())
+print("fastq %.1f MB in %.1f s" % (os.path.getsize("/tmp/in.fastq") / 1e6, time.time() - t))
+t = time.time(); subprocess.check_call("gzip -6 -k -f /tmp/in.fastq", shell=True); print("gzip -6: %.1f MB, %.1f s" % (os.path.getsize("/tmp/in.fastq.gz") / 1e6, time.time() - t))
+PY
+g++ -O3 -std=c++17 tools/gzpar_bench.cpp -o /tmp/gzpar_bench -lz -lpthread
+/tmp/gzpar_bench /tmp/in.fastq.gz 1 2 4 8 12 16
+CHUNK=4194304 /tmp/gzpar_bench /tmp/in.fastq.gz 8 16 | grep parallel
+CHUNK=262144 /tmp/gzpar_bench /tmp/in.fastq.gz 8 16 | grep parallel
