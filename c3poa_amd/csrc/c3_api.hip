@@ -150,6 +150,7 @@ struct DBuf {
     // new buffer with a pattern instead (tests/test_gpu_band.py runs the pipeline that way)
     if (e == hipSuccess && getenv("C3_DEBUG_POISON")) e = hipMemset(p, 0xA5, want);
     g_alloc_ms += dbg_now_ms() - t0;
+    if (getenv("C3_DEBUG_ALLOC")) fprintf(stderr, "c3poa alloc: %.1f MB in %.1f ms\n", want / 1048576.0, dbg_now_ms() - t0);
     return e;
   }
   void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
