@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy what one gpurun call of the round's profile commands merged into gpurun_out/ into profiles/ (run locally, sources = the ones profiled):
 #   tools/collect_round.sh r05 [fuzz gate line from the call's log]
-TAG=${1:-r05}
+TAG=${1:-r06}
 for c in cfg2:cfg2_100k cfg4:cfg4_100k cfgL:cfgL_50k; do
   cfg=${c%%:*}; wl=${c##*:}; R=gpurun_out/${TAG}_$cfg
   python tools/collect_profiles.py $TAG $R/stats $R/fetch $R/write $R/bench.json $wl > /dev/null 2>&1
