@@ -882,6 +882,7 @@ static int run_polish(c3_handle* h, const std::vector<int>& work, const int* d_w
     a.phases = (unsigned long long*)(h->d_counter.as<char>() + 64);
     if (const char* e = getenv("C3_DEBUG_BAND")) a.band_mode = !strcmp(e, "off") ? 1 : !strcmp(e, "fail") ? 2 : !strcmp(e, "verify") ? 3 : 0;    // test hook (tests/test_gpu_band.py)
     a.ovf_list = h->d_wovf.as<int>();
+    if (const char* e = getenv("C3_DEBUG_OVF_DELAY_MS")) a.dbg_ovf_delay = atoi(e);      // test hook (tests/test_gpu_band.py): an overflow entry that appears long after its index was taken
     // Three launches (round 6).  (1) on stream_mw, FIRST, so that its few waves are resident before the first launch fills the device: the
     // full-size kernel as a consumer of the overflow list (every entry -1, the flag 0), a few waves, each of which costs one SIMD one
     // of its six first-launch waves (twice the number of windows the previous run handed over, 16..256: enough to take every window at once

@@ -51,6 +51,7 @@ struct WinArgs {
   // and stop when the flag is set (by the host, on the first launch's stream, behind that launch) and the list is empty.  A third, ordinary
   // launch (done_flag = nullptr) mops up what they left
   const int* done_flag;
+  int dbg_ovf_delay;                      // test hook (C3_DEBUG_OVF_DELAY_MS): the first launch waits this long between taking an overflow index and writing the entry
   // output of the second launch: entry q of its queue writes wout2 + q * wout2_cap (a window consensus can be as long as the graph has
   // nodes; the first launch's slots hold 3 windows + 64 and hand longer ones over); WinRec::pad_ = q + 1 tells k_stitch where to look
   uint8_t* wout2; int wout2_cap, wout2_n;

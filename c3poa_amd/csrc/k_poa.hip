@@ -179,6 +179,9 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 #ifndef C3_STEADY
 #define C3_STEADY 1            /* steady rows (round 6); 0 = the round-5 row loop, instruction for instruction */
 #endif
+#ifndef C3_NEAR1_TYPE0
+#define C3_NEAR1_TYPE0 1       /* near rows with ONE predecessor keep no predecessor byte (it is always 0): row type 0, as the fast rows (round 6) */
+#endif
 #ifndef C3_STEADY_FORK
 #define C3_STEADY_FORK 0       /* steady rows also for rows that a row further down reads (they write the ring at once) */
 #endif
@@ -775,7 +778,7 @@ __device__ __forceinline__ int poa_align(Ctx& c, const C3Params& P, int qb, int 
         const int ht = k2 & ~7;
         const unsigned mp = 3u - ((unsigned)kM & 3u), c1 = 7u - ((unsigned)kE1 & 7u), c2 = 7u - ((unsigned)kE2 & 7u);
         unsigned d = ((~c1) & 1u) | (((~c2) & 1u) << 1) | (((unsigned)k2 & 3u) << 2);
-        const unsigned pby = mp | ((c1 >> 1) << 2) | ((c2 >> 1) << 4);
+        const unsigned pby = mp | ((c1 >> 1) << 2) | ((c2 >> 1) << 4);                 // (one predecessor: always 0 -- such a row keeps no predecessor byte, C3_NEAR1_TYPE0)
         const int htm = act ? ht : NEG2_16;
         const int cl1 = le1_8 + e1_8 * c0, cl2 = le2_8 + e2_8 * c0;           // e * (column - beg)
         int s1 = htm + cl1, s2 = htm + cl2, s3 = htm;
@@ -789,8 +792,9 @@ __device__ __forceinline__ int poa_align(Ctx& c, const C3Params& P, int qb, int 
         d |= (((unsigned)k3 & 3u) << 4);
         d |= (((unsigned)(htl - oe1_8 - f1)) >> 25) & 64u;                      // f1 > its "open" candidate: extended
         d |= (((unsigned)(htl - oe2_8 - f2)) >> 24) & 128u;
-        // unmasked stores (see the fast row); every near row keeps a predecessor byte (type 1), also with one predecessor
-        c.D8()[(unsigned)(ro + c0 + lane)] = (uint8_t)d; c.P8()[(unsigned)(ro + c0 + lane)] = (uint8_t)pby;
+        // unmasked stores (see the fast row); a near row with several predecessors keeps a predecessor byte per cell (type 1)
+        c.D8()[(unsigned)(ro + c0 + lane)] = (uint8_t)d;
+        if (NP > 1 || !C3_NEAR1_TYPE0) c.P8()[(unsigned)(ro + c0 + lane)] = (uint8_t)pby;
         cH[ch] = h; cE1[ch] = E1c; cE2[ch] = E2c;
         const int cmx = __builtin_amdgcn_readlane(s3, 63);                      // maximum of Ht over the chunk (== maximum of H)
         const unsigned long long mxm = __ballot(htm == cmx);
@@ -826,7 +830,7 @@ __device__ __forceinline__ int poa_align(Ctx& c, const C3Params& P, int qb, int 
       if (lane == 0) {
         L.meta[slot] = make_int4(beg, end, left, right); L.base8[slot] = nb8;
         int off = 3 * idx; UNI(off);
-        int* rm = c.rowm() + off; rm[0] = beg; rm[1] = end | (1 << 28); rm[2] = ro;
+        int* rm = c.rowm() + off; rm[0] = beg; rm[1] = end | ((NP > 1 || !C3_NEAR1_TYPE0) ? (1 << 28) : 0); rm[2] = ro;      // (type 0 = direction bytes only: the traceback takes predecessor 0)
         if (far) { c.mpl()[idx] = left; c.mpr()[idx] = right; c.foff()[idx] = u_nfar; }
       }
       if (far) u_nfar = wave_first(u_nfar) + wave_first(wd);

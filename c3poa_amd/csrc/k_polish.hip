@@ -1124,7 +1124,7 @@ __global__ __launch_bounds__(64, SECOND ? C3_WIN_WAVES2 : C3_WIN_WAVES) void k_w
   unsigned long long* d0bits = mabits + MW; unsigned long long* d1bits = d0bits + MW;         // band shift bits of every DP row (banded layers)
   const int lds_ints = (int)(win_lds_bytes(a.Lcap, a.Ncap, !SECOND) / 4);    // = the launch's dynamic LDS
   PH_DECL
-  if (!SECOND && lane == 0) a.counter[W_CNT_START] = 1;       // (for the consumer launch beside this one: see below)
+  if (!SECOND && lane == 0) __hip_atomic_store(a.counter + W_CNT_START, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // (for the consumer launch beside this one: see below)
 
   for (;;) {
     int wi = 0, qi = 0;
@@ -1140,15 +1140,19 @@ __global__ __launch_bounds__(64, SECOND ? C3_WIN_WAVES2 : C3_WIN_WAVES) void k_w
         // overlap -- the first k_window launch of a process waits for the queue's scratch to be (re)allocated, which waits for this kernel;
         // counter passes of a profiler serialise dispatches -- half a millisecond is all this launch may cost
         bool started = false;
-        for (int it = 0; it < 256 && !(started = *(const volatile int*)(a.counter + W_CNT_START) != 0); ++it) __builtin_amdgcn_s_sleep(16);
-        for (int it = 0; started && it < (1 << 20); ++it) {
-          const int done = *(const volatile int*)a.done_flag;          // (read BEFORE the count: with the flag set the count is final)
-          const int nl_ = *(const volatile int*)a.n_win_dev, q = *(const volatile int*)(a.counter + W_CNT_Q2);
+        for (int it = 0; it < 256 && !(started = __hip_atomic_load(a.counter + W_CNT_START, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0); ++it) __builtin_amdgcn_s_sleep(16);
+        for (int it = 0; started && it < (1 << 22); ++it) {
+          const int done = __hip_atomic_load(a.done_flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);          // (read BEFORE the count: with the flag set the count is final)
+          const int nl_ = __hip_atomic_load(a.n_win_dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT), q = __hip_atomic_load(a.counter + W_CNT_Q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           if (q < nl_) {
             if (atomicCAS(a.counter + W_CNT_Q2, q, q + 1) != q) continue;
             qi = q;
-            // (the producer takes its index first and writes the entry right after: a moment, but not none)
-            for (int it2 = 0; it2 < (1 << 20) && (wi = *(const volatile int*)(a.wlist + q)) < 0; ++it2) __builtin_amdgcn_s_sleep(2);
+            // The producer takes its index first and writes the entry right after: a moment, but not none -- and on this device a moment can be
+            // long: a plain store stays in the producing XCD's L2 until that kernel ends, invisible to a consumer on another XCD (the first
+            // version bounded this wait and, when the first launch ran for seconds, gave up on entries it had CLAIMED: six windows of a 250-read
+            // fuzz batch lost, profiles/r06_fuzz_parity.txt).  The entry is stored and loaded with agent scope, and a claimed entry is waited
+            // for without a bound: its producer is a running wave that waits for nothing
+            while ((wi = __hip_atomic_load(a.wlist + q, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)) < 0) __builtin_amdgcn_s_sleep(8);
             break;
           }
           if (done) break;
@@ -1590,7 +1594,12 @@ __global__ __launch_bounds__(64, SECOND ? C3_WIN_WAVES2 : C3_WIN_WAVES) void k_w
       }
     }
     if (fail == 2 && a.ovf_list) {
-      if (lane == 0) a.ovf_list[atomicAdd(a.counter + W_CNT_OVF, 1)] = wi;          // nothing of this window has been published
+      // (nothing of this window has been published; the entry with agent scope: the consumer beside this launch may sit on another XCD)
+      if (lane == 0) {
+        const int k_ = atomicAdd(a.counter + W_CNT_OVF, 1);
+        if (a.dbg_ovf_delay) for (long long t_ = __builtin_readcyclecounter() + (long long)a.dbg_ovf_delay * 100000; (long long)__builtin_readcyclecounter() < t_;) __builtin_amdgcn_s_sleep(64);      // (test hook; s_memtime counts at 100 MHz)
+        __hip_atomic_store(a.ovf_list + k_, wi, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
     } else if (lane == 0) {
       WinRec* r = &a.wrec[wi];
       r->out_len = fail ? -1 : olen; r->polished = polished; r->pad_ = SECOND ? qi + 1 : 0;        // (fail == 2 with no second launch to take it: the window is over the limits)

@@ -248,7 +248,8 @@ int c3_reader_open(const char* path, int n_sets, c3_reader** out);
 int c3_reader_open_range(const char* path, int n_sets, int64_t beg, int64_t end, c3_reader** out);
 /* BGZF (bgzip) input can be cut into ranges as well -- its members are located by their headers without inflating them: the inflated
  * size of the file (-1: not BGZF from end to end), and c3_reader_open_range over [beg, end) in bytes of the INFLATED file.  A plain
- * gzip stream cannot be entered in the middle: c3_reader_open_range refuses it (C3_E_ARG), one c3_reader_open reads it.
+ * gzip stream cannot be entered in the middle: c3_reader_open_range refuses it (C3_E_ARG), one c3_reader_open reads it -- with several
+ * inflating threads behind its one parser (csrc/c3_gzpar.hpp: block starts by trial decoding, the unknown window resolved afterwards).
  * (C3POa.py:201,239 read .gz through one Python gzip stream; the read sharding is C3POa.py:236-256) */
 int64_t c3_bgzf_size(const char* path);
 void c3_reader_close(c3_reader* r);

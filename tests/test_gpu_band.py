@@ -149,6 +149,21 @@ def test_full_size_launch_as_a_consumer_beside_the_first_one(monkeypatch, consum
     h.close()
 
 
+def test_an_overflow_entry_that_appears_seconds_after_its_index_was_taken(monkeypatch):
+    """round 6: the consumer beside the first launch claims an entry of the overflow list as soon as the COUNT says it exists; the entry
+    itself is written a moment later -- and until the writer's store is visible device-wide.  The first version gave up on a claimed
+    entry after about a second and lost the window (found by the fuzz gate on a batch whose first launch ran for seconds:
+    profiles/r06_fuzz_parity.txt).  The test hook makes every producer wait 2.5 s between the two; no window may be lost."""
+    recs = list(synth.generate("cfg2", n_reads=24))
+    want, wcons, t0 = _run(recs, 500, None)
+    monkeypatch.setenv("C3_DEBUG_HCAP_DIV", "100000")
+    monkeypatch.setenv("C3_DEBUG_OVF_DELAY_MS", "2500")
+    monkeypatch.setenv("C3_DEBUG_WIN_CONSUMERS", "64")
+    got, gcons, t1 = _run(recs, 500, None)
+    assert gcons == wcons and np.array_equal(got["status"], want["status"]) and np.array_equal(got["cons_len"], want["cons_len"])
+    assert t1["n_win_redo"] >= 0.9 * t1["n_windows"] > 0 and t1["n_windows"] == t0["n_windows"]
+
+
 def test_results_do_not_depend_on_what_fresh_device_memory_holds(monkeypatch):
     """every device buffer poisoned at allocation (C3_DEBUG_POISON): nothing may read a scratch cell it did not write -- with the
     usual scratch and with the tiny first-launch scratch that sends the windows through the abort + second-launch path"""
