@@ -182,6 +182,11 @@ __device__ __forceinline__ int32_t rdcell(const Ctx& c, const int32_t* a, int pb
 #ifndef C3_NEAR1_TYPE0
 #define C3_NEAR1_TYPE0 1       /* near rows with ONE predecessor keep no predecessor byte (it is always 0): row type 0, as the fast rows (round 6) */
 #endif
+#ifndef C3_STEADY_RING
+#define C3_STEADY_RING 0       /* 1: a steady run may start at a row whose one predecessor sits 2 .. PR-1 rows up (cells from the LDS ring).  Built, parity-green,
+                                  SLOWER: cfg2 +6.4 %, cfg3 +3.9 %, cfg4 +2.5 % on distinct reads -- every row kind got slower with it, steady rows 1 977 -> 2 319 cycles, fast rows
+                                  2 934 -> 3 112, although their listings are unchanged: profiles/r06_ab_poa_steady_rows.txt */
+#endif
 #ifndef C3_STEADY_FORK
 #define C3_STEADY_FORK 0       /* steady rows also for rows that a row further down reads (they write the ring at once) */
 #endif
@@ -353,7 +358,7 @@ __device__ __forceinline__ int cv_9to16(int x9, int b8, int& bad) {
 // the first, a target outside the chunk is already final (one gather from hops[]), and the chains inside a chunk are
 // resolved by pointer doubling between lanes (ds_bpermute, at most six rounds).  Replaces log2(n) rounds of pointer jumping
 // over four node arrays in memory by four dependent memory levels per chunk.
-// descriptor A: x = node, y = ring slots (position mod PR) of the first four predecessors, 4 bits each, z = base | nin<<8 | far<<16 | (nin>4)<<17 | fast-row candidate<<18 | sink<<19 | fork<<20, w = qr = Q - rem;
+// descriptor A: x = node, y = ring slots (position mod PR) of the first four predecessors, 4 bits each, z = base | nin<<8 | far<<16 | (nin>4)<<17 | fast-row candidate<<18 | sink<<19 | fork<<20 | one predecessor in the ring<<21 | its slot<<22, w = qr = Q - rem;
 // descriptor B: positions of the first four predecessors.  hops[] (by position) lives in col() (free until the MSA columns).
 __device__ void poa_sweep_desc(Ctx& c, int lane, int Q, bool qlds, const int PR) {
   const int n = c.n;
@@ -393,6 +398,8 @@ __device__ void poa_sweep_desc(Ctx& c, int lane, int Q, bool qlds, const int PR)
       // bit 18: candidate for the fast row (one predecessor, the row above; query in LDS); bit 19: the sink (no DP row)
       // bit 20: some row other than the next one reads this row's cells (the steady row keeps them out of the LDS ring otherwise)
       A.z |= ((unsigned)(qlds && nin == 1 && (int)p[0] == idx - 1 && v != SRC && v != SNK) << 18) | ((unsigned)(v == SNK) << 19) | (fork << 20);
+      // bit 21: one predecessor, 2 .. PR-1 rows up (its cells are in the LDS ring: a steady row can start from there); bits 22-24: its ring slot
+      A.z |= ((unsigned)(qlds && nin == 1 && idx - (int)p[0] >= 2 && idx - (int)p[0] < PR && v != SRC && v != SNK) << 21) | ((p[0] % PR) << 22);
       A.w = (unsigned)(Q - (d - 1));                         // qr: the query column this node would sit on by distance to the sink
       uint4 B; B.x = p[0]; B.y = p[1]; B.z = p[2]; B.w = p[3];
       c.descA()[idx] = A; c.descB()[idx] = B;
@@ -481,6 +488,15 @@ __device__ __forceinline__ int poa_align(Ctx& c, const C3Params& P, int qb, int 
   // band records (begin, end, cell offset: what the traceback reads) of a run of steady rows, rows s_idx0 .. iend - 1, written when the run
   // ends -- one lane per row: within a run the band moves one column per row and the width stays, so the last row's record gives them all
   // (a lane-0 store per row cost three scalar-to-vector moves, the address arithmetic and an EXEC switch in every steady row)
+  // the previous row was a steady row whose cells are still in registers only: into the ring, exactly as the fast row's tail writes them
+  auto flush_ring = [&](int cur_slot) {
+    const int ps = cur_slot == 0 ? PR - 1 : cur_slot - 1;
+    const int cb = ps * PWT + PADL + lane;
+    LH[cb] = (unsigned short)pH; LE1[cb] = (unsigned short)pE1; LE2[cb] = (unsigned short)pE2;
+#pragma unroll
+    for (int f = 1; f < NCHMAX; ++f) { LH[cb + 64 * f] = NEG16; LE1[cb + 64 * f] = NEG16; LE2[cb + 64 * f] = NEG16; }
+    if (lane == 0) { L.meta[ps] = make_int4(u_beg, u_end, u_left, u_right); L.base8[ps] = u_b8; }
+  };
   auto steady_rowm = [&](int iend) {
     const int R = iend - s_idx0, swd = s_end - s_beg + 1;
     for (int t0 = 0; t0 < R; t0 += 64) {
@@ -523,8 +539,19 @@ __device__ __forceinline__ int poa_align(Ctx& c, const C3Params& P, int qb, int 
     // (steady_rowm); and a row whose cells nobody but the next row reads (descriptor bit 20 clear) writes nothing to the LDS ring -- when
     // the NEXT row turns out not to be a fast / steady row, the cells still in registers go there then (ring_stale, below).  Rows with a
     // successor beyond the ring (far) keep the fast row.  The arithmetic of the cells is the fast row's, instruction for instruction.
-    if (!W32 && !WIDE && ((fl & ((1 << 16) | (1 << 18) | (1 << 19) | (C3_STEADY_FORK ? 0 : 1 << 20))) == (1 << 18)) && pv_ok) {
-      if (!st_on) { s_beg = wave_first(u_beg); s_end = wave_first(u_end); s_left = wave_first(u_left); s_right = wave_first(u_right); s_ro = wave_first(u_ncell); s_idx0 = idx; }
+    const unsigned stm = (unsigned)fl & ((1u << 16) | (1u << 18) | (1u << 19) | (1u << 21) | (C3_STEADY_FORK ? 0u : 1u << 20));
+    // (cand2, C3_STEADY_RING: the one predecessor sits 2 .. PR-1 rows up -- the second sibling of a bubble, 25-32 % of cfg4's near rows: a run can
+    // START there, its predecessor's cells and band record come out of the LDS ring instead of the registers)
+    const bool cand2 = C3_STEADY_RING && stm == (1u << 21);
+    if (!W32 && !WIDE && ((stm == (1u << 18) && pv_ok) || cand2)) {
+      int rslot = 0, rb8 = 0;
+      if (cand2) {
+        if (st_on) { steady_rowm(idx); u_beg = s_beg; u_end = s_end; u_left = s_left; u_right = s_right; u_ncell = s_ro; st_on = false; }      // a run ends here
+        if (ring_stale) { flush_ring(slot); ring_stale = false; }        // (cannot be: the row before would have no reader)
+        rslot = (fl >> 22) & 7;
+        const int4 m = L.meta[rslot]; rb8 = wave_first(L.base8[rslot]);
+        s_beg = wave_first(m.x); s_end = wave_first(m.y); s_left = wave_first(m.z); s_right = wave_first(m.w); s_ro = wave_first(u_ncell); s_idx0 = idx;
+      } else if (!st_on) { s_beg = wave_first(u_beg); s_end = wave_first(u_end); s_left = wave_first(u_left); s_right = wave_first(u_right); s_ro = wave_first(u_ncell); s_idx0 = idx; }
       const int qr1 = qr - 1, wd = s_end - s_beg + 1;
       if (min(s_left, qr1) == s_beg + w && s_end < Q && max(s_right, qr1) >= s_end - w && (unsigned)(wd - 1) < 63u && s_ro + 64 <= c.cells_cap) {
         const int beg = s_beg + 1, end = s_end + 1, ro = s_ro;
@@ -536,6 +563,10 @@ __device__ __forceinline__ int poa_align(Ctx& c, const C3Params& P, int qb, int 
           qw = __builtin_amdgcn_alignbit(w1, w0, (unsigned)(cq & 15) * 2);
         }
         st_on = true;
+        if (cand2) {                                                       // the predecessor's cells: lane = its band column, as a row above in registers would sit
+          const int cb = rslot * PWT + PADL + lane;
+          pH = LH[cb]; pE1 = LE1[cb]; pE2 = LE2[cb]; u_b8 = rb8; pv_ok = true;
+        }
         const unsigned long long am = __ballot(lane < wd);                 // active lanes: ONE compare, every select below names this mask
 #define SEL(a, b) ({ int d_; asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(d_) : "v"(b), "v"(a), "s"(am)); d_; })      /* act ? a : b */
         const int qc = (int)(qw & 3u);
@@ -676,15 +707,8 @@ __device__ __forceinline__ int poa_align(Ctx& c, const C3Params& P, int qb, int 
       }
     }
 #if C3_STEADY
-    if (ring_stale) {
-      // the previous row was a steady row and this one reads the ring: its cells (still in registers) and band record go there now,
-      // exactly as the fast row's tail would have written them
-      const int ps = slot == 0 ? PR - 1 : slot - 1;
-      const int cb = ps * PWT + PADL + lane;
-      LH[cb] = (unsigned short)pH; LE1[cb] = (unsigned short)pE1; LE2[cb] = (unsigned short)pE2;
-#pragma unroll
-      for (int f = 1; f < NCHMAX; ++f) { LH[cb + 64 * f] = NEG16; LE1[cb + 64 * f] = NEG16; LE2[cb + 64 * f] = NEG16; }
-      if (lane == 0) { L.meta[ps] = make_int4(u_beg, u_end, u_left, u_right); L.base8[ps] = u_b8; }
+    if (ring_stale) {                                                       // the previous row was a steady row and this one reads the ring
+      flush_ring(slot);
       ring_stale = false;
 #ifdef C3_PHASE_PROF
       ph_acc_[15] += 1;
