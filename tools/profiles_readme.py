@@ -52,6 +52,18 @@ NOTES = {   # what each further file of the round is (facts about HOW it was mad
     "band_verify_configs.txt": "`tools/band_verify_configs.py` (`C3_DEBUG_BAND=verify`): accepted band layers re-aligned unbanded on the device",
     "fuzz_parity.txt": "one line per `tools/fuzz_gate.sh` run, appended by the script: date, kernel-source hash, reads, mismatches",
     "phase_prof_cfg2.txt": "`tools/phase_prof.py` on the `-DC3_PHASE_PROF` build (shares of the wave time, not times)", "phase_prof_cfg4.txt": "the same, cfg4",
+    # ---- round 6
+    "ab_poa_steady_rows.txt": "`k_poa`'s steady rows (DESIGN 5.3): A/B on DISTINCT reads (`tools/ab_poa_distinct.py`) against `-DC3_STEADY=0` -- cfg2 -5.3 %, cfg2 at 15 % errors -3.8 %, cfg3 -1.9 %, cfg4 -0.7 % --; rows that a row further down reads (nothing); `poa_align` as a real call per instance on distinct reads (+1.3 to +3.4 %: not shipped); the tiled A/B incl. EIGHT waves per SIMD (+12 to +35 %); the phase-profiling build's cycles per row kind; one-predecessor near rows without a predecessor byte (-0.8 to -1.5 %, shipped); a steady run that starts from the LDS ring (+2.5 to +6.4 %, not shipped)",
+    "poa_fast_row_run_lengths.txt": "`tools/poa_run_lengths.py` (the oracle counts): rows in runs of k consecutive fast rows, and in runs whose band moved exactly one column at both ends -- the prediction a steady row checks (DESIGN 5.3, first bullet)",
+    "ubench_poa_rows_floor.txt": "`tools/ubench/poa_rows.hip`: the arithmetic of `k_poa`'s rows and nothing else at six waves per SIMD -- steady row 2 005 wave cycles, fast row 2 856, without the scans 1 476, without the direction byte 1 675: the floor of the row formulation",
+    "pmc_icache_cfg2.txt": "`tools/pmc_icache.sh 16384 cfg2`: SQC_ICACHE_* per kernel for the shipped library, the ring-entry variant and `-DC3_STEADY=0`: 0.00 % of the instruction-cache requests miss in every build",
+    "noisy_reads_window_time.txt": "`tools/noisy_window_time.py 8192 1.0 1.5 2.0 [3.0]`: `k_window` on cfg2-shaped reads with the error rates scaled, at the start of the round, with the band width remembered across the layers of a window (four margins), and with the full-size launch as a consumer beside the first launch (on / off)",
+    "ab_window_consumer_beside_first_launch.txt": "`tools/ab_env.py CFG N C3_NO_WIN_CONSUMER`: one resident batch of distinct reads at bench size, the consumer on / off, alternating in one process: `k_window` -1.9 % (cfg2), -4.1 % (cfg4)",
+    "gzip_parallel_decoder_throughput.txt": "`tools/experiments/host_r06_gz.sh` on the GPU box's 16-core quota: zlib, the single-thread decoder and `csrc/c3_gzpar.hpp` with 1-16 threads and three chunk sizes on 1 GB of FASTQ (`gzip -6`)",
+    "cli_500k_gz_parallel_decoder_ab.log": "`tools/cli_throughput.py 500000 --gz --ab C3_GZ_SERIAL`: the command line on a `.gz` file, parallel decoder against the single-thread one, alternating cold processes",
+    "cli_2m_gz_parallel_decoder.log": "`tools/cli_throughput.py 2000000 --gz` on two boxes",
+    "cli_3m_tmpfs.log": "`tools/cli_throughput.py 3000000 --dir /dev/shm` with the round's library",
+    "cli_1m_tmpfs_window_consumer_ab.log": "`tools/cli_throughput.py 1000000 --dir /dev/shm --ab C3_NO_WIN_CONSUMER`: four cold processes",
 }
 
 
@@ -67,7 +79,7 @@ def kernel_ms(path):
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r06"
     L = []
     sha = None
     for wl in ("cfg2_100k", "cfg4_100k", "cfgL_50k"):
@@ -118,8 +130,8 @@ def main():
             q = json.load(open(fj))
             L.append("| `%s`, `.txt` | `tools/pmc_sq.sh %s %s` (two passes of 8 SQ counters): %s; kernel sources `%s` |" % (
                 os.path.basename(fj), q.get("reads"), cfg,
-                "; ".join("`%s` %s vector wave-instructions per counted cell, %.3f per SIMD cycle = %.0f %% of the issue cycles at %.1f cycles each" % (
-                    k, ("%.2f" % v["insts_per_cell"]) if v.get("insts_per_cell") else "-", v["insts_per_simd_cycle"], 100 * v["busy_frac"], q["cycles_per_inst_assumed"])
+                "; ".join("`%s` %s vector wave-instructions per counted cell, %.3f per SIMD cycle = %.0f %% of the issue cycles at %.2f cycles each" % (
+                    k, ("%.2f" % v["insts_per_cell"]) if v.get("insts_per_cell") else "-", v["insts_per_simd_cycle"], 100 * v["busy_frac"], v.get("cycles_per_inst") or q["cycles_per_inst_assumed"])
                     for k, v in q["kernels"].items() if k in ("k_poa", "k_window", "k_conk")), q.get("kernel_src_sha")))
     for name, note in NOTES.items():
         f = os.path.join(P, "%s_%s" % (tag, name))
