@@ -212,6 +212,7 @@ struct ParChunk {
 struct GzPar {
   const uint8_t* map = nullptr; size_t size = 0;
   int T = 4; size_t chunk = (size_t)1 << 20;
+  size_t head = 0;                         // bytes left free in front of every chunk's output (the reader moves a partial line there and takes the buffer as it is)
   size_t next_bit = 0; bool next_known = true; bool started = false, done = false, bad = false;
   std::vector<uint8_t> window;             // last 32 KiB of everything produced so far (front padded with zeros)
   uint32_t run_crc = 0; uint64_t run_len = 0;     // the member that is still open: CRC-32 and length so far
@@ -325,8 +326,8 @@ struct GzPar {
       ParChunk& c = chunks[(size_t)j];
       if (c.start == (size_t)-1) return;
       const size_t m = c.sym.len;
-      c.out.resize(m);
-      const uint16_t* s = c.sym.p; const uint8_t* wv = c.window.data(); char* o = c.out.data();
+      c.out.resize(head + m);
+      const uint16_t* s = c.sym.p; const uint8_t* wv = c.window.data(); char* o = c.out.data() + head;
       for (size_t i = 0; i < m; ++i) { const uint16_t v = s[i]; o[i] = (char)(v < 256 ? (uint8_t)v : wv[v & 0x7fffu]); }
       c.sym.release();
       size_t at = 0;

@@ -325,7 +325,7 @@ void gzpar_thread(GzParReader* g) {
     const bool ok = g->par.next_round();
     std::vector<std::vector<char>>& dst = g->ready[g->prod];
     dst.clear();
-    if (ok) for (c3inf::ParChunk& c : g->par.chunks) if (c.start != (size_t)-1 && !c.out.empty()) dst.emplace_back(std::move(c.out));
+    if (ok) for (c3inf::ParChunk& c : g->par.chunks) if (c.start != (size_t)-1 && c.out.size() > g->par.head) dst.emplace_back(std::move(c.out));
     lk.lock();
     if (g->par.bad) { g->bad = true; g->done = true; g->cv.notify_all(); return; }
     if (!dst.empty()) { g->full[g->prod] = true; g->prod ^= 1; }
@@ -349,12 +349,40 @@ long gzpar_read(GzParReader* g, char* dst, size_t room) {
     std::vector<std::vector<char>>& cs = g->ready[g->cons];
     if (g->ci < cs.size()) {
       std::vector<char>& c = cs[g->ci];
-      const size_t k = std::min(room, c.size() - g->cpos);
-      memcpy(dst, c.data() + g->cpos, k); g->cpos += k;
-      if (g->cpos == c.size()) { std::vector<char>().swap(c); ++g->ci; g->cpos = 0; }
+      const size_t hd = g->par.head;                                 // (the chunk's bytes sit behind `head` free ones: gzpar_swap)
+      const size_t k = std::min(room, c.size() - hd - g->cpos);
+      memcpy(dst, c.data() + hd + g->cpos, k); g->cpos += k;
+      if (g->cpos == c.size() - hd) { std::vector<char>().swap(c); ++g->ci; g->cpos = 0; }
       if (k) return (long)k;
     }
     if (g->ci >= cs.size()) { lk.lock(); g->full[g->cons] = false; g->cons ^= 1; g->ci = 0; g->cpos = 0; g->cv.notify_all(); }
+  }
+}
+// The next chunk WITHOUT a copy: the reader's buffer and the chunk's buffer change places, the unread rest of the reader's buffer (a partial
+// line: `*end - *beg` bytes) is moved into the free bytes in front of the chunk first.  1 = done, 0 = end of the input, -1 = damaged stream,
+// -2 = not applicable right now (a chunk partly handed out by gzpar_read, or a rest longer than the free space): the caller copies instead.
+// (One pass over the inflated bytes less on the one thread every byte of the file goes through: the parser.)
+int gzpar_swap(GzParReader* g, std::vector<char>& buf, size_t* beg, size_t* end) {
+  if (!g->started) return -2;
+  for (;;) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->cv.wait(lk, [g] { return g->full[g->cons] || g->done; });
+    if (g->bad) return -1;
+    if (!g->full[g->cons]) return 0;
+    lk.unlock();
+    std::vector<std::vector<char>>& cs = g->ready[g->cons];
+    if (g->ci < cs.size()) {
+      std::vector<char>& c = cs[g->ci];
+      const size_t hd = g->par.head, left = *end - *beg;
+      if (g->cpos != 0 || left > hd) return -2;
+      memcpy(c.data() + hd - left, buf.data() + *beg, left);
+      buf.swap(c);
+      *beg = hd - left; *end = buf.size();
+      std::vector<char>().swap(c); ++g->ci;
+      if (g->ci >= cs.size()) { lk.lock(); g->full[g->cons] = false; g->cons ^= 1; g->ci = 0; g->cpos = 0; g->cv.notify_all(); }
+      return 1;
+    }
+    lk.lock(); g->full[g->cons] = false; g->cons ^= 1; g->ci = 0; g->cpos = 0; g->cv.notify_all();
   }
 }
 void gzpar_close(GzParReader* g) {
@@ -499,6 +527,13 @@ long bgzf_read(Bgzf* b, char* dst, size_t room) {
 
 bool refill(c3_reader* r) {
   if (r->eof) return false;
+  if (r->gzp && r->gzp->started) {
+    // plain gzip by several threads: take the next chunk's buffer as it is (the unread rest of this one moves in front of it)
+    const int rc = gzpar_swap(r->gzp, r->buf, &r->beg, &r->end);
+    if (rc == 1) return true;
+    if (rc == -1) { r->gz_bad = true; r->eof = true; return false; }
+    if (rc == 0) { r->eof = true; return false; }
+  }
   if (r->beg > 0) { memmove(r->buf.data(), r->buf.data() + r->beg, r->end - r->beg); r->end -= r->beg; r->buf_off += (int64_t)r->beg; r->beg = 0; }
   if (r->end == r->buf.size()) r->buf.resize(r->buf.size() * 2);
   size_t room = r->buf.size() - r->end;
@@ -600,6 +635,7 @@ extern "C" int c3_reader_open(const char* path, int n_sets, c3_reader** out) {
             if (T > 1 && !getenv("C3_GZ_SERIAL") && (size_t)sb.st_size >= 2 * chunk) {
               r->gzp = new GzParReader(); r->gzp->fd = fd; r->gzp->map = (const uint8_t*)mp; r->gzp->size = (size_t)sb.st_size;
               r->gzp->par.map = r->gzp->map; r->gzp->par.size = r->gzp->size; r->gzp->par.T = T; r->gzp->par.chunk = chunk;
+              r->gzp->par.head = getenv("C3_GZ_CHUNK") ? 4096 : (size_t)512 << 10;       // (room for a partial line in front of every chunk: see gzpar_swap)
             } else {
               r->gzf = new GzFast(); r->gzf->fd = fd; r->gzf->map = (const uint8_t*)mp; r->gzf->size = (size_t)sb.st_size;
             }

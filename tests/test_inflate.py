@@ -243,3 +243,26 @@ def test_plain_gz_file_through_the_reader_with_several_inflating_threads(tmp_pat
     monkeypatch.setenv("C3_GZ_THREADS", "4")
     with pytest.raises(Exception):
         _read_all(str(bad))
+
+
+def test_plain_gz_with_default_chunks_hands_buffers_over_without_copying(tmp_path, monkeypatch):
+    """a file of several default-size (1 MiB) chunks: the parser takes every chunk's buffer as it is (gzpar_swap: the partial line at the end
+    of one buffer moves into the free bytes in front of the next) -- records equal the plain file's, lines of 30 kb among them (a rest
+    longer than usual) and one line longer than the free space in front of a chunk (that refill copies instead)"""
+    rng = random.Random(12)
+    recs = []
+    for i in range(1400):
+        n = rng.choice([3000, 9000, 30000]) + rng.randint(0, 500)
+        if i == 700:
+            n = 700000                                     # longer than the 512 KiB in front of a chunk
+        recs.append(("q%d" % i, "".join(rng.choice("ACGT") for _ in range(n)), "".join(chr(rng.randint(40, 60)) for _ in range(n))))
+    text = "".join("@%s\n%s\n+\n%s\n" % r for r in recs).encode()
+    plain = tmp_path / "b.fastq"
+    plain.write_bytes(text)
+    gzp = tmp_path / "b.fastq.gz"
+    gzp.write_bytes(gzip.compress(text, 1))
+    assert gzp.stat().st_size > 4 << 20
+    want = _read_all(str(plain))
+    for th in ("4", "2"):
+        monkeypatch.setenv("C3_GZ_THREADS", th)
+        assert _read_all(str(gzp)) == want
