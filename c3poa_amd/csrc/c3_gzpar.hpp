@@ -8,19 +8,19 @@
 //   1. the compressed file is cut into chunks of `chunk` bytes; in every chunk but the first a thread looks for the first bit offset
 //      that holds a DYNAMIC block header whose three Huffman codes are complete and whose block decodes to its end-of-block symbol
 //      with another well-formed block header behind it (probe);
-//   2. every thread decodes from its offset with an UNKNOWN window: symbols are 16 bits wide, a literal is its byte, a copy from
-//      before the chunk yields the marker 0x8000 | k for byte k of the 32 KiB before the chunk (copies of markers copy the marker),
-//      and it stops at the block boundary where the next chunk begins;
+//   2. every thread decodes from its offset with an UNKNOWN window: a copy from before the chunk yields a MARK -- "this byte is byte k of
+//      the 32 KiB before the chunk" -- kept beside the bytes (a bitmap + a sorted list), copies of marked bytes copy the mark, and it
+//      stops at the block boundary where the next chunk begins;
 //   3. the chunks are chained in order: the chunk before must have stopped EXACTLY where this one started (an offset that is not a
 //      block boundary of the real stream -- a false positive of step 1 -- is found out here, structurally: its chunk is dropped and
 //      the chunk before decodes on through it), its last 32 KiB, resolved, are this chunk's window;
-//   4. every thread replaces the markers of its chunk, narrows the symbols to bytes and takes the CRC-32 of every stretch of a gzip
-//      member in it; the stretches are combined (crc32_combine) and checked against every member's trailer, as is its length.
+//   4. every thread fills in the marked bytes of its chunk and takes the CRC-32 of every stretch of a gzip member in it; the stretches are combined (crc32_combine) and checked against every member's trailer, as is its length.
 //
 // Members may be concatenated (one stream, as for gzread); bytes behind the last member that are no gzip header end the input.
 // The code is this repository's own; zlib supplies crc32 / crc32_combine only.
 #pragma once
 #include "c3_inflate.hpp"
+#include "c3_crc32.hpp"
 #include <zlib.h>
 #include <algorithm>
 #include <atomic>
@@ -44,22 +44,40 @@ static inline const uint8_t* gz_member_data(const uint8_t* p, size_t n) {
   return p + q;
 }
 
-// growable array of 16-bit symbols WITHOUT value-initialisation (std::vector::resize would fill megabytes with zeros per probe)
-struct SymBuf {
-  uint16_t* p = nullptr; size_t cap = 0, len = 0;
-  SymBuf() {}
-  SymBuf(const SymBuf&) = delete; SymBuf& operator=(const SymBuf&) = delete;
-  SymBuf(SymBuf&& o) noexcept : p(o.p), cap(o.cap), len(o.len) { o.p = nullptr; o.cap = o.len = 0; }
-  SymBuf& operator=(SymBuf&& o) noexcept { if (this != &o) { free(p); p = o.p; cap = o.cap; len = o.len; o.p = nullptr; o.cap = o.len = 0; } return *this; }
-  ~SymBuf() { free(p); }
-  void release() { free(p); p = nullptr; cap = len = 0; }
-  bool reserve(size_t need) {
-    if (need <= cap) return true;
-    size_t nc = cap ? cap : (size_t)1 << 16;
+// What one chunk decodes into when the 32 KiB before it are unknown: BYTES, in the buffer the parser will read them from, plus -- for the
+// few positions whose value is a byte of that unknown window -- a mark: a bit in a bitmap (one per output byte) and an entry (position,
+// index into the window) in a list that is sorted by position because positions only grow.  A copy whose source holds no mark is the
+// ordinary byte copy; one whose source may hold marks (its first byte lies before `mk_end`, one past the last mark, AND a bitmap word of
+// its range is non-zero) goes byte by byte and carries the marks along.  (The first version decoded into 16-bit symbols, a literal its
+// byte, a window byte 0x8000 | index: half the copy rate, a second pass to narrow the symbols, ~0.4x the rate of the plain decoder.  FASTQ
+// keeps a few marks alive through a whole chunk -- every header is copied from the one before -- so "switch to bytes once the last 32 KiB
+// are clean", the published trick, never fires on it; marks are ~0.5 % of the bytes, and this form pays for them only where they are.)
+struct ChunkBuf {
+  std::vector<char> out;                   // `head` free bytes, then the chunk's bytes
+  size_t head = 0, len = 0, mk_end = 0;
+  std::vector<uint64_t> bits;              // bit i: byte i is a placeholder for a byte of the unknown window
+  std::vector<std::pair<size_t, uint16_t>> marks;      // (position, window index), increasing positions
+  std::vector<uint32_t> first;             // per 64 bytes with a mark: the index of its first mark in `marks`
+  bool grow(size_t need) {                 // room for `need` bytes (and their bits) behind `head`
+    if (head + need <= out.size()) return true;
+    size_t nc = std::max<size_t>(out.size() > head ? out.size() - head : 0, (size_t)1 << 16);
     while (nc < need) nc *= 2;
-    uint16_t* q = (uint16_t*)realloc(p, nc * sizeof(uint16_t));
-    if (!q) return false;
-    p = q; cap = nc; return true;
+    out.resize(head + nc);
+    bits.resize(nc / 64 + 2, 0); first.resize(nc / 64 + 2);
+    return true;
+  }
+  bool has_marks(size_t src, size_t n) const {          // (conservative: whole words)
+    for (size_t w = src >> 6, we = (src + n - 1) >> 6; w <= we; ++w) if (bits[w]) return true;
+    return false;
+  }
+  uint16_t widx_at(size_t p) const {        // (p is marked) marks are appended in order of position: rank within the word
+    const uint64_t b = bits[p >> 6];
+    return marks[first[p >> 6] + (size_t)__builtin_popcountll(b & ((1ull << (p & 63)) - 1))].second;
+  }
+  void mark(size_t p, uint16_t widx) {
+    uint64_t& b = bits[p >> 6];
+    if (!b) first[p >> 6] = (uint32_t)marks.size();
+    b |= 1ull << (p & 63); marks.emplace_back(p, widx); mk_end = p + 1;
   }
 };
 
@@ -75,45 +93,107 @@ struct Dec16 {
   }
   size_t bitpos() const { return (size_t)(z.in - base) * 8 - z.bitcnt; }
 
-  // Decode blocks from the current position into out (symbols appended; `known` = the decoder starts at the first block of a member, so
-  // nothing may be copied from before out[0]).  Stops at the first block boundary at or beyond stop_bit that lies behind the start
-  // (returns 0), at the end of the last member (1), or on an error / more than max_syms symbols (-1).  *end_bit = where it stopped.
-  int run(SymBuf& out, size_t stop_bit, size_t* end_bit, bool known, std::vector<MemberEnd>& ends, size_t max_syms) {
+  // Decode blocks from the current position into `co` (bytes appended; `known` = the decoder starts at the first block of a member, so
+  // nothing may be copied from before the chunk).  Stops at the first block boundary at or beyond stop_bit that lies behind the start
+  // (returns 0), at the end of the last member (1), or on an error / more than max_out bytes (-1).  *end_bit = where it stopped.
+  int run(ChunkBuf& co, size_t stop_bit, size_t* end_bit, bool known, std::vector<MemberEnd>& ends, size_t max_out) {
     const size_t start_bit = bitpos();
-    size_t pos = out.len;
-    if (!out.reserve(pos + 65536)) return -1;
-    uint16_t* o = out.p; size_t capv = out.cap;
-    size_t mstart = 0;                       // first symbol of the member being decoded (0: the chunk began inside it, or with it when `known`)
-    bool reach = !known;                     // copies may reach up to 32 KiB before out[0]
+    size_t pos = co.len;
+    co.grow(pos + 65536);
+    uint8_t* o = (uint8_t*)co.out.data() + co.head; size_t capv = co.out.size() - co.head;
+    size_t mstart = 0;                       // first byte of the member being decoded (0: the chunk began inside it, or with it when `known`)
+    bool reach = !known;                     // copies may reach up to 32 KiB before the chunk
     const uint32_t LM = (1u << LIT_BITS) - 1;
-    auto fail = [&]() { out.len = pos; return -1; };
+    auto fail = [&]() { co.len = pos; return -1; };
+#define C3GZ_ROOM(n_) if (pos + (n_) + 600 > capv) { if (pos + (n_) + 600 > max_out) return fail(); co.grow(std::max(pos + (n_) + 600, 2 * capv)); o = (uint8_t*)co.out.data() + co.head; capv = co.out.size() - co.head; }
     for (;;) {
       const size_t bp = bitpos();
-      if (bp >= stop_bit && bp > start_bit) { *end_bit = bp; out.len = pos; return 0; }
+      if (bp >= stop_bit && bp > start_bit) { *end_bit = bp; co.len = pos; return 0; }
       if (!z.read_block_header()) return fail();
       if (z.btype == 0) {
-        size_t n = z.stored_left;
+        const size_t n = z.stored_left;
         if (n > (size_t)(fend - z.in)) return fail();
-        if (pos + n + 600 > capv) { if (pos + n + 600 > max_syms || !out.reserve(pos + n + 600)) return fail(); o = out.p; capv = out.cap; }
-        for (size_t i = 0; i < n; ++i) o[pos + i] = z.in[i];
+        C3GZ_ROOM(n)
+        memcpy(o + pos, z.in, n);
         z.in += n; pos += n; z.stored_left = 0;
       } else {
         for (;;) {
-          if (pos + 600 > capv) { if (capv * 2 > max_syms || !out.reserve(capv * 2)) return fail(); o = out.p; capv = out.cap; }
-          const bool fast = (size_t)(fend - z.in) >= 16;
+          C3GZ_ROOM(0)
+          if ((size_t)(fend - z.in) >= 16) {
+            // FAST LOOP (as Inflater::run's: no per-symbol bounds checks while 16 bytes of input and 600 of room are certain; the bit buffer lives in
+            // locals, stores through `o` may alias the decoder's fields).  Leaves at a second-level literal/length code, the end of the block, a
+            // copy from before the chunk or anything damaged: the careful code below decodes that symbol again.
+            uint64_t bb = z.bitbuf; unsigned bc = z.bitcnt; const uint8_t* in = z.in; const uint8_t* const in_stop = fend - 16;
+            const uint32_t* const lit = z.lit; const uint32_t* const dist = z.dist;
+            const size_t lim = capv - 600;
+            while (in <= in_stop && pos <= lim) {
+              { uint64_t w; memcpy(&w, in, 8); bb |= w << bc; const unsigned add = (63 - bc) >> 3; in += add; bc += add * 8; }
+              uint32_t e = lit[bb & LM];
+#define C3INF_LITB() { bb >>= e_len(e); bc -= e_len(e); const uint32_t v_ = e_val(e), two_ = e_extra(e); o[pos] = (uint8_t)v_; o[pos + 1] = (uint8_t)(v_ >> 8); pos += 1 + two_; e = lit[bb & LM]; }
+              if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) {
+                C3INF_LITB()
+                if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) {
+                  C3INF_LITB()
+                  if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) C3INF_LITB()
+                }
+              }
+#undef C3INF_LITB
+              if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) continue;
+              if ((e & (K_MASK | K_VALID)) != (K_LEN | K_VALID)) break;
+              const uint64_t bb0 = bb; const unsigned bc0 = bc; const uint8_t* const in0 = in;          // (to hand this symbol to the careful code)
+              bb >>= e_len(e); bc -= e_len(e);
+              unsigned len = e_val(e); const unsigned xb = e_extra(e);
+              len += (unsigned)(bb & ((1u << xb) - 1)); bb >>= xb; bc -= xb;
+              { uint64_t w; memcpy(&w, in, 8); bb |= w << bc; const unsigned add = (63 - bc) >> 3; in += add; bc += add * 8; }
+              uint32_t d = dist[bb & ((1u << DIST_BITS) - 1)];
+              if ((d & (K_MASK | K_VALID)) == (K_SUB | K_VALID)) { d = dist[e_val(d) + ((bb >> DIST_BITS) & ((1u << e_extra(d)) - 1))]; bb >>= DIST_BITS; bc -= DIST_BITS; }
+              if ((d & (K_MASK | K_VALID)) != (K_LEN | K_VALID)) { bb = bb0; bc = bc0; in = in0; break; }
+              bb >>= e_len(d); bc -= e_len(d);
+              unsigned dd = e_val(d); const unsigned db = e_extra(d);
+              dd += (unsigned)(bb & ((1u << db) - 1)); bb >>= db; bc -= db;
+              if ((size_t)dd > pos - mstart) { bb = bb0; bc = bc0; in = in0; break; }
+              const size_t src = pos - dd;
+              // the marks of the source: for the common copy (no longer than 64 bytes, not overlapping itself) the exact bits of its range
+              uint64_t mm = 0; bool slow = false;
+              if (src < co.mk_end) {
+                if (len <= 64 && dd >= len) {
+                  const unsigned sh = (unsigned)(src & 63); const uint64_t* bw = co.bits.data() + (src >> 6);
+                  mm = bw[0] >> sh; if (sh) mm |= bw[1] << (64 - sh);
+                  if (len < 64) mm &= (1ull << len) - 1;
+                } else slow = co.has_marks(src, std::min<size_t>(len, dd));
+              }
+              if (!slow) {
+                uint8_t* dst = o + pos; const uint8_t* sp = dst - dd; uint8_t* const end = dst + len;
+                if (dd >= 8) { do { uint64_t w; memcpy(&w, sp, 8); memcpy(dst, &w, 8); sp += 8; dst += 8; } while (dst < end); }
+                else if (dd == 1) memset(dst, *sp, len);
+                else { do { *dst++ = *sp++; } while (dst < end); }
+                while (mm) { const unsigned i = (unsigned)__builtin_ctzll(mm); mm &= mm - 1; co.mark(pos + i, co.widx_at(src + i)); }
+              } else {
+                for (unsigned i = 0; i < len; ++i) {
+                  const size_t sp = src + i;
+                  o[pos + i] = o[sp];
+                  if ((co.bits[sp >> 6] >> (sp & 63)) & 1) co.mark(pos + i, co.widx_at(sp));
+                }
+              }
+              pos += len;
+            }
+            z.bitbuf = bb; z.bitcnt = bc; z.in = in;
+            C3GZ_ROOM(0)
+          }
+          const bool fast = false;
           if (fast) z.refill_fast(); else z.refill_safe();
           uint32_t e = z.lit[z.bitbuf & LM];
           if (fast) {
             // up to three literal lookups (one or two bytes each, at most 11 bits each) out of one refill, as in Inflater::run
-#define C3INF_LIT16() { z.bitbuf >>= e_len(e); z.bitcnt -= e_len(e); const uint32_t v_ = e_val(e), two_ = e_extra(e); o[pos] = (uint16_t)(v_ & 0xff); o[pos + 1] = (uint16_t)(v_ >> 8); pos += 1 + two_; e = z.lit[z.bitbuf & LM]; }
+#define C3INF_LITB() { z.bitbuf >>= e_len(e); z.bitcnt -= e_len(e); const uint32_t v_ = e_val(e), two_ = e_extra(e); o[pos] = (uint8_t)v_; o[pos + 1] = (uint8_t)(v_ >> 8); pos += 1 + two_; e = z.lit[z.bitbuf & LM]; }
             if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) {
-              C3INF_LIT16()
+              C3INF_LITB()
               if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) {
-                C3INF_LIT16()
-                if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) C3INF_LIT16()
+                C3INF_LITB()
+                if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) C3INF_LITB()
               }
             }
-#undef C3INF_LIT16
+#undef C3INF_LITB
             if ((e & (K_MASK | K_VALID)) == (K_LIT | K_VALID)) continue;
           }
           if ((e & (K_MASK | K_VALID)) == (K_SUB | K_VALID)) {
@@ -123,7 +203,7 @@ struct Dec16 {
           if (!(e & K_VALID) || e_len(e) > z.bitcnt) return fail();
           z.bitbuf >>= e_len(e); z.bitcnt -= e_len(e);
           const uint32_t kind = e & K_MASK;
-          if (kind == K_LIT) { o[pos++] = (uint16_t)(e_val(e) & 0xff); if (e_extra(e)) o[pos++] = (uint16_t)(e_val(e) >> 8); continue; }
+          if (kind == K_LIT) { o[pos++] = (uint8_t)e_val(e); if (e_extra(e)) o[pos++] = (uint8_t)(e_val(e) >> 8); continue; }
           if (kind == K_EOB) break;
           unsigned len = e_val(e), xb = e_extra(e);
           if (xb) { if (z.bitcnt < xb) return fail(); len += (unsigned)(z.bitbuf & ((1u << xb) - 1)); z.bitbuf >>= xb; z.bitcnt -= xb; }
@@ -138,14 +218,30 @@ struct Dec16 {
           unsigned dd = e_val(d), db = e_extra(d);
           if (db) { if (z.bitcnt < db) { z.refill_safe(); if (z.bitcnt < db) return fail(); } dd += (unsigned)(z.bitbuf & ((1u << db) - 1)); z.bitbuf >>= db; z.bitcnt -= db; }
           if ((size_t)dd <= pos - mstart) {
-            uint16_t* dst = o + pos; const uint16_t* src = dst - dd; uint16_t* const end = dst + len;
-            if (dd >= 4) { do { uint64_t w; memcpy(&w, src, 8); memcpy(dst, &w, 8); src += 4; dst += 4; } while (dst < end); }      // (room: 600 symbols were ensured)
-            else { do { *dst++ = *src++; } while (dst < end); }
+            const size_t src = pos - dd;
+            if (src < co.mk_end && co.has_marks(src, std::min<size_t>(len, dd))) {
+              // the source may hold marks: byte by byte, the marks travel with their bytes (an overlapping copy reads what it has just written,
+              // marks included)
+              for (unsigned i = 0; i < len; ++i) {
+                const size_t sp = src + i;
+                o[pos + i] = o[sp];
+                if ((co.bits[sp >> 6] >> (sp & 63)) & 1) co.mark(pos + i, co.widx_at(sp));
+              }
+            } else {
+              uint8_t* dst = o + pos; const uint8_t* sp = dst - dd; uint8_t* const end = dst + len;
+              if (dd >= 8) { do { uint64_t w; memcpy(&w, sp, 8); memcpy(dst, &w, 8); sp += 8; dst += 8; } while (dst < end); }      // (room: 600 bytes were ensured)
+              else if (dd == 1) memset(dst, *sp, len);
+              else { do { *dst++ = *sp++; } while (dst < end); }
+            }
           } else {
-            // from before the chunk: markers for the part that lies there
+            // from before the chunk: marks for the part that lies there
             if (mstart != 0 || !reach || (size_t)dd - pos > 32768) return fail();
             const long long p0 = (long long)pos - (long long)dd;
-            for (unsigned i = 0; i < len; ++i) { const long long p = p0 + i; o[pos + i] = p >= 0 ? o[p] : (uint16_t)(0x8000u | (unsigned)(32768 + p)); }
+            for (unsigned i = 0; i < len; ++i) {
+              const long long q = p0 + i;
+              if (q < 0) { o[pos + i] = 0; co.mark(pos + i, (uint16_t)(32768 + q)); }
+              else { o[pos + i] = o[q]; if ((co.bits[(size_t)q >> 6] >> ((size_t)q & 63)) & 1) co.mark(pos + i, co.widx_at((size_t)q)); }
+            }
           }
           pos += len;
         }
@@ -160,17 +256,17 @@ struct Dec16 {
         ends.push_back({pos, crc, isz});
         const uint8_t* nx = t + 8;
         const uint8_t* data = nx < fend ? gz_member_data(nx, (size_t)(fend - nx)) : nullptr;
-        if (!data) { *end_bit = (size_t)(nx - base) * 8; out.len = pos; return 1; }      // (trailing bytes that are no member end the input, as zlib does)
+        if (!data) { *end_bit = (size_t)(nx - base) * 8; co.len = pos; return 1; }      // (trailing bytes that are no member end the input, as zlib does)
         seek((size_t)(data - base) * 8);
         mstart = pos; reach = false;
-        if (mstart == 0) { reach = false; known = true; }
       }
     }
+#undef C3GZ_ROOM
   }
 
   // first bit offset in [from, to) that opens a dynamic block which decodes to its end with a well-formed block header behind it;
   // (size_t)-1 when there is none.  tmp: scratch
-  size_t find_block(size_t from, size_t to, SymBuf& tmp, std::vector<MemberEnd>& tends) {
+  size_t find_block(size_t from, size_t to, ChunkBuf& tmp, std::vector<MemberEnd>& tends) {
     const size_t nbits = (size_t)(fend - base) * 8;
     if (to > nbits) to = nbits;
     for (size_t bit = from; bit + 64 < nbits && bit < to; ++bit) {
@@ -184,7 +280,8 @@ struct Dec16 {
       if (!z.read_block_header()) continue;
       // ... the block must decode to its end-of-block symbol, and a well-formed header must follow
       seek(bit);
-      tmp.len = 0; tends.clear();
+      if (tmp.len) { for (size_t i = 0; i <= tmp.len / 64 + 1 && i < tmp.bits.size(); ++i) tmp.bits[i] = 0; }
+      tmp.len = 0; tmp.mk_end = 0; tmp.marks.clear(); tends.clear();
       size_t eb = 0;
       const int rc = run(tmp, bit + 1, &eb, false, tends, (size_t)1 << 24);       // exactly one block (stops at the next boundary)
       if (rc < 0) continue;
@@ -200,10 +297,9 @@ struct ParChunk {
   size_t start = (size_t)-1, end = 0;      // bit offsets (start: -1 = no block start found: the chunk before decodes through)
   bool known = false;                      // starts at the first block of a member
   int rc = 0;                              // result of the decode: 0 stopped at a boundary, 1 end of the input, -1 error
-  SymBuf sym;
+  ChunkBuf cb;                             // cb.out: the chunk's bytes behind `head` free ones
   std::vector<MemberEnd> ends;
   std::vector<uint8_t> window;             // the 32 KiB before the chunk (resolved), oldest first, 32768 bytes (front padded)
-  std::vector<char> out;                   // final bytes
   std::vector<uint32_t> seg_crc; std::vector<size_t> seg_len;     // CRC-32 of every stretch between member ends (ends.size() + 1 stretches)
 };
 
@@ -254,7 +350,7 @@ struct GzPar {
       const size_t from = (b0 + (size_t)(j + 1) * chunk) * 8;
       if (from >= nbits) return;
       Dec16 d; d.base = map; d.fend = map + size;
-      SymBuf tmp; std::vector<MemberEnd> te;
+      ChunkBuf tmp; std::vector<MemberEnd> te;
       // (the last one -- where the next round starts -- searches on until it finds one: a round must end at a block boundary)
       const size_t to = j + 1 < n ? from + chunk * 8 : nbits;
       starts[(size_t)j + 1] = d.find_block(from, to, tmp, te);
@@ -271,8 +367,9 @@ struct GzPar {
       if (c.start == (size_t)-1) return;
       Dec16 d; d.base = map; d.fend = map + size;
       d.seek(c.start);
-      c.sym.reserve(chunk * 4);
-      c.rc = d.run(c.sym, target_of(j), &c.end, c.known, c.ends, (size_t)1 << 30);
+      c.cb.head = head;
+      c.cb.grow(chunk * 4);
+      c.rc = d.run(c.cb, target_of(j), &c.end, c.known, c.ends, (size_t)1 << 30);
     });
 #ifdef C3_GZPAR_PROF
     const double T2 = now_();
@@ -291,13 +388,13 @@ struct GzPar {
       if (want == (size_t)-1 || p.end < want) { bad = true; return false; }          // (cannot happen: p stops at the first boundary at or beyond its target)
       if (p.end == want) { if (nx < 0) break; cur = nx; continue; }
       if (nx < 0) { rend = p.end; break; }                                           // the next round's start was the false positive: it begins where p stopped
-      chunks[(size_t)nx].start = (size_t)-1; chunks[(size_t)nx].sym.release(); chunks[(size_t)nx].ends.clear();
+      chunks[(size_t)nx].start = (size_t)-1; chunks[(size_t)nx].cb = ChunkBuf(); chunks[(size_t)nx].ends.clear();
       size_t tgt = rend;
       for (int k = nx + 1; k < n; ++k) if (chunks[(size_t)k].start != (size_t)-1) { tgt = chunks[(size_t)k].start; break; }
       if (tgt == (size_t)-1 || p.end < tgt) {
         Dec16 d; d.base = map; d.fend = map + size;
         d.seek(p.end);
-        p.rc = d.run(p.sym, tgt, &p.end, p.known, p.ends, (size_t)1 << 30);
+        p.rc = d.run(p.cb, tgt, &p.end, p.known, p.ends, (size_t)1 << 30);
       }
     }
     {
@@ -314,27 +411,28 @@ struct GzPar {
       ParChunk& c = chunks[(size_t)j];
       if (c.start == (size_t)-1) continue;
       c.window = w;
-      const size_t m = c.sym.len;
-      const size_t keep = std::min<size_t>(m, 32768);
+      // this chunk's last 32 KiB: its bytes, the marks among them resolved from the window before it
+      const size_t m = c.cb.len, keep = std::min<size_t>(m, 32768);
       std::vector<uint8_t> nw(32768, 0);
       if (keep < 32768) memcpy(nw.data(), w.data() + keep, 32768 - keep);
-      for (size_t i = 0; i < keep; ++i) { const uint16_t s = c.sym.p[m - keep + i]; nw[32768 - keep + i] = s < 256 ? (uint8_t)s : w[s & 0x7fffu]; }
+      memcpy(nw.data() + 32768 - keep, c.cb.out.data() + c.cb.head + (m - keep), keep);
+      for (size_t k = c.cb.marks.size(); k-- > 0 && c.cb.marks[k].first >= m - keep;) nw[32768 - keep + (c.cb.marks[k].first - (m - keep))] = w[c.cb.marks[k].second & 0x7fffu];
       w.swap(nw);
     }
     window = w;
     parallel(n, [&](int j) {
       ParChunk& c = chunks[(size_t)j];
       if (c.start == (size_t)-1) return;
-      const size_t m = c.sym.len;
-      c.out.resize(head + m);
-      const uint16_t* s = c.sym.p; const uint8_t* wv = c.window.data(); char* o = c.out.data() + head;
-      for (size_t i = 0; i < m; ++i) { const uint16_t v = s[i]; o[i] = (char)(v < 256 ? (uint8_t)v : wv[v & 0x7fffu]); }
-      c.sym.release();
+      const size_t m = c.cb.len;
+      c.cb.out.resize(head + m);
+      char* o = c.cb.out.data() + head; const uint8_t* wv = c.window.data();
+      for (const auto& mk : c.cb.marks) o[mk.first] = (char)wv[mk.second & 0x7fffu];
+      std::vector<uint64_t>().swap(c.cb.bits); std::vector<std::pair<size_t, uint16_t>>().swap(c.cb.marks); std::vector<uint32_t>().swap(c.cb.first);
       size_t at = 0;
       for (size_t k = 0; k <= c.ends.size(); ++k) {
         const size_t to = k < c.ends.size() ? c.ends[k].off : m;
         uint32_t cr = (uint32_t)crc32(0L, Z_NULL, 0);
-        for (size_t p = at; p < to;) { const size_t q = std::min<size_t>(to - p, (size_t)1 << 30); cr = (uint32_t)crc32(cr, (const unsigned char*)o + p, (unsigned)q); p += q; }
+        cr = c3crc::crc32_fast(cr, (const unsigned char*)o + at, to - at);
         c.seg_crc.push_back(cr); c.seg_len.push_back(to - at);
         at = to;
       }

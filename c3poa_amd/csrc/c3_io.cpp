@@ -285,7 +285,7 @@ bool gzfast_verify(GzFast* g, const std::vector<char>& c, const std::vector<GzFa
   if (!g->run_init) { g->run_crc = (uint32_t)crc32(0L, Z_NULL, 0); g->run_len = 0; g->run_init = true; }
   size_t s0 = 0;
   auto feed = [&](size_t to) {
-    for (size_t p = s0; p < to;) { const size_t k = std::min<size_t>(to - p, (size_t)1 << 30); g->run_crc = (uint32_t)crc32(g->run_crc, (const unsigned char*)c.data() + p, (unsigned)k); p += k; }
+    g->run_crc = c3crc::crc32_fast(g->run_crc, (const unsigned char*)c.data() + s0, to - s0);
     g->run_len += to - s0; s0 = to;
   };
   for (const GzFast::End& e : ends) {
@@ -325,7 +325,7 @@ void gzpar_thread(GzParReader* g) {
     const bool ok = g->par.next_round();
     std::vector<std::vector<char>>& dst = g->ready[g->prod];
     dst.clear();
-    if (ok) for (c3inf::ParChunk& c : g->par.chunks) if (c.start != (size_t)-1 && c.out.size() > g->par.head) dst.emplace_back(std::move(c.out));
+    if (ok) for (c3inf::ParChunk& c : g->par.chunks) if (c.start != (size_t)-1 && c.cb.out.size() > g->par.head) dst.emplace_back(std::move(c.cb.out));
     lk.lock();
     if (g->par.bad) { g->bad = true; g->done = true; g->cv.notify_all(); return; }
     if (!dst.empty()) { g->full[g->prod] = true; g->prod ^= 1; }
@@ -797,6 +797,8 @@ extern "C" long c3_debug_inflate(const unsigned char* in, size_t n, unsigned cha
   }
 }
 
+// test hook (tests/test_inflate.py): the reader's CRC-32 (c3_crc32.hpp) continued from `crc`, to be held against zlib's
+extern "C" unsigned c3_debug_crc32(unsigned crc, const unsigned char* p, size_t n) { return c3crc::crc32_fast(crc, p, n); }
 // test hook (tests/test_inflate.py): a whole gzip FILE image `in` through the parallel decoder (threads, chunk bytes); the size, -1 on a
 // damaged stream, -2 when cap is too small, -3 when `in` is no gzip member
 extern "C" long c3_debug_gunzip_par(const unsigned char* in, size_t n, int threads, size_t chunk, unsigned char* out, size_t cap) {
@@ -807,8 +809,8 @@ extern "C" long c3_debug_gunzip_par(const unsigned char* in, size_t n, int threa
     const bool ok = par.next_round();
     if (par.bad) return -1;
     if (ok) for (c3inf::ParChunk& c : par.chunks) if (c.start != (size_t)-1) {
-      if (total + c.out.size() > cap) return -2;
-      memcpy(out + total, c.out.data(), c.out.size()); total += c.out.size();
+      if (total + c.cb.out.size() > cap) return -2;
+      memcpy(out + total, c.cb.out.data(), c.cb.out.size()); total += c.cb.out.size();
     }
     if (!ok || par.done) break;
   }

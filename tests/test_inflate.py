@@ -266,3 +266,27 @@ def test_plain_gz_with_default_chunks_hands_buffers_over_without_copying(tmp_pat
     for th in ("4", "2"):
         monkeypatch.setenv("C3_GZ_THREADS", th)
         assert _read_all(str(gzp)) == want
+
+
+def test_the_readers_crc32_is_zlibs():
+    """c3_crc32.hpp (carry-less multiplication, constants derived from the polynomial) against zlib.crc32: every length 0..400 at every
+    alignment 0..16, continued from arbitrary states, and long buffers."""
+    lib = _lib.load()
+    lib.c3_debug_crc32.restype = C.c_uint
+    lib.c3_debug_crc32.argtypes = [C.c_uint, C.c_char_p, C.c_size_t]
+    rng = np.random.default_rng(77)
+    buf = rng.integers(0, 256, size=3 << 20, dtype=np.uint8).tobytes()
+    for n in range(0, 401):
+        for a in range(0, 17):
+            s = int(rng.integers(0, 1 << 32))
+            piece = buf[a:a + n]
+            assert lib.c3_debug_crc32(s, piece, n) == zlib.crc32(piece, s), (n, a)
+    for _ in range(60):
+        n, a, s = int(rng.integers(0, 3 << 20)), int(rng.integers(0, 64)), int(rng.integers(0, 1 << 32))
+        piece = buf[a:a + n]
+        assert lib.c3_debug_crc32(s, piece, len(piece)) == zlib.crc32(piece, s), (n, a)
+    # in pieces = in one go
+    c = 0
+    for k in range(0, len(buf), 100003):
+        c = lib.c3_debug_crc32(c, buf[k:k + 100003], len(buf[k:k + 100003]))
+    assert c == zlib.crc32(buf)
