@@ -45,39 +45,55 @@ static inline const uint8_t* gz_member_data(const uint8_t* p, size_t n) {
 }
 
 // What one chunk decodes into when the 32 KiB before it are unknown: BYTES, in the buffer the parser will read them from, plus -- for the
-// few positions whose value is a byte of that unknown window -- a mark: a bit in a bitmap (one per output byte) and an entry (position,
-// index into the window) in a list that is sorted by position because positions only grow.  A copy whose source holds no mark is the
-// ordinary byte copy; one whose source may hold marks (its first byte lies before `mk_end`, one past the last mark, AND a bitmap word of
-// its range is non-zero) goes byte by byte and carries the marks along.  (The first version decoded into 16-bit symbols, a literal its
-// byte, a window byte 0x8000 | index: half the copy rate, a second pass to narrow the symbols, ~0.4x the rate of the plain decoder.  FASTQ
-// keeps a few marks alive through a whole chunk -- every header is copied from the one before -- so "switch to bytes once the last 32 KiB
-// are clean", the published trick, never fires on it; marks are ~0.5 % of the bytes, and this form pays for them only where they are.)
+// positions whose value is a byte of that unknown window -- a MARK: a bit in a bitmap (one per output byte) and the index into the window in
+// a 16-bit plane beside the bytes (`widx`, never initialised: an entry means something only where the bit is set).  A copy whose source
+// range holds no set bit is the ordinary byte copy; the common copy (at most 64 bytes, not overlapping itself) that does hold marks copies
+// its stretch of the index plane as well and ORs the source's bits, shifted, into the destination's -- constant work per copy, however
+// many marks; only long or self-overlapping copies with marks go byte by byte.  (History: the first version decoded into 16-bit symbols,
+// a literal its byte, a window byte 0x8000 | index -- half the copy rate and a pass to narrow the symbols, 0.4x the plain decoder.  The
+// second kept the marks in a sorted list: fine at the 0.5 % of marked bytes `gzip -6` FASTQ settles at -- headers are copied from one
+// another, so "switch to bytes once the last 32 KiB are clean", the published trick, never fires -- and 2x SLOWER than the first on
+// `gzip -1` output of repetitive reads, where 25-45 % of a chunk's bytes stay marked to its end.  This form costs what the first did where
+// marks are dense and what the plain decoder does where they are not.)
 struct ChunkBuf {
   std::vector<char> out;                   // `head` free bytes, then the chunk's bytes
-  size_t head = 0, len = 0, mk_end = 0;
-  std::vector<uint64_t> bits;              // bit i: byte i is a placeholder for a byte of the unknown window
-  std::vector<std::pair<size_t, uint16_t>> marks;      // (position, window index), increasing positions
-  std::vector<uint32_t> first;             // per 64 bytes with a mark: the index of its first mark in `marks`
-  bool grow(size_t need) {                 // room for `need` bytes (and their bits) behind `head`
-    if (head + need <= out.size()) return true;
+  size_t head = 0, len = 0, mk_end = 0;    // mk_end: one past the last marked byte
+  std::vector<uint64_t> bits;              // bit i: byte i is a placeholder for a byte of the unknown window ...
+  uint16_t* widx = nullptr; size_t wcap = 0;      // ... namely window[widx[i]]
+  ChunkBuf() = default;
+  ChunkBuf(const ChunkBuf&) = delete; ChunkBuf& operator=(const ChunkBuf&) = delete;
+  ChunkBuf(ChunkBuf&& o) noexcept { *this = std::move(o); }
+  ChunkBuf& operator=(ChunkBuf&& o) noexcept {
+    if (this != &o) { free(widx); out = std::move(o.out); bits = std::move(o.bits); head = o.head; len = o.len; mk_end = o.mk_end; widx = o.widx; wcap = o.wcap; o.widx = nullptr; o.wcap = 0; o.len = 0; o.mk_end = 0; }
+    return *this;
+  }
+  ~ChunkBuf() { free(widx); }
+  bool grow(size_t need) {                 // room for `need` bytes (their bits, their index entries) behind `head`
+    if (head + need <= out.size() && need <= wcap) return true;
     size_t nc = std::max<size_t>(out.size() > head ? out.size() - head : 0, (size_t)1 << 16);
     while (nc < need) nc *= 2;
     out.resize(head + nc);
-    bits.resize(nc / 64 + 2, 0); first.resize(nc / 64 + 2);
+    bits.resize(nc / 64 + 2, 0);
+    uint16_t* nw = (uint16_t*)realloc(widx, (nc + 64) * sizeof(uint16_t));
+    if (!nw) return false;
+    widx = nw; wcap = nc;
     return true;
   }
+  void drop_marks() { std::vector<uint64_t>().swap(bits); free(widx); widx = nullptr; wcap = 0; mk_end = 0; }
   bool has_marks(size_t src, size_t n) const {          // (conservative: whole words)
     for (size_t w = src >> 6, we = (src + n - 1) >> 6; w <= we; ++w) if (bits[w]) return true;
     return false;
   }
-  uint16_t widx_at(size_t p) const {        // (p is marked) marks are appended in order of position: rank within the word
-    const uint64_t b = bits[p >> 6];
-    return marks[first[p >> 6] + (size_t)__builtin_popcountll(b & ((1ull << (p & 63)) - 1))].second;
-  }
-  void mark(size_t p, uint16_t widx) {
-    uint64_t& b = bits[p >> 6];
-    if (!b) first[p >> 6] = (uint32_t)marks.size();
-    b |= 1ull << (p & 63); marks.emplace_back(p, widx); mk_end = p + 1;
+  bool marked(size_t p) const { return (bits[p >> 6] >> (p & 63)) & 1; }
+  void mark(size_t p, uint16_t wi) { bits[p >> 6] |= 1ull << (p & 63); widx[p] = wi; mk_end = p + 1; }
+  // every mark in [from, to): f(position, window index)
+  template <class F> void for_marks(size_t from, size_t to, F f) const {
+    if (to > mk_end) to = mk_end;
+    for (size_t w = from >> 6; (w << 6) < to; ++w) {
+      uint64_t b = bits[w];
+      if (w == (from >> 6)) b &= ~0ull << (from & 63);
+      while (b) { const size_t p = (w << 6) + (size_t)__builtin_ctzll(b); b &= b - 1; if (p < to) f(p, widx[p]); }
+    }
   }
 };
 
@@ -167,12 +183,19 @@ struct Dec16 {
                 if (dd >= 8) { do { uint64_t w; memcpy(&w, sp, 8); memcpy(dst, &w, 8); sp += 8; dst += 8; } while (dst < end); }
                 else if (dd == 1) memset(dst, *sp, len);
                 else { do { *dst++ = *sp++; } while (dst < end); }
-                while (mm) { const unsigned i = (unsigned)__builtin_ctzll(mm); mm &= mm - 1; co.mark(pos + i, co.widx_at(src + i)); }
+                if (mm) {
+                  // the index entries of the whole stretch (those of unmarked bytes mean nothing, here as there) and the bits, shifted
+                  uint16_t* wd = co.widx + pos; const uint16_t* ws = co.widx + src; unsigned i = 0;
+                  do { uint64_t a_, b_; memcpy(&a_, ws + i, 8); memcpy(&b_, ws + i + 4, 8); memcpy(wd + i, &a_, 8); memcpy(wd + i + 4, &b_, 8); i += 8; } while (i < len);   // (dd >= len: no overlap inside the stretch; up to 7 entries beyond it are scratch)
+                  const unsigned dh = (unsigned)(pos & 63); uint64_t* bd = co.bits.data() + (pos >> 6);
+                  bd[0] |= mm << dh; if (dh) bd[1] |= mm >> (64 - dh);
+                  co.mk_end = pos + len;
+                }
               } else {
                 for (unsigned i = 0; i < len; ++i) {
                   const size_t sp = src + i;
                   o[pos + i] = o[sp];
-                  if ((co.bits[sp >> 6] >> (sp & 63)) & 1) co.mark(pos + i, co.widx_at(sp));
+                  if (co.marked(sp)) co.mark(pos + i, co.widx[sp]);
                 }
               }
               pos += len;
@@ -225,7 +248,7 @@ struct Dec16 {
               for (unsigned i = 0; i < len; ++i) {
                 const size_t sp = src + i;
                 o[pos + i] = o[sp];
-                if ((co.bits[sp >> 6] >> (sp & 63)) & 1) co.mark(pos + i, co.widx_at(sp));
+                if (co.marked(sp)) co.mark(pos + i, co.widx[sp]);
               }
             } else {
               uint8_t* dst = o + pos; const uint8_t* sp = dst - dd; uint8_t* const end = dst + len;
@@ -240,7 +263,7 @@ struct Dec16 {
             for (unsigned i = 0; i < len; ++i) {
               const long long q = p0 + i;
               if (q < 0) { o[pos + i] = 0; co.mark(pos + i, (uint16_t)(32768 + q)); }
-              else { o[pos + i] = o[q]; if ((co.bits[(size_t)q >> 6] >> ((size_t)q & 63)) & 1) co.mark(pos + i, co.widx_at((size_t)q)); }
+              else { o[pos + i] = o[q]; if (co.marked((size_t)q)) co.mark(pos + i, co.widx[(size_t)q]); }
             }
           }
           pos += len;
@@ -281,7 +304,7 @@ struct Dec16 {
       // ... the block must decode to its end-of-block symbol, and a well-formed header must follow
       seek(bit);
       if (tmp.len) { for (size_t i = 0; i <= tmp.len / 64 + 1 && i < tmp.bits.size(); ++i) tmp.bits[i] = 0; }
-      tmp.len = 0; tmp.mk_end = 0; tmp.marks.clear(); tends.clear();
+      tmp.len = 0; tmp.mk_end = 0; tends.clear();
       size_t eb = 0;
       const int rc = run(tmp, bit + 1, &eb, false, tends, (size_t)1 << 24);       // exactly one block (stops at the next boundary)
       if (rc < 0) continue;
@@ -416,7 +439,7 @@ struct GzPar {
       std::vector<uint8_t> nw(32768, 0);
       if (keep < 32768) memcpy(nw.data(), w.data() + keep, 32768 - keep);
       memcpy(nw.data() + 32768 - keep, c.cb.out.data() + c.cb.head + (m - keep), keep);
-      for (size_t k = c.cb.marks.size(); k-- > 0 && c.cb.marks[k].first >= m - keep;) nw[32768 - keep + (c.cb.marks[k].first - (m - keep))] = w[c.cb.marks[k].second & 0x7fffu];
+      c.cb.for_marks(m - keep, m, [&](size_t p, uint16_t wi) { nw[32768 - keep + (p - (m - keep))] = w[wi & 0x7fffu]; });
       w.swap(nw);
     }
     window = w;
@@ -426,8 +449,8 @@ struct GzPar {
       const size_t m = c.cb.len;
       c.cb.out.resize(head + m);
       char* o = c.cb.out.data() + head; const uint8_t* wv = c.window.data();
-      for (const auto& mk : c.cb.marks) o[mk.first] = (char)wv[mk.second & 0x7fffu];
-      std::vector<uint64_t>().swap(c.cb.bits); std::vector<std::pair<size_t, uint16_t>>().swap(c.cb.marks); std::vector<uint32_t>().swap(c.cb.first);
+      c.cb.for_marks(0, m, [&](size_t p, uint16_t wi) { o[p] = (char)wv[wi & 0x7fffu]; });
+      c.cb.drop_marks();
       size_t at = 0;
       for (size_t k = 0; k <= c.ends.size(); ++k) {
         const size_t to = k < c.ends.size() ? c.ends[k].off : m;

@@ -631,11 +631,11 @@ extern "C" int c3_reader_open(const char* path, int n_sets, c3_reader** out) {
             const char* et = getenv("C3_GZ_THREADS");
             const int T = et ? std::max(1, atoi(et)) : std::min(16, host_cores());
             const char* ec = getenv("C3_GZ_CHUNK");
-            const size_t chunk = ec ? (size_t)std::max(1024, atoi(ec)) : (size_t)1 << 20;
+            const size_t chunk = ec ? (size_t)std::max(1024, atoi(ec)) : (size_t)2 << 20;      // (16 threads, 1 GB of FASTQ: 3.4 / 4.3 / 3.7 / 1.9 GB/s at 1 / 2 / 4 / 8 MiB, profiles/r06_gzip_parallel_decoder_throughput.txt)
             if (T > 1 && !getenv("C3_GZ_SERIAL") && (size_t)sb.st_size >= 2 * chunk) {
               r->gzp = new GzParReader(); r->gzp->fd = fd; r->gzp->map = (const uint8_t*)mp; r->gzp->size = (size_t)sb.st_size;
               r->gzp->par.map = r->gzp->map; r->gzp->par.size = r->gzp->size; r->gzp->par.T = T; r->gzp->par.chunk = chunk;
-              r->gzp->par.head = getenv("C3_GZ_CHUNK") ? 4096 : (size_t)512 << 10;       // (room for a partial line in front of every chunk: see gzpar_swap)
+              r->gzp->par.head = std::min<size_t>((size_t)512 << 10, std::max<size_t>(chunk / 2, 4096));       // (room for a partial line in front of every chunk: see gzpar_swap)
             } else {
               r->gzf = new GzFast(); r->gzf->fd = fd; r->gzf->map = (const uint8_t*)mp; r->gzf->size = (size_t)sb.st_size;
             }

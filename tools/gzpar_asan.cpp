@@ -29,15 +29,28 @@ int main(int argc, char** argv) {
   const int N = argc > 2 ? atoi(argv[2]) : 3000;
   long errs = 0, oks = 0;
   for (int it = 0; it < N; ++it) {
-    std::vector<unsigned char> data, img;
+    std::vector<unsigned char> data, img; std::vector<size_t> bounds;
     const int members = 1 + rng() % 3;
     for (int m = 0; m < members; ++m) {
       size_t n = rng() % 5 == 0 ? 0 : rng() % 200000;
       std::vector<unsigned char> part(n);
-      const int kind = rng() % 4;
+      const int kind = rng() % 5;
       for (size_t i = 0; i < n; ++i) part[i] = kind == 0 ? rng() : kind == 1 ? "ACGT"[rng() % 4] : kind == 2 ? (unsigned char)(i / 100) : (unsigned char)('A' + (rng() % 3 == 0));
+      if (kind == 4) {          // FASTQ: the headers are copied from one another across the whole chunk (marks that never die out), repeats inside a read
+        size_t i = 0; int rec = 0;
+        while (i < n) {
+          char hd[64]; const int hl = snprintf(hd, sizeof hd, "@read_%08d ch=%d\n", rec++, (int)(rng() % 512));
+          const size_t L = 50 + rng() % 3000, unit = 20 + rng() % 400;
+          std::vector<unsigned char> u(unit); for (auto& b : u) b = "ACGT"[rng() % 4];
+          for (int k = 0; k < hl && i < n; ++k) part[i++] = hd[k];
+          for (size_t k = 0; k < L && i < n; ++k) part[i++] = rng() % 8 == 0 ? "ACGT"[rng() % 4] : u[k % unit];
+          if (i < n) part[i++] = '\n'; if (i < n) part[i++] = '+'; if (i < n) part[i++] = '\n';
+          for (size_t k = 0; k < L && i < n; ++k) part[i++] = (unsigned char)('!' + rng() % 40);
+          if (i < n) part[i++] = '\n';
+        }
+      }
       std::vector<unsigned char> g = gz_of(part, rng() % 10, rng);
-      img.insert(img.end(), g.begin(), g.end()); data.insert(data.end(), part.begin(), part.end());
+      img.insert(img.end(), g.begin(), g.end()); data.insert(data.end(), part.begin(), part.end()); bounds.push_back(data.size());
     }
     const int mode = rng() % 4;
     if (mode == 1 && !img.empty()) img[rng() % img.size()] ^= 1u << (rng() % 8);
@@ -53,7 +66,11 @@ int main(int argc, char** argv) {
       if (!ok || par.done) break;
     }
     if (mode == 0) { if (bad || got != data) { if (FILE* f = fopen("/tmp/gzpar_fail.gz", "wb")) { fwrite(img.data(), 1, img.size(), f); fclose(f); } printf("MISMATCH it=%d (bad %d, %zu of %zu bytes, T %d chunk %zu)\n", it, (int)bad, got.size(), data.size(), par.T, par.chunk); return 1; } ++oks; }
-    else if (bad) ++errs; else if (mode == 1 && got != data) { /* a flip the CRC cannot see does not exist; one in a header field changes nothing */ printf("SILENT DAMAGE it=%d\n", it); return 1; }
+    else if (bad) ++errs; else if (mode == 1 && got != data && [&] {
+      // a flip in the magic / method bytes of a LATER member's header turns the rest of the file into trailing bytes that are no member: the
+      // input ends there, as it does for zlib -- the members before it, whole
+      for (size_t k = 0; k + 1 < bounds.size(); ++k) if (got.size() == bounds[k] && std::equal(got.begin(), got.end(), data.begin())) return false;
+      return true; }()) { /* a flip the CRC cannot see does not exist; one in a header field changes nothing */ printf("SILENT DAMAGE it=%d\n", it); return 1; }
     free(in);
   }
   printf("done: %d images, %ld intact ones decoded exactly, %ld damaged ones reported\n", N, oks, errs);
