@@ -63,6 +63,15 @@ def _payloads(seed):
     # far matches: a block repeated at the maximum distance
     blk = bytes(nprng.integers(0, 256, 32768, dtype=np.uint8))
     yield blk + blk + blk[:5000]
+    # concatemers (what the CLI reads): every read repeats a unit with errors, so copies refer to copies of copies -- with `gzip -1` a quarter to
+    # half of a chunk decoded without its window stays "a byte of the unknown window" to its end (the parallel decoder's index plane)
+    cc = []
+    for i in range(120):
+        unit = "".join(rng.choice("ACGT") for _ in range(rng.randint(60, 500)))
+        n = rng.randint(500, 5000)
+        seq = "".join(unit[k % len(unit)] if rng.random() > 0.1 else rng.choice("ACGT") for k in range(n))
+        cc.append("@c%07d ch=%d\n%s\n+\n%s\n" % (i, rng.randint(1, 512), seq, "".join(chr(rng.randint(34, 60)) for _ in range(n))))
+    yield ("".join(cc)).encode()
 
 
 @pytest.mark.parametrize("seed", [1, 2])
