@@ -331,6 +331,7 @@ struct ParChunk {
 struct GzPar {
   const uint8_t* map = nullptr; size_t size = 0;
   int T = 4; size_t chunk = (size_t)1 << 20;
+  int per_round = 0;                       // chunks per round (0: one per thread)
   size_t head = 0;                         // bytes left free in front of every chunk's output (the reader moves a partial line there and takes the buffer as it is)
   size_t next_bit = 0; bool next_known = true; bool started = false, done = false, bad = false;
   std::vector<uint8_t> window;             // last 32 KiB of everything produced so far (front padded with zeros)
@@ -348,11 +349,18 @@ struct GzPar {
     return true;
   }
 
+  // body(0 .. n-1) on min(T, n) threads that take the indices as they get free (a round may hold more chunks than threads: under
+  // contention -- the writers and the GPU's host threads share the cores -- the slow thread of a static split held the round up)
   template <class F> void parallel(int n, F body) {
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+      auto loop = [&]() { for (int j; (j = next.fetch_add(1)) < n;) body(j); };
+      if (with_slot) with_slot(loop); else loop();
+    };
+    const int W = std::min(T, n);
     std::vector<std::thread> th;
-    auto wrapped = [&](int j) { if (with_slot) with_slot([&]() { body(j); }); else body(j); };
-    for (int j = 1; j < n; ++j) th.emplace_back(wrapped, j);
-    if (n > 0) wrapped(0);
+    for (int k = 1; k < W; ++k) th.emplace_back(worker);
+    if (W > 0) worker();
     for (auto& t : th) t.join();
   }
 
@@ -360,7 +368,7 @@ struct GzPar {
     if (done || bad) return false;
     const size_t nbits = size * 8;
     const size_t b0 = next_bit >> 3;
-    int n = T;
+    int n = per_round > 0 ? per_round : T;
     chunks.clear(); chunks.resize((size_t)n);
     chunks[0].start = next_bit; chunks[0].known = next_known;
 #ifdef C3_GZPAR_PROF

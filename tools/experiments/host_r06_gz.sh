@@ -20,3 +20,5 @@ for c in 262144 2097152 4194304 8388608; do CHUNK=$c /tmp/gzpar_bench /tmp/in.fa
 # the same reads through gzip -1 (what tools/cli_throughput.py --gz feeds the command line): 25-45 % of a chunk's bytes stay marked
 zcat /tmp/in.fastq.gz | gzip -1 > /tmp/in1.fastq.gz
 for c in 1048576 4194304; do CHUNK=$c /tmp/gzpar_bench /tmp/in1.fastq.gz 1 8 16 | grep -v zlib; done
+# rounds of more chunks than threads (the threads take chunks as they get free)
+for cr in "2097152 16" "1048576 32" "1048576 48" "2097152 32" "524288 64"; do set -- $cr; CHUNK=$1 ROUND=$2 /tmp/gzpar_bench /tmp/in.fastq.gz 16 | grep parallel; CHUNK=$1 ROUND=$2 /tmp/gzpar_bench /tmp/in1.fastq.gz 16 | grep parallel; done

@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     if (mode == 2 && !img.empty()) img.resize(rng() % img.size());
     if (mode == 3) { img.resize(rng() % 3000 + 1); for (auto& b : img) b = rng(); if (rng() & 1) { img[0] = 0x1f; if (img.size() > 3) { img[1] = 0x8b; img[2] = 8; img[3] = 0; } } }
     unsigned char* in = (unsigned char*)malloc(img.size() ? img.size() : 1); memcpy(in, img.data(), img.size());       // exact size: ASan sees any overrun
-    c3inf::GzPar par; par.map = in; par.size = img.size(); par.T = 1 + rng() % 6; par.chunk = rng() % 4 == 0 ? (size_t)1 << 22 : 300 + rng() % 60000; par.head = rng() % 3 == 0 ? rng() % 5000 : 0;
+    c3inf::GzPar par; par.map = in; par.size = img.size(); par.T = 1 + rng() % 6; par.chunk = rng() % 4 == 0 ? (size_t)1 << 22 : 300 + rng() % 60000; par.head = rng() % 3 == 0 ? rng() % 5000 : 0; par.per_round = rng() % 3 == 0 ? 1 + (int)(rng() % 14) : 0;
     std::vector<unsigned char> got; bool bad = !par.open();
     for (int guard = 0; !bad && guard < 100000; ++guard) {
       const bool ok = par.next_round();
