@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <atomic>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -68,18 +69,22 @@ struct ChunkBuf {
     return *this;
   }
   ~ChunkBuf() { free(widx); }
-  bool grow(size_t need) {                 // room for `need` bytes (their bits, their index entries) behind `head`
-    if (head + need <= out.size() && need <= wcap) return true;
-    size_t nc = std::max<size_t>(out.size() > head ? out.size() - head : 0, (size_t)1 << 16);
+  bool grow(size_t need) {                 // room for `need` bytes behind `head`, and bits + index entries for EVERY byte the buffer can hold (the decoder
+    const size_t have = out.size() > head ? out.size() - head : 0;      // takes the buffer's size as its room; a buffer that came back from the reader keeps its size)
+    size_t nc = std::max<size_t>(have, (size_t)1 << 16);
     while (nc < need) nc *= 2;
-    out.resize(head + nc);
-    bits.resize(nc / 64 + 2, 0);
-    uint16_t* nw = (uint16_t*)realloc(widx, (nc + 64) * sizeof(uint16_t));
-    if (!nw) return false;
-    widx = nw; wcap = nc;
+    if (out.size() < head + nc) out.resize(head + nc);
+    const size_t room = out.size() - head;
+    if (bits.size() < room / 64 + 2) bits.resize(room / 64 + 2, 0);
+    if (wcap < room) {
+      uint16_t* nw = (uint16_t*)realloc(widx, (room + 64) * sizeof(uint16_t));
+      if (!nw) return false;
+      widx = nw; wcap = room;
+    }
     return true;
   }
   void drop_marks() { std::vector<uint64_t>().swap(bits); free(widx); widx = nullptr; wcap = 0; mk_end = 0; }
+  uint16_t* release_widx(size_t* cap) { uint16_t* p = widx; *cap = wcap; widx = nullptr; wcap = 0; return p; }      // (the caller keeps the plane for another chunk)
   bool has_marks(size_t src, size_t n) const {          // (conservative: whole words)
     for (size_t w = src >> 6, we = (src + n - 1) >> 6; w <= we; ++w) if (bits[w]) return true;
     return false;
@@ -320,7 +325,7 @@ struct ParChunk {
   size_t start = (size_t)-1, end = 0;      // bit offsets (start: -1 = no block start found: the chunk before decodes through)
   bool known = false;                      // starts at the first block of a member
   int rc = 0;                              // result of the decode: 0 stopped at a boundary, 1 end of the input, -1 error
-  ChunkBuf cb;                             // cb.out: the chunk's bytes behind `head` free ones
+  ChunkBuf cb;                             // cb.out: the chunk's cb.len bytes behind `head` free ones (the vector itself is longer)
   std::vector<MemberEnd> ends;
   std::vector<uint8_t> window;             // the 32 KiB before the chunk (resolved), oldest first, 32768 bytes (front padded)
   std::vector<uint32_t> seg_crc; std::vector<size_t> seg_len;     // CRC-32 of every stretch between member ends (ends.size() + 1 stretches)
@@ -338,6 +343,12 @@ struct GzPar {
   uint32_t run_crc = 0; uint64_t run_len = 0;     // the member that is still open: CRC-32 and length so far
   int members = 0;
   std::function<void(std::function<void()>)> with_slot;       // runs a worker body under the process-wide core limiter (c3_io.cpp: CpuSlot)
+  // Used output buffers come back in through here (c3_io.cpp: the parser hands every buffer back once it has read it) and the index planes stay
+  // with the decoder: their pages are mapped already.  Without this every chunk allocates 4x its size twice over and frees it on another
+  // thread -- page faults, page zeroing and munmap for every 2 MiB of input, a fifth of the one parser thread's time.
+  std::function<void(std::vector<char>&)> take_buf;
+  std::mutex wmu; std::vector<std::pair<uint16_t*, size_t>> wpool;
+  ~GzPar() { for (auto& w : wpool) free(w.first); }
   std::vector<ParChunk> chunks;
 
   bool open() {
@@ -399,6 +410,8 @@ struct GzPar {
       Dec16 d; d.base = map; d.fend = map + size;
       d.seek(c.start);
       c.cb.head = head;
+      if (take_buf) take_buf(c.cb.out);
+      { std::lock_guard<std::mutex> lk(wmu); if (!wpool.empty()) { c.cb.widx = wpool.back().first; c.cb.wcap = wpool.back().second; wpool.pop_back(); } }
       c.cb.grow(chunk * 4);
       c.rc = d.run(c.cb, target_of(j), &c.end, c.known, c.ends, (size_t)1 << 30);
     });
@@ -455,9 +468,9 @@ struct GzPar {
       ParChunk& c = chunks[(size_t)j];
       if (c.start == (size_t)-1) return;
       const size_t m = c.cb.len;
-      c.cb.out.resize(head + m);
-      char* o = c.cb.out.data() + head; const uint8_t* wv = c.window.data();
+      char* o = c.cb.out.data() + head; const uint8_t* wv = c.window.data();            // (the buffer keeps its size: the chunk is cb.len bytes behind `head`)
       c.cb.for_marks(0, m, [&](size_t p, uint16_t wi) { o[p] = (char)wv[wi & 0x7fffu]; });
+      { size_t wc = 0; uint16_t* wp = c.cb.release_widx(&wc); std::lock_guard<std::mutex> lk(wmu); if (wp && wpool.size() < 4 * (size_t)n) wpool.emplace_back(wp, wc); else free(wp); }
       c.cb.drop_marks();
       size_t at = 0;
       for (size_t k = 0; k <= c.ends.size(); ++k) {

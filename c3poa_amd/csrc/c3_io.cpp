@@ -146,7 +146,7 @@ struct Bgzf {
 
 // plain gzip input read with the own decoder (c3_inflate.hpp): see gzfast_chunk
 struct GzFast {
-  static const size_t W = 32768, CHUNK = (size_t)4 << 20;
+  static constexpr size_t W = 32768, CHUNK = (size_t)4 << 20;      // (constexpr: std::min takes W by reference)
   int fd = -1; const uint8_t* map = nullptr; size_t size = 0, at = 0;
   c3inf::Inflater inf; bool in_member = false; size_t hist = 0; int members = 0;
   std::vector<uint8_t> win;
@@ -164,8 +164,16 @@ struct GzParReader {
   int fd = -1; const uint8_t* map = nullptr; size_t size = 0;
   c3inf::GzPar par;
   std::thread th; std::mutex mu; std::condition_variable cv;
-  std::vector<std::vector<char>> ready[2]; bool full[2] = {false, false}; int prod = 0, cons = 0; size_t ci = 0, cpos = 0;
+  struct Out { std::vector<char> v; size_t len; };          // a chunk: `len` bytes behind par.head free ones
+  std::vector<Out> ready[2]; bool full[2] = {false, false}; int prod = 0, cons = 0; size_t ci = 0, cpos = 0;
   bool done = false, bad = false, stop = false, started = false;
+  // buffers the parser has read come back to the inflating threads (GzPar::take_buf)
+  std::mutex pmu; std::vector<std::vector<char>> pool;
+  void give_back(std::vector<char>&& v) {
+    if (v.size() < par.head + par.chunk * 4) return;         // (the reader's own first buffer, a chunk that had to grow oddly: freed)
+    std::lock_guard<std::mutex> lk(pmu);
+    if (pool.size() < 3 * (size_t)std::max(par.per_round, par.T)) pool.emplace_back(std::move(v));
+  }
 };
 
 struct c3_reader {
@@ -323,9 +331,9 @@ void gzpar_thread(GzParReader* g) {
     if (g->stop) return;
     lk.unlock();
     const bool ok = g->par.next_round();
-    std::vector<std::vector<char>>& dst = g->ready[g->prod];
+    std::vector<GzParReader::Out>& dst = g->ready[g->prod];
     dst.clear();
-    if (ok) for (c3inf::ParChunk& c : g->par.chunks) if (c.start != (size_t)-1 && c.cb.out.size() > g->par.head) dst.emplace_back(std::move(c.cb.out));
+    if (ok) for (c3inf::ParChunk& c : g->par.chunks) if (c.start != (size_t)-1 && c.cb.len > 0) dst.push_back(GzParReader::Out{std::move(c.cb.out), c.cb.len});
     lk.lock();
     if (g->par.bad) { g->bad = true; g->done = true; g->cv.notify_all(); return; }
     if (!dst.empty()) { g->full[g->prod] = true; g->prod ^= 1; }
@@ -337,6 +345,7 @@ long gzpar_read(GzParReader* g, char* dst, size_t room) {
   if (!g->started) {
     g->started = true;
     g->par.with_slot = [](std::function<void()> f) { CpuSlot s_; f(); };
+    g->par.take_buf = [g](std::vector<char>& v) { std::lock_guard<std::mutex> lk(g->pmu); if (!g->pool.empty()) { v = std::move(g->pool.back()); g->pool.pop_back(); } };
     if (!g->par.open()) { g->bad = true; return -1; }
     g->th = std::thread(gzpar_thread, g);
   }
@@ -346,13 +355,13 @@ long gzpar_read(GzParReader* g, char* dst, size_t room) {
     if (g->bad) return -1;                                          // (a damaged stream: nothing of the failing round is handed out)
     if (!g->full[g->cons]) return 0;
     lk.unlock();
-    std::vector<std::vector<char>>& cs = g->ready[g->cons];
+    std::vector<GzParReader::Out>& cs = g->ready[g->cons];
     if (g->ci < cs.size()) {
-      std::vector<char>& c = cs[g->ci];
+      GzParReader::Out& c = cs[g->ci];
       const size_t hd = g->par.head;                                 // (the chunk's bytes sit behind `head` free ones: gzpar_swap)
-      const size_t k = std::min(room, c.size() - hd - g->cpos);
-      memcpy(dst, c.data() + hd + g->cpos, k); g->cpos += k;
-      if (g->cpos == c.size() - hd) { std::vector<char>().swap(c); ++g->ci; g->cpos = 0; }
+      const size_t k = std::min(room, c.len - g->cpos);
+      memcpy(dst, c.v.data() + hd + g->cpos, k); g->cpos += k;
+      if (g->cpos == c.len) { g->give_back(std::move(c.v)); std::vector<char>().swap(c.v); ++g->ci; g->cpos = 0; }
       if (k) return (long)k;
     }
     if (g->ci >= cs.size()) { lk.lock(); g->full[g->cons] = false; g->cons ^= 1; g->ci = 0; g->cpos = 0; g->cv.notify_all(); }
@@ -370,15 +379,15 @@ int gzpar_swap(GzParReader* g, std::vector<char>& buf, size_t* beg, size_t* end)
     if (g->bad) return -1;
     if (!g->full[g->cons]) return 0;
     lk.unlock();
-    std::vector<std::vector<char>>& cs = g->ready[g->cons];
+    std::vector<GzParReader::Out>& cs = g->ready[g->cons];
     if (g->ci < cs.size()) {
-      std::vector<char>& c = cs[g->ci];
+      GzParReader::Out& c = cs[g->ci];
       const size_t hd = g->par.head, left = *end - *beg;
       if (g->cpos != 0 || left > hd) return -2;
-      memcpy(c.data() + hd - left, buf.data() + *beg, left);
-      buf.swap(c);
-      *beg = hd - left; *end = buf.size();
-      std::vector<char>().swap(c); ++g->ci;
+      memcpy(c.v.data() + hd - left, buf.data() + *beg, left);
+      buf.swap(c.v);
+      *beg = hd - left; *end = hd + c.len;                           // (the vector is longer than the chunk: its size is its capacity for the next chunk it will hold)
+      g->give_back(std::move(c.v)); std::vector<char>().swap(c.v); ++g->ci;
       if (g->ci >= cs.size()) { lk.lock(); g->full[g->cons] = false; g->cons ^= 1; g->ci = 0; g->cpos = 0; g->cv.notify_all(); }
       return 1;
     }
@@ -810,8 +819,8 @@ extern "C" long c3_debug_gunzip_par(const unsigned char* in, size_t n, int threa
     const bool ok = par.next_round();
     if (par.bad) return -1;
     if (ok) for (c3inf::ParChunk& c : par.chunks) if (c.start != (size_t)-1) {
-      if (total + c.cb.out.size() > cap) return -2;
-      memcpy(out + total, c.cb.out.data(), c.cb.out.size()); total += c.cb.out.size();
+      if (total + c.cb.len > cap) return -2;
+      memcpy(out + total, c.cb.out.data() + par.head, c.cb.len); total += c.cb.len;
     }
     if (!ok || par.done) break;
   }

@@ -62,7 +62,7 @@ int main(int argc, char** argv) {
     for (int guard = 0; !bad && guard < 100000; ++guard) {
       const bool ok = par.next_round();
       if (par.bad) { bad = true; break; }
-      if (ok) for (auto& c : par.chunks) if (c.start != (size_t)-1) got.insert(got.end(), c.cb.out.begin() + (long)par.head, c.cb.out.end());
+      if (ok) for (auto& c : par.chunks) if (c.start != (size_t)-1) got.insert(got.end(), c.cb.out.begin() + (long)par.head, c.cb.out.begin() + (long)(par.head + c.cb.len));
       if (!ok || par.done) break;
     }
     if (mode == 0) { if (bad || got != data) { if (FILE* f = fopen("/tmp/gzpar_fail.gz", "wb")) { fwrite(img.data(), 1, img.size(), f); fclose(f); } printf("MISMATCH it=%d (bad %d, %zu of %zu bytes, T %d chunk %zu)\n", it, (int)bad, got.size(), data.size(), par.T, par.chunk); return 1; } ++oks; }

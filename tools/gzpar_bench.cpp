@@ -25,7 +25,7 @@ int main(int argc, char** argv) {
     c3inf::GzPar par; par.map = d.data(); par.size = n; par.T = atoi(argv[a]); par.chunk = getenv("CHUNK") ? atol(getenv("CHUNK")) : (size_t)1 << 20; par.per_round = getenv("ROUND") ? atoi(getenv("ROUND")) : 0;
     const double t = now_(); size_t tot = 0;
     if (!par.open()) return 2;
-    for (;;) { const bool ok = par.next_round(); if (par.bad) { printf("BAD\n"); return 3; } if (ok) for (auto& c : par.chunks) if (c.start != (size_t)-1) tot += c.cb.out.size(); if (!ok || par.done) break; }
+    for (;;) { const bool ok = par.next_round(); if (par.bad) { printf("BAD\n"); return 3; } if (ok) for (auto& c : par.chunks) if (c.start != (size_t)-1) tot += c.cb.len; if (!ok || par.done) break; }
     printf("parallel, %2d threads, chunk %zu, %d chunks per round: %zu bytes, %.1f MB/s\n", par.T, par.chunk, par.per_round ? par.per_round : par.T, tot, tot / (now_() - t) / 1e6);
   }
 }
