@@ -9,15 +9,17 @@
 //      that holds a DYNAMIC block header whose three Huffman codes are complete and whose block decodes to its end-of-block symbol
 //      with another well-formed block header behind it (probe);
 //   2. every thread decodes from its offset with an UNKNOWN window: a copy from before the chunk yields a MARK -- "this byte is byte k of
-//      the 32 KiB before the chunk" -- kept beside the bytes (a bitmap + a sorted list), copies of marked bytes copy the mark, and it
-//      stops at the block boundary where the next chunk begins;
+//      the 32 KiB before the chunk" -- kept beside the bytes (a bitmap + a 16-bit index plane: ChunkBuf below), copies of marked bytes copy
+//      the mark, and it stops at the block boundary where the next chunk begins;
 //   3. the chunks are chained in order: the chunk before must have stopped EXACTLY where this one started (an offset that is not a
 //      block boundary of the real stream -- a false positive of step 1 -- is found out here, structurally: its chunk is dropped and
 //      the chunk before decodes on through it), its last 32 KiB, resolved, are this chunk's window;
-//   4. every thread fills in the marked bytes of its chunk and takes the CRC-32 of every stretch of a gzip member in it; the stretches are combined (crc32_combine) and checked against every member's trailer, as is its length.
+//   4. every thread fills in the marked bytes of its chunk and takes the CRC-32 of every stretch of a gzip member in it; the stretches are
+//      combined (crc32_combine) and checked against every member's trailer, as is its length.
+// A round holds `per_round` chunks (two per thread in the reader); the threads take chunks off a counter, every numbered step ends at a barrier.
 //
 // Members may be concatenated (one stream, as for gzread); bytes behind the last member that are no gzip header end the input.
-// The code is this repository's own; zlib supplies crc32 / crc32_combine only.
+// The code is this repository's own; zlib supplies crc32_combine (and crc32 where the CPU has no carry-less multiply: c3_crc32.hpp).
 #pragma once
 #include "c3_inflate.hpp"
 #include "c3_crc32.hpp"
