@@ -45,13 +45,17 @@ def main():
         _lib.compress_file(fq, bg, level=a.level, remove=False)
         print("%d reads, %.2f GB of FASTQ; gzip -%d %.2f GB, BGZF %.2f GB" % (a.n, raw / 1e9, a.level, os.path.getsize(gz) / 1e9, os.path.getsize(bg) / 1e9))
         for path, what in ((gz, "plain gzip"), (bg, "BGZF")):
-            for env, name in (({"C3_GZ_ZLIB": "1"}, "zlib"), ({}, "own decoder"), ({"C3_GZ_ZLIB": "1"}, "zlib"), ({}, "own decoder")):
-                e = dict(os.environ); e.pop("C3_GZ_ZLIB", None); e.update(env)
+            # (plain gzip since round 6: "own decoder" = several inflating threads behind the parser, c3_gzpar.hpp; C3_GZ_SERIAL=1 = round 5's single thread)
+            variants = [({"C3_GZ_ZLIB": "1"}, "zlib"), ({}, "own decoder")]
+            if what == "plain gzip":
+                variants.insert(1, ({"C3_GZ_SERIAL": "1"}, "own, 1 thread"))
+            for env, name in variants + variants:
+                e = dict(os.environ); e.pop("C3_GZ_ZLIB", None); e.pop("C3_GZ_SERIAL", None); e.update(env)
                 out = subprocess.run([sys.executable, "-c", CHILD, path], env=e, capture_output=True, text=True)
                 if out.returncode:
                     print(what, name, "FAILED", out.stderr[-300:]); continue
                 n, nb, dt = out.stdout.split()
-                print("%-10s %-12s %7.1f k reads/s  %6.0f MB of FASTQ per s" % (what, name, int(n) / float(dt) / 1e3, raw / float(dt) / 1e6), flush=True)
+                print("%-10s %-14s %7.1f k reads/s  %6.0f MB of FASTQ per s" % (what, name, int(n) / float(dt) / 1e3, raw / float(dt) / 1e6), flush=True)
     finally:
         subprocess.call(["rm", "-rf", d])
 
