@@ -472,7 +472,7 @@ struct GzPar {
       const size_t m = c.cb.len;
       char* o = c.cb.out.data() + head; const uint8_t* wv = c.window.data();            // (the buffer keeps its size: the chunk is cb.len bytes behind `head`)
       c.cb.for_marks(0, m, [&](size_t p, uint16_t wi) { o[p] = (char)wv[wi & 0x7fffu]; });
-      { size_t wc = 0; uint16_t* wp = c.cb.release_widx(&wc); std::lock_guard<std::mutex> lk(wmu); if (wp && wpool.size() < 4 * (size_t)n) wpool.emplace_back(wp, wc); else free(wp); }
+      { size_t wc = 0; uint16_t* wp = c.cb.release_widx(&wc); std::lock_guard<std::mutex> lk(wmu); if (wp && wpool.size() < 2 * (size_t)n) wpool.emplace_back(wp, wc); else free(wp); }
       c.cb.drop_marks();
       size_t at = 0;
       for (size_t k = 0; k <= c.ends.size(); ++k) {
