@@ -16,7 +16,15 @@
 #include "c3_args.h"
 
 #define PK_T 256
-#define SG_T 1024        /* outputs per LDS tile */
+#ifndef SG_T
+#define SG_T 896         /* outputs per LDS tile: 22 592 bytes of LDS with the rest = 18 granules of 1 280, seven workgroups per CU (1 024: six) */
+#endif
+#ifndef C3_PK_WAVES
+#define C3_PK_WAVES 7     /* waves per SIMD the register allocation is held to (<= 72 VGPRs; the compiler's own choice is 82 = five workgroups per CU) */
+#endif
+#ifndef PK_CR
+#define PK_CR 2          /* candidates per thread that the suppression loop keeps in registers (more candidates: the loop through memory) */
+#endif
 #define SG_H 64          /* largest halo (iters * half) the tiled path supports; 3 * 20 = 60 for the reference's settings */
 
 
@@ -137,6 +145,7 @@ __device__ __forceinline__ int c3_rounding(int x, int base) {
   return ((q & 1) ? q + 1 : q) * base;
 }
 
+__attribute__((amdgpu_waves_per_eu(C3_PK_WAVES, C3_PK_WAVES)))
 __global__ __launch_bounds__(PK_T) void k_peaks(PeaksArgs a) {
   __shared__ __attribute__((aligned(8))) unsigned hist[256];
   __shared__ int sh_i[8];
@@ -251,60 +260,102 @@ __global__ __launch_bounds__(PK_T) void k_peaks(PeaksArgs a) {
           uint64_t key = dkey(x[i]);
           if (key <= k1) ++cnt_le; else if (key < mn) mn = key;
         }
-        sh_cnt[tid] = cnt_le; sh_d[tid] = __longlong_as_double((long long)mn);
-        __syncthreads();
-        for (int s = PK_T / 2; s > 0; s >>= 1) {
-          if (tid < s) {
-            sh_cnt[tid] += sh_cnt[tid + s];
-            uint64_t o = (uint64_t)__double_as_longlong(sh_d[tid + s]), m = (uint64_t)__double_as_longlong(sh_d[tid]);
-            if (o < m) sh_d[tid] = sh_d[tid + s];
-          }
-          __syncthreads();
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+          cnt_le += __shfl_xor(cnt_le, o);
+          const unsigned long long om = __shfl_xor((unsigned long long)mn, o);
+          if (om < mn) mn = om;
         }
-        int tot_le = sh_cnt[0]; uint64_t mnk = (uint64_t)__double_as_longlong(sh_d[0]);
+        if ((tid & 63) == 0) { sh_cnt[tid >> 6] = cnt_le; sh_d[tid >> 6] = __longlong_as_double((long long)mn); }
+        __syncthreads();
+        int tot_le = 0; uint64_t mnk = ~0ull;
+#pragma unroll
+        for (int q = 0; q < PK_T / 64; ++q) { tot_le += sh_cnt[q]; const uint64_t o = (uint64_t)__double_as_longlong(sh_d[q]); if (o < mnk) mnk = o; }
         __syncthreads();
         double v2 = (tot_le > n / 2) ? v1 : dunkey(mnk);
         med = (v1 + v2) / 2.0;
       }
     }
-    // ---- max
+    // ---- max (wave shuffles, then the four wave results: two barriers instead of nine)
     double mx = -1.0e308;
     for (int i = tid; i < n; i += PK_T) mx = fmax(mx, x[i]);
-    sh_d[tid] = mx;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) sh_d[tid >> 6] = mx;
     __syncthreads();
-    for (int s = PK_T / 2; s > 0; s >>= 1) { if (tid < s) sh_d[tid] = fmax(sh_d[tid], sh_d[tid + s]); __syncthreads(); }
-    mx = sh_d[0];
+    mx = fmax(fmax(sh_d[0], sh_d[1]), fmax(sh_d[2], sh_d[3]));
     __syncthreads();
     int n_kept = 0;
     if (!(mx < 6 * med)) {
       const double height = med * 3;
-      // ---- strict local maxima (plateau midpoint) with inclusive height, order preserving
-      const int chunk = (n + PK_T - 1) / PK_T;
-      const int lo = max(1, tid * chunk), hi = min(n - 1, (tid + 1) * chunk);
-      int cnt = 0;
+      // ---- strict local maxima (plateau midpoint) with inclusive height, order preserving.  Every wave takes a contiguous quarter of the
+      // track in strips of 64 consecutive points (lane = point: the three loads of a strip are coalesced; a thread walking its own 20
+      // consecutive points made every load instruction touch 64 cache lines), counts its candidates with ballots, and after the four
+      // totals are known writes them in order.
+      const int lane = tid & 63, wv = tid >> 6;
+      const int seg = ((n + 4 * 64 - 1) / (4 * 64)) * 64;
+      const int wlo = wv * seg, whi = min(n - 1, wlo + seg);
+      int wcnt = 0;
       for (int pass = 0; pass < 2; ++pass) {
-        int w = (pass == 1) ? sh_cnt[tid] : 0;
-        for (int i = lo; i < hi; ++i) {
-          if (x[i - 1] < x[i]) {
-            int ia = i + 1;
-            while (ia < n - 1 && x[ia] == x[i]) ++ia;
-            if (x[ia] < x[i] && x[i] >= height) {
-              if (pass == 0) ++cnt; else { cand[w] = (i + ia - 1) / 2; cst[w] = 1; ++w; }
+        int w = (pass == 1) ? sh_cnt[wv] : 0;
+        for (int b = wlo; b < whi; b += 64) {
+          const int i = b + lane;
+          bool is = false; int mid = 0;
+          if (i >= 1 && i < whi) {
+            const double xi = x[i];
+            if (x[i - 1] < xi) {
+              int ia = i + 1;
+              while (ia < n - 1 && x[ia] == xi) ++ia;
+              if (x[ia] < xi && xi >= height) { is = true; mid = (i + ia - 1) / 2; }
             }
           }
+          const unsigned long long m = __ballot(is);
+          if (pass == 1 && is) { const int k = w + __popcll(m & ((1ull << lane) - 1ull)); cand[k] = mid; cst[k] = 1; }
+          w += __popcll(m);
         }
         if (pass == 0) {
-          unsigned tot;
-          const unsigned ex = block_excl_scan((unsigned)cnt, sh_i + 2, &tot);
-          sh_cnt[tid] = (int)ex;
-          if (tid == 0) sh_cnt[PK_T] = (int)tot;
+          wcnt = w;
+          if (lane == 0) sh_i[2 + wv] = wcnt;
+          __syncthreads();
+          if (tid == 0) { int acc = 0; for (int q = 0; q < PK_T / 64; ++q) { sh_cnt[q] = acc; acc += sh_i[2 + q]; } sh_cnt[PK_T] = acc; }
           __syncthreads();
         }
       }
+      __syncthreads();
       const int nc = sh_cnt[PK_T];
       __syncthreads();
       // ---- _select_by_peak_distance: highest first, equal priority -> later index first
       const int dist = a.min_dist < 1 ? 1 : a.min_dist;
+      if (nc <= PK_T * PK_CR) {
+        // the usual read: every candidate (position, value) lives in a register of one thread for the whole loop -- no memory access in it; the
+        // winner of a round is found by wave shuffles and one barrier (the four wave results alternate between two LDS rows).  Candidate
+        // positions are distinct and ascending in the candidate index, so "equal value: the later index" is "the larger position".
+        double cv[PK_CR]; int cp[PK_CR];
+#pragma unroll
+        for (int u = 0; u < PK_CR; ++u) { const int c = tid + u * PK_T; cp[u] = c < nc ? cand[c] : -1; cv[u] = c < nc ? x[max(cp[u], 0)] : -1.0e308; }
+        for (int round = 0;; ++round) {
+          double bv = -1.0e308; int bp = -1;
+#pragma unroll
+          for (int u = 0; u < PK_CR; ++u) if (cp[u] >= 0 && (bp < 0 || cv[u] > bv || (cv[u] == bv && cp[u] > bp))) { bv = cv[u]; bp = cp[u]; }
+#pragma unroll
+          for (int o = 32; o >= 1; o >>= 1) {
+            const double ov = __shfl_xor(bv, o); const int op = __shfl_xor(bp, o);
+            if (op >= 0 && (bp < 0 || ov > bv || (ov == bv && op > bp))) { bv = ov; bp = op; }
+          }
+          const int row = (round & 1) * 4;
+          if (lane == 0) { sh_d[row + wv] = bv; sh_idx[row + wv] = bp; }
+          __syncthreads();
+          bv = sh_d[row]; bp = sh_idx[row];
+#pragma unroll
+          for (int q = 1; q < PK_T / 64; ++q) { const double ov = sh_d[row + q]; const int op = sh_idx[row + q]; if (op >= 0 && (bp < 0 || ov > bv || (ov == bv && op > bp))) { bv = ov; bp = op; } }
+          if (bp < 0) break;
+          if (tid == 0 && n_kept < C3_MAX_PEAKS) kept[n_kept] = bp;
+          ++n_kept;
+#pragma unroll
+          for (int u = 0; u < PK_CR; ++u) { int dlt = cp[u] - bp; if (dlt < 0) dlt = -dlt; if (cp[u] >= 0 && dlt < dist) cp[u] = -1; }      // (the winner itself: distance 0)
+        }
+        __syncthreads();
+      } else
       for (;;) {
         double bv = -1.0e308; int bi = -1;
         for (int c = tid; c < nc; c += PK_T)

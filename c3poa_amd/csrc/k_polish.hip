@@ -99,6 +99,7 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
         cells_s += max(0, vhi - max(0, vlo) + 1);
         const int nxt0 = __builtin_amdgcn_update_dpp(NEGK, hprev[0], 0x130, 0xf, 0xf, false);   // wave_shl:1
         int key[EC], y[EC];
+        bool valm[EC];
         int run = NEGK;
 #pragma unroll
         for (int cc = 0; cc < EC; ++cc) {
@@ -107,6 +108,7 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
           const int up = (cc + 1 < EC) ? hprev[cc + 1 < EC ? cc + 1 : cc] : nxt0;
           const int k = max(kd, up + (g4 + 2));
           const bool val = (unsigned)(bb0 + cc - vlo) <= span && vhi >= vlo && bb0 + cc >= 0;
+          valm[cc] = val;
           key[cc] = val ? k : NEGK;
           y[cc] = (key[cc] & ~3) - (g4bb1[cc] - 1);
           run = max(run, y[cc]);
@@ -120,7 +122,7 @@ __device__ long long extend_align(const PrepArgs& a, const uint32_t* pk, const u
           // an invalid cell is re-masked because ex can be a real score)
           int k2 = max(key[cc], ex + g4bb1[cc]);
           ex = max(ex, y[cc]);
-          k2 = key[cc] == NEGK ? NEGK : k2;
+          k2 = valm[cc] ? k2 : NEGK;                                        // (the first loop's mask again: comparing the key with NEGK cost a v_cmp per cell, 6 % of the kernel)
           const int hh = k2 & ~3;
           hprev[cc] = hh;
           const unsigned tag = (unsigned)k2 & 3u;                           // 3 diag, 2 up, 1 left, 0 invalid
