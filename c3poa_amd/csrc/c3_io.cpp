@@ -979,7 +979,7 @@ extern "C" int c3_reader_next_set(c3_reader* r, int set, int max_reads, int64_t 
     s.name_off.push_back((int64_t)nn); s.off.push_back((int64_t)nb);
   }
   if (r->bz && r->bz->bad) return fail(r, "BGZF input: a member is damaged (header, size, inflate or CRC)");      // never a silently short file
-  if (r->gz_bad) return fail(r, "gzip input: the stream is damaged (inflate, CRC or length check)");
+  if (r->gz_bad) return fail(r, "gzip input: the stream is damaged (inflate, CRC or length check; with several inflating threads also: 2 MiB of input that inflate to more than 1 GiB -- C3_GZ_SERIAL=1 reads such a file)");
   s.n_names = nn; s.n_bases = nb;
   r->hint_bases = std::max(r->hint_bases, nb);
   out->n = n; out->n_short = n_short;
