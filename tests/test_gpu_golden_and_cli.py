@@ -177,3 +177,39 @@ def test_full_size_cfg2_properties():
     assert [cons[i] for i in idx] == ocons
     ident = [synth.identity(cons[i], recs[i][3]) for i in idx[:24] if cons[i]]
     assert np.mean(ident) > 0.96
+
+
+def _bumpy_track(rng, n, spacing, ties):
+    """narrow bumps every `spacing` points on a low noisy floor: the median stays at the floor, every bump is a candidate"""
+    x = np.arange(n)
+    tr = np.abs(rng.normal(40, 12, n))
+    centres = np.arange(spacing // 2, n - 20, spacing) + rng.integers(-spacing // 8, spacing // 8 + 1, size=len(np.arange(spacing // 2, n - 20, spacing)))
+    amps = np.full(len(centres), 3000.0) if ties else rng.uniform(1500, 6000, len(centres))
+    for c, a_ in zip(centres, amps):
+        lo, hi = max(0, c - 40), min(n, c + 41)
+        tr[lo:hi] += a_ * np.exp(-0.5 * ((x[lo:hi] - c) / 9.0) ** 2)
+    tr = tr.astype(np.int32)
+    return (tr // 32) * 32 if ties else tr
+
+
+def test_call_peaks_with_few_and_with_many_candidates_equals_the_oracle():
+    """k_peaks keeps up to 512 candidates in registers for the suppression loop and walks memory beyond that: tracks with tens, hundreds and
+    more than a thousand local maxima above the height gate, equal values and plateaus (later candidate first), small and large distances:
+    HIP == oracle"""
+    from c3poa_amd import _lib
+    from oracle import oracle_py as O
+    rng = np.random.default_rng(2024)
+    h = _lib.Handle()
+    seen = {"registers": 0, "memory": 0}
+    for n, spacing, ties in ((8000, 700, False), (60000, 150, False), (60000, 150, True), (200000, 150, False), (200000, 130, True), (120000, 260, False)):
+        tr = _bumpy_track(rng, n, spacing, ties)
+        n_cand = len(O.call_peaks(tr, 1))                 # (distance 1 keeps every candidate -- more than the 250 a read may have is the oracle's LIMIT too: only counted here)
+        for md in (300, 1500, 4000):
+            want = O.call_peaks(tr, md).tolist()
+            if len(want) >= 250:
+                continue
+            got = h.call_peaks(tr, md).tolist()
+            assert got == want, (n, spacing, ties, md, len(got), len(want))
+            seen["memory" if n // spacing > 512 else "registers"] += len(want) > 0
+    assert seen["registers"] >= 3 and seen["memory"] >= 3, seen
+    h.close()
