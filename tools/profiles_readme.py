@@ -71,6 +71,8 @@ NOTES = {   # what each further file of the round is (facts about HOW it was mad
     "gzip_parallel_decoder_round_phases.txt": "`tools/gzpar_prof.cpp` (phase times per round) with 16 threads: find 2.7 ms, decode 12-15, convert 1.1 per round of 16 x 2 MiB; a round of 32 chunks takes twice its phases' sum standalone -- the harness frees 32 touched 8.5 MB buffers before the next round, which is what the reader's recycling removes",
     "cli_2m_gz1_final_reader.log": "`tools/cli_throughput.py 2000000 --gz --gz-level 1 --ab C3_GZ_ROUND=16`: the decoder's slow case (dense marks) with the final reader, 159-176 k reads/s; 130-132 k with 16 chunks per round",
     "inflate_bench_gpu_box_host.txt": "`tools/inflate_bench.py 200000`: the reader alone -- one `gzip -6` member 31 k (zlib) / 49.6 k (own decoder, one thread) / **207-219 k reads/s** (several inflating threads, 2.1 GB of FASTQ per second: the one parser thread behind them); BGZF 172-191 k (150-158 k in round 5: its members' CRC-32 by carry-less multiplication)",
+    "cli_2m_bgzf_inflating_threads_ab.log": "`tools/cli_throughput.py 2000000 --bgzf --ab C3_GZ_THREADS=16`: BGZF input with 8 inflating threads (the default until then) 167 k reads/s, with 16 (the default since) **223-244 k**",
+    "host_ceiling_gz_bgzf.txt": "`tools/host_ceiling.py 1000000 --gz / --bgzf` with the reader's wait time (`C3_STREAM_STATS`): 135 k reads/s on both (27.5 k on gzip in round 4); the one parser thread waits 3.2-3.4 s of its 5.5 s for inflated bytes; BGZF with 8 / 12 / 16 inflating threads 119-124 / 139 / 153-160 k",
     "cli_2m_gz6.log": "`tools/cli_throughput.py 2000000 --gz --gz-level 6 --ab C3_GZ_SERIAL`: ONE gzip member at level 6 (deflated in pieces by the process pool, each ended by a sync flush), parallel decoder against the single-thread one, alternating",
     "cli_3m_tmpfs.log": "`tools/cli_throughput.py 3000000 --dir /dev/shm` with the round's library",
     "cli_1m_tmpfs_window_consumer_ab.log": "`tools/cli_throughput.py 1000000 --dir /dev/shm --ab C3_NO_WIN_CONSUMER`: four cold processes",
