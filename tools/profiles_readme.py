@@ -65,7 +65,7 @@ NOTES = {   # what each further file of the round is (facts about HOW it was mad
     "gzip_parallel_decoder_throughput_index_plane.txt": "the same script with the decoder's final form (bytes + bitmap + 16-bit index plane): `gzip -6` 353 / 1 074 / 1 890 / 3 404 MB/s with 1 / 4 / 8 / 16 threads at 1 MiB chunks, 4 296 at 2 MiB (the default since), 3 730 at 4 MiB, 1 904 at 8 MiB; the same reads through `gzip -1`: 1 913 (1 MiB) - 2 214 (4 MiB) MB/s with 16 threads",
     "cli_2m_gz_index_plane_chunk_ab.log": "`tools/cli_throughput.py 2000000 --gz --ab C3_GZ_CHUNK=4194304` (`gzip -1` input): 125-145 k reads/s with 1 MiB chunks, 128-129 k with 4 MiB -- the parse stage (waiting for the inflating threads) is 12.3 s in all four runs",
     "cli_2m_gz_sorted_marks_rejected.log": "the intermediate decoder (marks in a position-sorted list) on `gzip -1` input: 61 k reads/s, half of what it replaced -- why the index plane exists",
-    "gpu_tests_and_smoke_final_tree.txt": "`pytest -m gpu` (93 passed, 1 skipped: the two-GPU CLI test on a one-GPU box) and `__graft_entry__.smoke()` on the round's final tree, in the same call as `r06_bench_default.json`",
+    "gpu_tests_and_smoke_final_tree.txt": "`pytest -m gpu` (94 passed, 1 skipped: the two-GPU CLI test on a one-GPU box) and `__graft_entry__.smoke()` on the round's final tree, in the same call as `r06_bench_default.json`",
     "ab_peaks_registers_ballots_occupancy.txt": "`k_peaks` with the suppression loop in registers, ballot-compacted candidates and 7-8 workgroups per CU: 3.74 -> 3.60 ms per 32 768 cfg2 reads at 7 workgroups (3.85 at 6) -- first kept as a patch, shipped at 7 workgroups in the round's last kernel commit with `k_prep`'s mask reuse (4.65 -> 4.32 ms)",
     "cli_2m_gz6_chunks_per_round_ab.log": "`tools/cli_throughput.py 2000000 --gz --ab C3_GZ_ROUND=...` on one `gzip -6` member: 16 against 32 chunks per round with recycled buffers 175-181 k -> 197-200 k reads/s; the same A/B before recycling (147-152 -> 168-173 k, another box); 32 against 48: no change",
     "gzip_parallel_decoder_round_phases.txt": "`tools/gzpar_prof.cpp` (phase times per round) with 16 threads: find 2.7 ms, decode 12-15, convert 1.1 per round of 16 x 2 MiB; a round of 32 chunks takes twice its phases' sum standalone -- the harness frees 32 touched 8.5 MB buffers before the next round, which is what the reader's recycling removes",
