@@ -73,6 +73,7 @@ NOTES = {   # what each further file of the round is (facts about HOW it was mad
     "inflate_bench_gpu_box_host.txt": "`tools/inflate_bench.py 200000`: the reader alone -- one `gzip -6` member 31 k (zlib) / 49.6 k (own decoder, one thread) / **207-219 k reads/s** (several inflating threads, 2.1 GB of FASTQ per second: the one parser thread behind them); BGZF 172-191 k (150-158 k in round 5: its members' CRC-32 by carry-less multiplication)",
     "cli_2m_bgzf_inflating_threads_ab.log": "`tools/cli_throughput.py 2000000 --bgzf --ab C3_GZ_THREADS=16`: BGZF input with 8 inflating threads (the default until then) 167 k reads/s, with 16 (the default since) **223-244 k**",
     "host_ceiling_gz_bgzf.txt": "`tools/host_ceiling.py 1000000 --gz / --bgzf` with the reader's wait time (`C3_STREAM_STATS`): 135 k reads/s on both (27.5 k on gzip in round 4); the one parser thread waits 3.2-3.4 s of its 5.5 s for inflated bytes; BGZF with 8 / 12 / 16 inflating threads 119-124 / 139 / 153-160 k",
+    "cli_2m_bgzf_parser_prefetch_ab.log": "`tools/cli_throughput.py 2000000 --bgzf --ab C3_PARSE_PREFETCH=...`: the parser's prefetch cursor (16 KiB default) against 64 KiB and against none -- 192-252 k reads/s whatever the setting: inside the command line's run-to-run spread",
     "cli_2m_gz6.log": "`tools/cli_throughput.py 2000000 --gz --gz-level 6 --ab C3_GZ_SERIAL`: ONE gzip member at level 6 (deflated in pieces by the process pool, each ended by a sync flush), parallel decoder against the single-thread one, alternating",
     "cli_3m_tmpfs.log": "`tools/cli_throughput.py 3000000 --dir /dev/shm` with the round's library",
     "cli_1m_tmpfs_window_consumer_ab.log": "`tools/cli_throughput.py 1000000 --dir /dev/shm --ab C3_NO_WIN_CONSUMER`: four cold processes",
